@@ -1,0 +1,62 @@
+"""AMP-format mocap loader and column map.
+
+Same surface as the reference's loader (/root/reference/diffphys/dataloader.py:9-31):
+``DataLoader(opts)`` exposes ``amp_info`` [frames, 85], ``frame_interval`` and
+``data_info["offset"]``; ``parse_amp`` slices the AMP row; ``bullet2gl`` is the
+axis change of /root/reference/diffphys/dp_utils.py:141-156.
+"""
+import json
+import os
+
+import numpy as np
+
+
+class DataLoader:
+    def __init__(self, opts, cap=-1, data_root="./data/motion_sequences"):
+        seq = opts["seqname"]
+        path = os.path.join(data_root, seq, "amp-%s.txt" % seq)
+        if os.path.exists(path):
+            with open(path, "r") as f:
+                d = json.load(f)
+            self.frame_interval = d["FrameDuration"]
+            self.amp_info = np.asarray(d["Frames"])
+        else:  # compiled fixture (scripts/compile_templates.py)
+            from .robots import TEMPLATE_DIR
+
+            with np.load(os.path.join(TEMPLATE_DIR, "mocap_laikago.npz")) as z:
+                self.amp_info = z[seq + "/frames"]
+                self.frame_interval = float(z[seq + "/frame_duration"])
+        self.data_info = {"offset": np.asarray([0, len(self.amp_info)])}
+
+
+def parse_amp(amp_info):
+    return {
+        "pos": amp_info[..., 0:3],
+        "orn": amp_info[..., 3:7],
+        "vel": amp_info[..., 31:34],
+        "avel": amp_info[..., 34:37],
+        "jang": amp_info[..., 7:19],
+        "jvel": amp_info[..., 37:49],
+        "kp": amp_info[..., 61:73],
+        "kp_vel": amp_info[..., 73:85],
+    }
+
+
+_ISAAC_TO_GL = np.asarray([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+
+
+def bullet2gl(msm, in_bullet):
+    """In place: (x,y,z) -> (y,z,x) on pos / quaternion vector part / vel / avel."""
+    m = _ISAAC_TO_GL
+    msm["pos"] = msm["pos"] @ m.T
+    if in_bullet:
+        from scipy.spatial.transform import Rotation as R
+
+        shape = msm["orn"].shape[:-1]
+        orn = R.from_quat(msm["orn"].reshape((-1, 4))).as_matrix()
+        msm["orn"] = R.from_matrix(orn @ m).as_quat().reshape(shape + (4,))
+    orn = np.array(msm["orn"], copy=True)
+    orn[..., :3] = orn[..., :3] @ m.T
+    msm["orn"] = orn
+    msm["vel"] = msm["vel"] @ m.T
+    msm["avel"] = msm["avel"] @ m.T
