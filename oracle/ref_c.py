@@ -1,0 +1,120 @@
+"""ORACLE (test infrastructure): ctypes binding of oracle/ref_c/diffphys_ref.c.
+
+``RefC(tpl, dtype)`` wraps one compiled precision (np.float32 / np.float64) and
+exposes rollout forward / backward and FK forward / backward on numpy arrays in
+the reference's flat env-major layouts.  See the C file's header for what it
+restates and why parity is unpinned.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_c")
+
+
+def build(force=False):
+    libs = [os.path.join(_DIR, "libdiffphys_ref_f32.so"), os.path.join(_DIR, "libdiffphys_ref_f64.so")]
+    src = os.path.join(_DIR, "diffphys_ref.c")
+    stale = force or any((not os.path.exists(l)) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs)
+    if stale:
+        subprocess.check_call(["make", "-C", _DIR, "-s", "-B"] if force else ["make", "-C", _DIR, "-s"])
+    return libs
+
+
+class RefC:
+    def __init__(self, tpl, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        name = "libdiffphys_ref_f32.so" if self.dtype == np.float32 else "libdiffphys_ref_f64.so"
+        path = os.path.join(_DIR, name)
+        if not os.path.exists(path):
+            build()
+        self.lib = ctypes.CDLL(path)
+        self.real = ctypes.c_float if self.dtype == np.float32 else ctypes.c_double
+        assert self.lib.ref_sizeof_real() == self.dtype.itemsize
+        self.lib.ref_template_create.restype = ctypes.c_void_p
+        self.nb, self.nq, self.nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+        f = lambda k: np.ascontiguousarray(tpl[k], dtype=self.dtype)
+        i = lambda k: np.ascontiguousarray(tpl[k], dtype=np.int32)
+        self._keep = [
+            i("joint_type"), i("joint_parent"), i("joint_q_start"), i("joint_qd_start"), f("joint_X_p"), f("joint_X_c"),
+            f("joint_axis"), f("body_com"), f("joint_limit_lower"), f("joint_limit_upper"), f("joint_limit_ke"),
+            f("joint_limit_kd"), i("contact_body"), f("contact_point"), f("contact_dist"), i("contact_material"),
+            f("shape_materials"), f("gravity"),
+        ]
+        nc, nmat = len(tpl["contact_body"]), len(tpl["shape_materials"])
+        args = [ctypes.c_int(v) for v in (self.nb, self.nq, self.nqd, nc, nmat)]
+        args += [a.ctypes.data_as(ctypes.c_void_p) for a in self._keep]
+        args += [self.real(float(tpl["joint_attach_ke"])), self.real(float(tpl["joint_attach_kd"]))]
+        self.h = ctypes.c_void_p(self.lib.ref_template_create(*args))
+
+    def __del__(self):
+        try:
+            self.lib.ref_template_destroy(self.h)
+        except Exception:
+            pass
+
+    def num_threads(self):
+        return int(self.lib.ref_num_threads())
+
+    def _p(self, a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def _c(self, a):
+        return np.ascontiguousarray(a, dtype=self.dtype)
+
+    def rollout_forward(self, inp, nsteps, frame2step, dt):
+        nb = self.nb
+        bs = inp["q_init"].size // self.nq
+        F = len(frame2step)
+        a = {k: self._c(inp[k]) for k in ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd",
+                                          "body_inv_mass", "body_inertia", "body_inv_inertia")}
+        f2s = np.ascontiguousarray(frame2step, dtype=np.int32)
+        z = lambda *s: np.zeros(s, dtype=self.dtype)
+        st = dict(states_q=z(nsteps + 1, bs * nb, 7), states_qd=z(nsteps + 1, bs * nb, 6), states_f=z(nsteps, bs * nb, 6),
+                  wp_pos=z(F, bs * nb, 7), wp_vel=z(F, bs * nb, 6), grf=z(F, bs * nb, 6), jaf=z(F, bs * nb, 6))
+        self.lib.ref_rollout_forward(
+            self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self.real(dt), self._p(a["q_init"]), self._p(a["qd_init"]),
+            self._p(a["torques"]), self._p(a["res_f"]), self._p(a["refs"]), self._p(a["target_ke"]), self._p(a["target_kd"]),
+            self._p(a["body_inv_mass"]), self._p(a["body_inertia"]), self._p(a["body_inv_inertia"]), ctypes.c_int(F),
+            self._p(f2s), self._p(st["states_q"]), self._p(st["states_qd"]), self._p(st["states_f"]), self._p(st["wp_pos"]),
+            self._p(st["wp_vel"]), self._p(st["grf"]), self._p(st["jaf"]))
+        st["_inputs"] = a
+        st["_f2s"] = f2s
+        st["_bs"], st["_nsteps"], st["_dt"] = bs, nsteps, dt
+        return st
+
+    def rollout_backward(self, st, adj_pos, adj_vel):
+        a, bs, nsteps = st["_inputs"], st["_bs"], st["_nsteps"]
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        z = lambda *s: np.zeros(s, dtype=self.dtype)
+        g = dict(q_init=z(bs * nq), qd_init=z(bs * nqd), torques=z(nsteps, bs * nqd), res_f=z(nsteps, bs * nb, 6),
+                 refs=z(nsteps, bs * nqd), target_ke=z(bs * nqd), target_kd=z(bs * nqd), body_mass=z(bs * nb),
+                 body_inv_mass=z(bs * nb), body_inertia=z(bs * nb, 3, 3), body_inv_inertia=z(bs * nb, 3, 3))
+        ap, av = self._c(adj_pos), self._c(adj_vel)
+        self.lib.ref_rollout_backward(
+            self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self.real(st["_dt"]), self._p(a["q_init"]), self._p(a["qd_init"]),
+            self._p(a["torques"]), self._p(a["refs"]), self._p(a["target_ke"]), self._p(a["target_kd"]),
+            self._p(a["body_inv_mass"]), self._p(a["body_inertia"]), self._p(a["body_inv_inertia"]),
+            ctypes.c_int(len(st["_f2s"])), self._p(st["_f2s"]), self._p(st["states_q"]), self._p(st["states_qd"]),
+            self._p(st["states_f"]), self._p(ap), self._p(av), self._p(g["q_init"]), self._p(g["qd_init"]),
+            self._p(g["torques"]), self._p(g["res_f"]), self._p(g["refs"]), self._p(g["target_ke"]), self._p(g["target_kd"]),
+            self._p(g["body_inv_mass"]), self._p(g["body_inertia"]), self._p(g["body_inv_inertia"]))
+        return g
+
+    def fk_forward(self, joint_q, joint_qd):
+        """joint_q [n,nq], joint_qd [n,nqd] -> body_q [n,nb,7], body_qd [n,nb,6]"""
+        jq, jqd = self._c(joint_q), self._c(joint_qd)
+        n = jq.shape[0]
+        bq, bqd = np.zeros((n, self.nb, 7), self.dtype), np.zeros((n, self.nb, 6), self.dtype)
+        self.lib.ref_fk_forward(self.h, ctypes.c_int(n), self._p(jq), self._p(jqd), self._p(bq), self._p(bqd))
+        return bq, bqd
+
+    def fk_backward(self, joint_q, joint_qd, body_q, adj_body_q, adj_body_qd):
+        jq, jqd, bq = self._c(joint_q), self._c(joint_qd), self._c(body_q)
+        n = jq.shape[0]
+        gq, gqd = np.zeros((n, self.nq), self.dtype), np.zeros((n, self.nqd), self.dtype)
+        self.lib.ref_fk_backward(self.h, ctypes.c_int(n), self._p(jq), self._p(jqd), self._p(bq),
+                                 self._p(self._c(adj_body_q)), self._p(self._c(adj_body_qd)), self._p(gq), self._p(gqd))
+        return gq, gqd
