@@ -1,0 +1,120 @@
+/*
+ * ppr_diffphys.h -- C ABI of libpprdiffphys_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the ONE hot path of gengshan-y/ppr-diffphys:
+ * the batched semi-implicit-Euler rigid-body rollout, its reverse-mode adjoint,
+ * and forward kinematics.  Plain pointers and sizes only; every `float*` /
+ * `int*` argument named *_dev is DEVICE memory (HBM) owned by the caller
+ * (in the Python host: torch tensors), `stream` is a hipStream_t passed as void*.
+ * All functions return 0 on success, non-zero on error (pd_last_error() has the text).
+ * Nothing here allocates, frees or synchronises in the launch path (graph-capturable);
+ * only pd_model_create / pd_model_destroy touch the allocator.
+ *
+ * What each entry point replaces in the reference (file:line under /root/reference):
+ *
+ *   pd_model_create      wp.sim.ModelBuilder.finalize + Model.collide
+ *                        (diffphys/dp_model.py:384-401; arrays per SURVEY.md App. A.2)
+ *   pd_rollout_forward   ForwardWarp.forward (diffphys/dp_model.py:1146-1249): eval_fk, then per step
+ *                        clear_forces + wp_add (:1210-1221) + SemiImplicitIntegrator.simulate
+ *                        (diffphys/integrator_euler.py:579-620: eval_body_contacts :93-179,
+ *                        eval_body_joints :289-451, integrate_bodies :21-91), frame gather (:1241-1248)
+ *   pd_rollout_backward  ForwardWarp.backward (diffphys/dp_model.py:1251-1400): wp.Tape.backward over the
+ *                        same launches, gradients of the 11 inputs
+ *   pd_fk_forward/backward  ForwardKinematics.forward/backward (diffphys/dp_model.py:1022-1130),
+ *                        i.e. warp.sim.articulation.eval_fk and its tape adjoint
+ *
+ * Layouts are the reference's flat env-major ones:
+ *   q_init [bs*nq]   qd_init [bs*nqd] (root twist as (w, v))
+ *   torques, refs [T][bs*nqd]         res_f [T][bs*nb][6] (tau, f)
+ *   target_ke, target_kd [bs*nqd]     body_mass, body_inv_mass [bs*nb]
+ *   body_inertia, body_inv_inertia [bs*nb][3][3] row-major
+ *   wp_pos [F][bs*nb][7] (p, q=xyzw)  wp_vel [F][bs*nb][6] (w, v)   grf, jaf [F][bs*nb][6]
+ * The saved trajectory (workspace) is internal SoA: see pd_rollout_workspace_floats.
+ */
+#ifndef PPR_DIFFPHYS_H
+#define PPR_DIFFPHYS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PD_ABI_VERSION 1
+
+/* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
+typedef struct pd_model_desc {
+  int nb, nq, nqd;              /* bodies (= joints), joint coords, joint dofs per env */
+  int nc, nmat;                 /* ground-contact candidate points, materials */
+  const int *joint_type;        /* [nb] Warp codes: 1 revolute, 3 fixed, 4 free, 5 compound */
+  const int *joint_parent;      /* [nb] -1 for the root; parents precede children */
+  const int *joint_q_start;     /* [nb] */
+  const int *joint_qd_start;    /* [nb] */
+  const float *joint_X_p;       /* [nb][7] parent-frame joint transform (p, q) */
+  const float *joint_X_c;       /* [nb][7] child-frame joint transform */
+  const float *joint_axis;      /* [nb][3] */
+  const float *body_com;        /* [nb][3] */
+  const float *joint_limit_lower, *joint_limit_upper, *joint_limit_ke, *joint_limit_kd; /* [nqd] */
+  const int *contact_body;      /* [nc] body index of each candidate point */
+  const float *contact_point;   /* [nc][3] body frame */
+  const float *contact_dist;    /* [nc] shape thickness */
+  const int *contact_material;  /* [nc] index into shape_materials */
+  const float *shape_materials; /* [nmat][4] (ke, kd, kf, mu) */
+  float gravity[3];
+  float joint_attach_ke, joint_attach_kd;
+} pd_model_desc;
+
+typedef struct pd_model pd_model; /* opaque; owns the device copy of the template */
+
+int pd_abi_version(void);
+const char *pd_last_error(void);
+
+int pd_model_create(const pd_model_desc *desc, pd_model **out);
+void pd_model_destroy(pd_model *m);
+/* Lanes of a 64-wide wavefront given to one articulation: 16, 32 or 64 (>= nb).  0 = default
+ * (smallest that fits).  64 is the literal "one articulation per wavefront" mapping. */
+int pd_model_set_segment_width(pd_model *m, int lanes);
+int pd_model_get_segment_width(const pd_model *m);
+
+/* Floats of caller-provided workspace that pd_rollout_forward fills and pd_rollout_backward reads:
+ * per step the 13-float body state and the 6-float body wrench, SoA planes [step][component][bs*nb]. */
+size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps);
+
+/* frame_of_step_dev: [nsteps+1] ints, frame index whose output is state `step`, or -1. */
+int pd_rollout_forward(const pd_model *m, int bs, int nsteps, float dt,
+                       const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
+                       const float *res_f_dev, const float *refs_dev, const float *target_ke_dev,
+                       const float *target_kd_dev, const float *body_inv_mass_dev,
+                       const float *body_inertia_dev, const float *body_inv_inertia_dev,
+                       int nframes, const int *frame_of_step_dev, float *workspace_dev,
+                       float *wp_pos_dev, float *wp_vel_dev, float *grf_dev, float *jaf_dev, void *stream);
+
+/* Gradients are OVERWRITTEN (not accumulated).  g_*_dev mirror the input shapes.  body_mass has no
+ * direct gradient (integrator_euler.py:43 loads it, nothing uses it), so there is no g_body_mass. */
+int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
+                        const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
+                        const float *refs_dev, const float *target_ke_dev, const float *target_kd_dev,
+                        const float *body_inv_mass_dev, const float *body_inertia_dev,
+                        const float *body_inv_inertia_dev, int nframes, const int *frame_of_step_dev,
+                        const float *workspace_dev, const float *adj_pos_dev, const float *adj_vel_dev,
+                        float *g_q_init_dev, float *g_qd_init_dev, float *g_torques_dev, float *g_res_f_dev,
+                        float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
+                        float *g_body_inv_mass_dev, float *g_body_inertia_dev, float *g_body_inv_inertia_dev,
+                        void *stream);
+
+/* n independent articulations: joint_q [n][nq], joint_qd [n][nqd] -> body_q [n][nb][7], body_qd [n][nb][6] */
+int pd_fk_forward(const pd_model *m, int n, const float *joint_q_dev, const float *joint_qd_dev,
+                  float *body_q_dev, float *body_qd_dev, void *stream);
+int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const float *joint_qd_dev,
+                   const float *adj_body_q_dev, const float *adj_body_qd_dev,
+                   float *g_joint_q_dev, float *g_joint_qd_dev, void *stream);
+
+/* Average device time (ms) of the last `kind` launch measured with hipEvents on its stream:
+ * kind 0 = rollout forward, 1 = rollout backward.  Enabled by pd_set_timing(1); used by bench.py. */
+void pd_set_timing(int on);
+float pd_last_kernel_ms(int kind);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

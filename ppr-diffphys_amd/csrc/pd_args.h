@@ -1,0 +1,38 @@
+// Kernel argument blocks and launcher prototypes shared by the kernel TUs and the host TU.
+#pragma once
+#include "pd_device.h"
+
+#define PD_BLOCK 256
+#define PD_WAVES (PD_BLOCK / 64)
+
+enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
+
+struct RolloutArgs {
+  int bs, nsteps, nframes;
+  float dt;
+  const float *q_init, *qd_init, *torques, *res_f, *refs, *target_ke, *target_kd, *inv_mass, *inertia, *inv_inertia;
+  const int *frame_of_step;
+  float *ws;                           // workspace: traj_q [T][7][N], traj_qd [T][6][N], traj_f [T][6][N], N = bs*nb
+  float *wp_pos, *wp_vel, *grf, *jaf;  // forward outputs (grf/jaf may be null)
+  // backward only
+  const float *adj_pos, *adj_vel;
+  float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
+};
+
+
+// Batched FK (ForwardKinematics, dp_model.py:1022-1130 of the reference): n articulations, one per segment.
+struct FkArgs {
+  int n;
+  const float *joint_q, *joint_qd;
+  float *body_q, *body_qd;                 // forward outputs [n][nb][7] / [n][nb][6]
+  const float *adj_body_q, *adj_body_qd;   // backward inputs
+  float *g_joint_q, *g_joint_qd;           // backward outputs
+};
+
+
+hipError_t pd_launch_seg16(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st);
+hipError_t pd_launch_seg32(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st);
+hipError_t pd_launch_seg64(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st);
+hipError_t pd_set_lds_seg16(int jt, int bytes);
+hipError_t pd_set_lds_seg32(int jt, int bytes);
+hipError_t pd_set_lds_seg64(int jt, int bytes);

@@ -1,0 +1,584 @@
+// Device-side model view + the per-lane physics of one sim step and its adjoint.
+//
+// Mapping: a 64-lane wavefront is cut into 64/SEGW segments; one
+// articulation (env) per segment, lane l of a segment owns body l (l < nb) for the per-body
+// passes (joints, integration) and is one of SEGW sweep lanes for the per-contact-point pass.
+// Body state lives in registers for the whole rollout; the kinematic chain (what a child needs
+// from its parent, what a parent receives from its children) is staged through LDS records
+// private to the segment, so no cross-wave synchronisation is ever needed.
+//
+// What is computed follows /root/reference/diffphys/integrator_euler.py (cited per function).
+#pragma once
+#include "pd_math.h"
+
+enum { PD_JOINT_REVOLUTE = 1, PD_JOINT_FIXED = 3, PD_JOINT_FREE = 4, PD_JOINT_COMPOUND = 5 };
+enum { PD_JT_REVOLUTE = 1, PD_JT_COMPOUND = 2, PD_JT_FIXED = 4 };  // template mask bits
+
+#define PD_REC 20  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16] Ry[16:19]
+#define PD_ADJ 13  // floats of a body-state adjoint: p q w v
+
+struct PdDevModel {
+  int nb, nq, nqd, nc, nc_pad, nchunks, max_children, max_depth;
+  const int *jtype, *jparent, *qstart, *qdstart, *depth;  // [nb]
+  const unsigned long long *children;                     // [nb] 8 child ids packed, 0xff = none
+  const float *X_p, *X_c, *axis, *com;                    // [nb*7] [nb*7] [nb*3] [nb*3]
+  const float *lim_lo, *lim_hi, *lim_ke, *lim_kd;         // [nqd]
+  const float4 *pts;                                      // [nc_pad] (x,y,z,dist), sorted by body
+  const unsigned char *pt_body;                           // [nc_pad]
+  const float4 *pt_mat;                                   // [nc_pad] (ke,kd,kf,mu)
+  const float4 *body_sphere;                              // [nb] centre + radius (r < 0: no points)
+  const float4 *chunk_sphere;                             // [nchunks] (r < 0: spans several bodies)
+  const unsigned long long *chunk_mask;                   // [nchunks] bodies present in the chunk
+  float gx, gy, gz, attach_ke, attach_kd;
+  int env_lds_floats;                                     // per-env LDS scratch
+};
+
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+struct BodyState { v3 p; qt r; v3 w; v3 v; };
+struct BodyAdj { v3 p; qt r; v3 w; v3 v; };
+
+PD_DEV BodyAdj adj_zero() {
+  BodyAdj a;
+  a.p = V3(0, 0, 0); a.r = Q4(0, 0, 0, 0); a.w = V3(0, 0, 0); a.v = V3(0, 0, 0);
+  return a;
+}
+PD_DEV void adj_store(float *s, const BodyAdj &a) {
+  s[0] = a.p.x; s[1] = a.p.y; s[2] = a.p.z; s[3] = a.r.x; s[4] = a.r.y; s[5] = a.r.z; s[6] = a.r.w;
+  s[7] = a.w.x; s[8] = a.w.y; s[9] = a.w.z; s[10] = a.v.x; s[11] = a.v.y; s[12] = a.v.z;
+}
+PD_DEV void adj_add_from(BodyAdj &a, const float *s) {
+  a.p.x += s[0]; a.p.y += s[1]; a.p.z += s[2]; a.r.x += s[3]; a.r.y += s[4]; a.r.z += s[5]; a.r.w += s[6];
+  a.w.x += s[7]; a.w.y += s[8]; a.w.z += s[9]; a.v.x += s[10]; a.v.y += s[11]; a.v.z += s[12];
+}
+
+PD_DEV v3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
+PD_DEV qt ld4(const float *p) { return Q4(p[0], p[1], p[2], p[3]); }
+
+// Per-lane constants of body l (registers for the whole rollout).
+struct BodyConst {
+  int type, parent, qstart, qdstart, depth;
+  unsigned long long children;
+  v3 com, axis, p_pj, com_par;
+  qt q_pj, q_off;
+};
+
+PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
+  BodyConst c;
+  c.type = m.jtype[b]; c.parent = m.jparent[b]; c.qstart = m.qstart[b]; c.qdstart = m.qdstart[b];
+  c.depth = m.depth[b]; c.children = m.children[b];
+  c.com = ld3(m.com + b * 3); c.axis = ld3(m.axis + b * 3);
+  c.p_pj = ld3(m.X_p + b * 7); c.q_pj = ld4(m.X_p + b * 7 + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
+  c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
+  return c;
+}
+
+PD_DEV void stage_record(float *rec, int b, const BodyState &s, v3 com) {
+  float *r = rec + b * PD_REC;
+  v3 rc = qrot(s.r, com);
+  v3 Ry = qrot_inv(s.r, V3(0.f, 1.f, 0.f));  // second row of R(q): world-y of a body-frame point is Ry . x
+  r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
+  r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
+  r[13] = rc.x; r[14] = rc.y; r[15] = rc.z; r[16] = Ry.x; r[17] = Ry.y; r[18] = Ry.z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward kinematics of one joint (warp.sim.articulation.eval_fk).
+// jq / jqd point at this joint's coordinates; parent state comes from the LDS record.
+struct FkLocals {
+  v3 p_jc, w_jc, v_jc, a0, a1, a2;
+  qt q_jc, q0, q1, q2, q_wj;
+};
+
+template <int JT>
+PD_DEV void fk_joint_local(const BodyConst &c, const float *jq, const float *jqd, FkLocals &L) {
+  L.p_jc = V3(0, 0, 0); L.w_jc = V3(0, 0, 0); L.v_jc = V3(0, 0, 0); L.q_jc = Q4(0, 0, 0, 1);
+  L.a0 = L.a1 = L.a2 = V3(0, 0, 0); L.q0 = L.q1 = L.q2 = Q4(0, 0, 0, 1);
+  if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
+    L.q_jc = q_axis_angle(c.axis, jq[0]);
+    L.w_jc = c.axis * jqd[0];
+  } else if (c.type == PD_JOINT_FREE) {
+    L.p_jc = ld3(jq); L.q_jc = ld4(jq + 3); L.w_jc = ld3(jqd); L.v_jc = ld3(jqd + 3);
+  } else if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
+    L.a0 = qrot(c.q_off, V3(1, 0, 0));
+    L.q0 = q_axis_angle(L.a0, jq[0]);
+    L.a1 = qrot(qmul(L.q0, c.q_off), V3(0, 1, 0));
+    L.q1 = q_axis_angle(L.a1, jq[1]);
+    L.a2 = qrot(qmul(L.q1, qmul(L.q0, c.q_off)), V3(0, 0, 1));
+    L.q2 = q_axis_angle(L.a2, jq[2]);
+    L.q_jc = qmul(L.q2, qmul(L.q1, L.q0));
+    L.w_jc = L.a0 * jqd[0] + L.a1 * jqd[1] + L.a2 * jqd[2];
+  }
+}
+
+template <int JT>
+PD_DEV BodyState fk_joint(const BodyConst &c, const float *jq, const float *jqd, const float *rec) {
+  v3 p_wp = V3(0, 0, 0), w_wp = V3(0, 0, 0), v_wp = V3(0, 0, 0);
+  qt q_wp = Q4(0, 0, 0, 1);
+  if (c.parent >= 0) {
+    const float *r = rec + c.parent * PD_REC;
+    p_wp = ld3(r); q_wp = ld4(r + 3); w_wp = ld3(r + 7); v_wp = ld3(r + 10);
+  }
+  FkLocals L;
+  fk_joint_local<JT>(c, jq, jqd, L);
+  v3 p_wj = p_wp + qrot(q_wp, c.p_pj);
+  qt q_wj = qmul(q_wp, c.q_pj);
+  BodyState s;
+  s.p = p_wj + qrot(q_wj, L.p_jc);
+  s.r = qmul(q_wj, L.q_jc);
+  v3 ang = qrot(q_wj, L.w_jc), lin = qrot(q_wj, L.v_jc);
+  s.w = w_wp + ang;
+  s.v = v_wp + (lin + cross(ang, c.com));
+  return s;
+}
+
+// Adjoint of fk_joint: g = adjoint of this body's (p,q,w,v); writes the joint-coordinate
+// gradients (overwrite) and returns the contribution to the parent's state adjoint.
+template <int JT>
+PD_DEV BodyAdj fk_joint_adj(const BodyConst &c, const float *jq, const float *jqd, const float *rec, const BodyAdj &g,
+                            float *gq, float *gqd) {
+  v3 p_wp = V3(0, 0, 0);
+  qt q_wp = Q4(0, 0, 0, 1);
+  if (c.parent >= 0) {
+    const float *r = rec + c.parent * PD_REC;
+    p_wp = ld3(r); q_wp = ld4(r + 3);
+  }
+  (void)p_wp;
+  FkLocals L;
+  fk_joint_local<JT>(c, jq, jqd, L);
+  qt q_wj = qmul(q_wp, c.q_pj);
+  BodyAdj par = adj_zero();
+  par.w = g.w; par.v = g.v;
+  v3 adj_ang = g.w, adj_lin = g.v;
+  adj_cross_a(c.com, adj_ang, g.v);
+  qt adj_q_wj = Q4(0, 0, 0, 0);
+  v3 adj_w_jc = V3(0, 0, 0), adj_v_jc = V3(0, 0, 0), adj_p_jc = V3(0, 0, 0);
+  adj_qrot(q_wj, L.v_jc, adj_q_wj, adj_v_jc, adj_lin);
+  adj_qrot(q_wj, L.w_jc, adj_q_wj, adj_w_jc, adj_ang);
+  qt adj_q_jc = Q4(0, 0, 0, 0);
+  adj_qmul(q_wj, L.q_jc, adj_q_wj, adj_q_jc, g.r);
+  adj_qrot(q_wj, L.p_jc, adj_q_wj, adj_p_jc, g.p);
+  adj_qmul_a(c.q_pj, par.r, adj_q_wj);
+  par.p = g.p;
+  adj_qrot_q(q_wp, c.p_pj, par.r, g.p);
+  if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
+    float a = 0.f;
+    adj_q_axis_angle_ang(c.axis, jq[0], a, adj_q_jc);
+    gq[0] = a;
+    gqd[0] = dot(c.axis, adj_w_jc);
+  } else if (c.type == PD_JOINT_FREE) {
+    gq[0] = adj_p_jc.x; gq[1] = adj_p_jc.y; gq[2] = adj_p_jc.z;
+    gq[3] = adj_q_jc.x; gq[4] = adj_q_jc.y; gq[5] = adj_q_jc.z; gq[6] = adj_q_jc.w;
+    gqd[0] = adj_w_jc.x; gqd[1] = adj_w_jc.y; gqd[2] = adj_w_jc.z;
+    gqd[3] = adj_v_jc.x; gqd[4] = adj_v_jc.y; gqd[5] = adj_v_jc.z;
+  } else if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
+    float aq0 = 0.f, aq1 = 0.f, aq2 = 0.f;
+    v3 adj_a0 = adj_w_jc * jqd[0], adj_a1 = adj_w_jc * jqd[1], adj_a2 = adj_w_jc * jqd[2];
+    gqd[0] = dot(L.a0, adj_w_jc); gqd[1] = dot(L.a1, adj_w_jc); gqd[2] = dot(L.a2, adj_w_jc);
+    qt q10 = qmul(L.q1, L.q0);
+    qt adj_q2 = Q4(0, 0, 0, 0), adj_q10 = adj_q2, adj_q1 = adj_q2, adj_q0 = adj_q2;
+    adj_qmul(L.q2, q10, adj_q2, adj_q10, adj_q_jc);
+    adj_q_axis_angle(L.a2, jq[2], adj_a2, aq2, adj_q2);
+    qt q0o = qmul(L.q0, c.q_off), q10o = qmul(L.q1, q0o);
+    qt adj_q10o = Q4(0, 0, 0, 0), adj_q0o = adj_q10o;
+    adj_qrot_q(q10o, V3(0, 0, 1), adj_q10o, adj_a2);
+    adj_qmul(L.q1, q0o, adj_q1, adj_q0o, adj_q10o);
+    adj_qmul(L.q1, L.q0, adj_q1, adj_q0, adj_q10);
+    adj_q_axis_angle(L.a1, jq[1], adj_a1, aq1, adj_q1);
+    adj_qrot_q(q0o, V3(0, 1, 0), adj_q0o, adj_a1);
+    adj_qmul_a(c.q_off, adj_q0, adj_q0o);
+    adj_q_axis_angle(L.a0, jq[0], adj_a0, aq0, adj_q0);
+    gq[0] = aq0; gq[1] = aq1; gq[2] = aq2;
+  }
+  return par;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One ground-contact candidate (integrator_euler.py:93-179).  rec = staged record of its body.
+// Returns false when the point is above ground (the kernel's early return, :132-133).
+struct ContactOut { v3 t, f; };
+
+PD_DEV bool contact_point_fwd(const float *r, float4 P, float4 mat, ContactOut &o) {
+  v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
+  qt q = ld4(r + 3);
+  v3 cp = (p + qrot(q, V3(P.x, P.y, P.z))) - V3(0.f, P.w, 0.f);
+  float c = cp.y;
+  if (c > 0.0f) return false;
+  v3 rr = cp - (p + rc);
+  v3 dpdt = v + cross(w, rr);
+  float ke = mat.x, kd = mat.y, kf = mat.z, mu = mat.w;
+  float vn = dpdt.y;
+  v3 vt = V3(dpdt.x, dpdt.y - vn, dpdt.z);
+  float fn = c * ke;
+  float fd = fminf(vn, 0.0f) * kd * (c < 0.0f ? 1.0f : 0.0f);
+  float a_ = kf * length(vt), b_ = 0.0f - mu * (fn + fd);
+  v3 ft = normalize(vt) * (a_ < b_ ? a_ : b_);
+  v3 f = clamp3(V3(ft.x, (fn + fd) + ft.y, ft.z), 500.0f);
+  o.f = f;
+  o.t = cross(rr, f);
+  return true;
+}
+
+// Adjoint: g_t, g_f = adjoint of the body's wrench accumulator; returns the contribution to (p,q,w,v).
+PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 com, v3 g_t, v3 g_f, BodyAdj &out) {
+  v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
+  qt q = ld4(r + 3);
+  v3 cpt = V3(P.x, P.y, P.z);
+  v3 cp = (p + qrot(q, cpt)) - V3(0.f, P.w, 0.f);
+  float c = cp.y;
+  if (c > 0.0f) return false;
+  v3 rr = cp - (p + rc);
+  v3 dpdt = v + cross(w, rr);
+  float ke = mat.x, kd = mat.y, kf = mat.z, mu = mat.w;
+  float vn = dpdt.y;
+  v3 vt = V3(dpdt.x, dpdt.y - vn, dpdt.z);
+  float fn = c * ke;
+  float stepc = c < 0.0f ? 1.0f : 0.0f;
+  float fd = fminf(vn, 0.0f) * kd * stepc;
+  float lvt = length(vt);
+  v3 nvt = normalize(vt);
+  float a_ = kf * lvt, b_ = 0.0f - mu * (fn + fd);
+  float mm = a_ < b_ ? a_ : b_;
+  v3 f_raw = V3(nvt.x * mm, (fn + fd) + nvt.y * mm, nvt.z * mm);
+  v3 fc = clamp3(f_raw, 500.0f);
+  // reverse (body_f -= (t, f))
+  v3 adj_t = -g_t, adj_fc = -g_f, adj_r = V3(0, 0, 0);
+  adj_cross(rr, fc, adj_r, adj_fc, adj_t);
+  v3 adj_fr = clamp3_pass(f_raw, adj_fc, 500.0f);
+  float adj_fnfd = adj_fr.y;
+  v3 adj_nvt = adj_fr * mm;
+  float adj_m = dot(adj_fr, nvt);
+  float adj_lvt = 0.f;
+  if (a_ < b_) adj_lvt = adj_m * kf; else adj_fnfd += -mu * adj_m;
+  v3 adj_vt = V3(0, 0, 0);
+  adj_normalize(vt, adj_vt, adj_nvt);
+  adj_length(vt, adj_vt, adj_lvt);
+  float adj_c = adj_fnfd * ke;
+  float adj_vn = (vn < 0.0f ? 1.0f : 0.0f) * kd * stepc * adj_fnfd;
+  v3 adj_dpdt = adj_vt;
+  adj_vn += -adj_vt.y;
+  adj_dpdt.y += adj_vn;
+  v3 adj_w = V3(0, 0, 0);
+  adj_cross(w, rr, adj_w, adj_r, adj_dpdt);
+  v3 adj_cp = V3(adj_r.x, adj_r.y + adj_c, adj_r.z);
+  qt adj_q = Q4(0, 0, 0, 0);
+  adj_qrot_q(q, com, adj_q, -adj_r);
+  adj_qrot_q(q, cpt, adj_q, adj_cp);
+  out.p = adj_cp - adj_r;
+  out.r = adj_q;
+  out.w = adj_w;
+  out.v = adj_dpdt;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Joint PD + attachment forces for joint i == child body i (integrator_euler.py:289-451).
+PD_DEV float joint_force(float q, float qd, float target, float ke, float kd, float act, float lo, float up, float lke,
+                         float lkd) {
+  float limit_f = 0.0f;  // :274-281
+  if (q < lo) limit_f = lke * (lo - q) - lkd * fminf(qd, 0.0f);
+  if (q > up) limit_f = lke * (up - q) - lkd * fmaxf(qd, 0.0f);
+  return ke * (q - target) + kd * qd + act - limit_f;  // :284
+}
+PD_DEV void joint_force_adj(float q, float qd, float target, float ke, float kd, float lo, float up, float lke, float lkd,
+                            float g, float &adj_q, float &adj_qd, float &adj_target, float &adj_ke, float &adj_kd,
+                            float &adj_act) {
+  adj_ke += g * (q - target); adj_q += g * ke; adj_target += -g * ke;
+  adj_kd += g * qd; adj_qd += g * kd; adj_act += g;
+  float adj_limit = -g;
+  if (q > up) { adj_q += -lke * adj_limit; if (qd > 0.0f) adj_qd += -lkd * adj_limit; }
+  else if (q < lo) { adj_q += -lke * adj_limit; if (qd < 0.0f) adj_qd += -lkd * adj_limit; }
+}
+
+PD_DEV void quat_decompose(qt q, float *ang) {  // :245-258
+  v3 c0 = qrot(q, V3(1, 0, 0)), c1 = qrot(q, V3(0, 1, 0)), c2 = qrot(q, V3(0, 0, 1));
+  ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asinf(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
+}
+PD_DEV void quat_decompose_adj(qt q, const float *g, qt &adj_q) {
+  v3 ex = V3(1, 0, 0), ey = V3(0, 1, 0), ez = V3(0, 0, 1);
+  v3 c0 = qrot(q, ex), c1 = qrot(q, ey), c2 = qrot(q, ez);
+  v3 a0 = V3(0, 0, 0), a1 = a0, a2 = a0;
+  float gphi = -g[0], gth = -g[1], gpsi = -g[2];
+  { float y = c2.y, x = c2.z, d = x * x + y * y; a2.y += gphi * x / d; a2.z += -gphi * y / d; }
+  { float s = -c2.x; a2.x += -gth / sqrtf(1.0f - s * s); }
+  { float y = c1.x, x = c0.x, d = x * x + y * y; a1.x += gpsi * x / d; a0.x += -gpsi * y / d; }
+  adj_qrot_q(q, ex, adj_q, a0); adj_qrot_q(q, ey, adj_q, a1); adj_qrot_q(q, ez, adj_q, a2);
+}
+
+struct JointCtx {  // locals shared by the forward and the adjoint
+  v3 pp, x_p, r_p, w_p, v_p, r_c, x_err, v_err, w_err;
+  qt qp, q_p, r_err;
+};
+
+PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, const float *rec, JointCtx &j) {
+  j.pp = V3(0, 0, 0); j.qp = Q4(0, 0, 0, 1); j.x_p = c.p_pj; j.q_p = c.q_pj;
+  j.r_p = V3(0, 0, 0); j.w_p = V3(0, 0, 0); j.v_p = V3(0, 0, 0);
+  if (c.parent >= 0) {  // :326-333
+    const float *r = rec + c.parent * PD_REC;
+    j.pp = ld3(r); j.qp = ld4(r + 3); j.w_p = ld3(r + 7); j.v_p = ld3(r + 10);
+    j.x_p = j.pp + qrot(j.qp, c.p_pj);
+    j.q_p = qmul(j.qp, c.q_pj);
+    j.r_p = j.x_p - (j.pp + ld3(r + 13));
+  }
+  j.r_c = s.p - (s.p + qrot(s.r, c.com));  // :338
+  j.x_err = s.p - j.x_p; j.r_err = qmul(qconj(j.q_p), s.r);  // :369-372
+  j.v_err = s.v - j.v_p; j.w_err = s.w - j.w_p;
+}
+
+// tgt/act/ke/kd: this joint's dofs (1 for revolute, 3 for compound).  Outputs the wrench pair:
+// parent += (t + r_p x f, f), child -= (t + r_c x f, f)   (:448-451)
+template <int JT>
+PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *rec, const float *tgt,
+                      const float *act, const float *ke, const float *kd, v3 &wp_t, v3 &wp_f, v3 &wc_t, v3 &wc_f) {
+  JointCtx j;
+  joint_ctx(c, s, rec, j);
+  const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
+  v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
+  const int qds = c.qdstart;
+  if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {  // :385-390
+    v3 ang_err = normalize(qvec(j.r_err)) * (acosf(j.r_err.w) * 2.0f);
+    f_total += j.x_err * ake + j.v_err * akd;
+    t_total += qrot(j.q_p, ang_err) * ake + j.w_err * (akd * ads);
+  }
+  if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {  // :392-409
+    v3 axis_p = qrot(j.q_p, c.axis), axis_c = qrot(s.r, c.axis);
+    v3 a = c.axis * dot(qvec(j.r_err), c.axis);
+    qt twist = qnormalize(Q4(a.x, a.y, a.z, j.r_err.w));
+    float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
+    float q = acosf(twist.w) * 2.0f * sgn;
+    float qd = dot(j.w_err, axis_p);
+    float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], m.lim_lo[qds], m.lim_hi[qds], m.lim_ke[qds], m.lim_kd[qds]);
+    t_total = axis_p * jf;
+    v3 swing = cross(axis_p, axis_c);
+    f_total += j.x_err * ake + j.v_err * akd;
+    t_total += swing * ake + (j.w_err - axis_p * qd) * (akd * ads);
+  }
+  if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {  // :411-445
+    qt q_pc = qmul(qmul(qmul(qconj(c.q_off), qconj(j.q_p)), s.r), c.q_off);
+    float ang[3];
+    quat_decompose(q_pc, ang);
+    v3 ax[3];
+    ax[0] = V3(1, 0, 0);
+    qt q_0 = q_axis_angle(ax[0], ang[0]);
+    ax[1] = qrot(q_0, V3(0, 1, 0));
+    qt q_1 = q_axis_angle(ax[1], ang[1]);
+    ax[2] = qrot(qmul(q_1, q_0), V3(0, 0, 1));
+    qt q_w = qmul(j.q_p, c.q_off);
+    t_total = V3(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      v3 axw = qrot(q_w, ax[k]);
+      float jf = joint_force(ang[k], dot(axw, j.w_err), tgt[k], ke[k], kd[k], act[k], m.lim_lo[qds + k], m.lim_hi[qds + k],
+                             m.lim_ke[qds + k], m.lim_kd[qds + k]);
+      t_total += axw * jf;
+    }
+    t_total = clamp3(t_total, 1.0e4f);
+    f_total += clamp3(j.x_err * ake + j.v_err * akd, 1.0e4f);
+  }
+  wp_t = t_total + cross(j.r_p, f_total); wp_f = f_total;
+  wc_t = t_total + cross(j.r_c, f_total); wc_f = f_total;
+}
+
+// Adjoint.  gc_* = adjoint of the child's wrench accumulator, gp_* = of the parent's (zero if none).
+// own += d/d(child state); par = d/d(parent state); a_* = per-dof gradients (overwritten).
+template <int JT>
+PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *rec, const float *tgt,
+                      const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
+                      BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
+  JointCtx j;
+  joint_ctx(c, s, rec, j);
+  const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
+  const int qds = c.qdstart;
+  v3 f_raw = j.x_err * ake + j.v_err * akd;
+  v3 f_total = ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) ? clamp3(f_raw, 1.0e4f) : f_raw;
+  v3 adj_t = -gc_t, adj_f = -gc_f, adj_r_c = V3(0, 0, 0), adj_r_p = V3(0, 0, 0);
+  adj_cross(j.r_c, f_total, adj_r_c, adj_f, -gc_t);
+  if (c.parent >= 0) {
+    adj_t += gp_t; adj_f += gp_f;
+    adj_cross(j.r_p, f_total, adj_r_p, adj_f, gp_t);
+  }
+  v3 adj_x_err = V3(0, 0, 0), adj_v_err = V3(0, 0, 0), adj_w_err = V3(0, 0, 0);
+  qt adj_r_err = Q4(0, 0, 0, 0), adj_q_p = Q4(0, 0, 0, 0), adj_q_c = Q4(0, 0, 0, 0);
+  if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {
+    v3 rv = qvec(j.r_err);
+    float ac = acosf(j.r_err.w) * 2.0f;
+    v3 nrm = normalize(rv), ang_err = nrm * ac;
+    adj_x_err += adj_f * ake; adj_v_err += adj_f * akd; adj_w_err += adj_t * (akd * ads);
+    v3 adj_ang_err = V3(0, 0, 0);
+    adj_qrot(j.q_p, ang_err, adj_q_p, adj_ang_err, adj_t * ake);
+    v3 adj_rv = V3(0, 0, 0);
+    adj_normalize(rv, adj_rv, adj_ang_err * ac);
+    adj_r_err.x += adj_rv.x; adj_r_err.y += adj_rv.y; adj_r_err.z += adj_rv.z;
+    adj_r_err.w += -2.0f * dot(adj_ang_err, nrm) / sqrtf(1.0f - j.r_err.w * j.r_err.w);
+  }
+  if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
+    v3 axis_p = qrot(j.q_p, c.axis), axis_c = qrot(s.r, c.axis);
+    float da = dot(qvec(j.r_err), c.axis);
+    v3 a = c.axis * da;
+    qt tq = Q4(a.x, a.y, a.z, j.r_err.w);
+    qt twist = qnormalize(tq);
+    float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
+    float q = acosf(twist.w) * 2.0f * sgn;
+    float qd = dot(j.w_err, axis_p);
+    float lo = m.lim_lo[qds], up = m.lim_hi[qds], lke = m.lim_ke[qds], lkd = m.lim_kd[qds];
+    float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], lo, up, lke, lkd);
+    adj_x_err += adj_f * ake; adj_v_err += adj_f * akd;
+    float adj_jf = dot(adj_t, axis_p);
+    v3 adj_axis_p = adj_t * jf, adj_axis_c = V3(0, 0, 0);
+    adj_w_err += adj_t * (akd * ads);
+    float adj_qd = -dot(adj_t, axis_p) * (akd * ads);
+    adj_axis_p += adj_t * (-qd * (akd * ads));
+    adj_cross(axis_p, axis_c, adj_axis_p, adj_axis_c, adj_t * ake);
+    float adj_q = 0.f;
+    a_tgt[0] = 0.f; a_act[0] = 0.f; a_ke[0] = 0.f; a_kd[0] = 0.f;
+    joint_force_adj(q, qd, tgt[0], ke[0], kd[0], lo, up, lke, lkd, adj_jf, adj_q, adj_qd, a_tgt[0], a_ke[0], a_kd[0], a_act[0]);
+    adj_w_err += axis_p * adj_qd; adj_axis_p += j.w_err * adj_qd;
+    qt adj_twist = Q4(0, 0, 0, -adj_q * 2.0f * sgn / sqrtf(1.0f - twist.w * twist.w));
+    qt adj_tq = Q4(0, 0, 0, 0);
+    adj_qnormalize(tq, adj_tq, adj_twist);
+    float adj_da = dot(qvec(adj_tq), c.axis);
+    adj_r_err.x += c.axis.x * adj_da; adj_r_err.y += c.axis.y * adj_da; adj_r_err.z += c.axis.z * adj_da;
+    adj_r_err.w += adj_tq.w;
+    adj_qrot_q(j.q_p, c.axis, adj_q_p, adj_axis_p);
+    adj_qrot_q(s.r, c.axis, adj_q_c, adj_axis_c);
+  }
+  if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
+    qt qa = qmul(qconj(c.q_off), qconj(j.q_p)), qb = qmul(qa, s.r), q_pc = qmul(qb, c.q_off);
+    float ang[3];
+    quat_decompose(q_pc, ang);
+    v3 ax[3];
+    ax[0] = V3(1, 0, 0);
+    qt q_0 = q_axis_angle(ax[0], ang[0]);
+    ax[1] = qrot(q_0, V3(0, 1, 0));
+    qt q_1 = q_axis_angle(ax[1], ang[1]);
+    qt q10 = qmul(q_1, q_0);
+    ax[2] = qrot(q10, V3(0, 0, 1));
+    qt q_w = qmul(j.q_p, c.q_off);
+    v3 axw[3], t_raw = V3(0, 0, 0);
+    float jf[3], qdk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      axw[k] = qrot(q_w, ax[k]); qdk[k] = dot(axw[k], j.w_err);
+      jf[k] = joint_force(ang[k], qdk[k], tgt[k], ke[k], kd[k], act[k], m.lim_lo[qds + k], m.lim_hi[qds + k],
+                          m.lim_ke[qds + k], m.lim_kd[qds + k]);
+      t_raw += axw[k] * jf[k];
+    }
+    v3 adj_f_raw = clamp3_pass(f_raw, adj_f, 1.0e4f);
+    adj_x_err += adj_f_raw * ake; adj_v_err += adj_f_raw * akd;
+    v3 adj_t_raw = clamp3_pass(t_raw, adj_t, 1.0e4f);
+    float adj_ang[3] = {0.f, 0.f, 0.f};
+    v3 adj_ax[3] = {V3(0, 0, 0), V3(0, 0, 0), V3(0, 0, 0)};
+    qt adj_q_w = Q4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+      float adj_jf = dot(adj_t_raw, axw[k]);
+      v3 adj_axw = adj_t_raw * jf[k];
+      float adj_qdk = 0.f;
+      a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f;
+      joint_force_adj(ang[k], qdk[k], tgt[k], ke[k], kd[k], m.lim_lo[qds + k], m.lim_hi[qds + k], m.lim_ke[qds + k],
+                      m.lim_kd[qds + k], adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k], a_kd[k], a_act[k]);
+      adj_axw += j.w_err * adj_qdk; adj_w_err += axw[k] * adj_qdk;
+      adj_qrot(q_w, ax[k], adj_q_w, adj_ax[k], adj_axw);
+    }
+    adj_qmul_a(c.q_off, adj_q_p, adj_q_w);
+    qt adj_q10 = Q4(0, 0, 0, 0), adj_q_1 = adj_q10, adj_q_0 = adj_q10;
+    adj_qrot_q(q10, V3(0, 0, 1), adj_q10, adj_ax[2]);
+    adj_qmul(q_1, q_0, adj_q_1, adj_q_0, adj_q10);
+    adj_q_axis_angle(ax[1], ang[1], adj_ax[1], adj_ang[1], adj_q_1);
+    adj_qrot_q(q_0, V3(0, 1, 0), adj_q_0, adj_ax[1]);
+    adj_q_axis_angle_ang(ax[0], ang[0], adj_ang[0], adj_q_0);
+    qt adj_q_pc = Q4(0, 0, 0, 0);
+    quat_decompose_adj(q_pc, adj_ang, adj_q_pc);
+    qt adj_qb = Q4(0, 0, 0, 0), adj_qa = adj_qb, adj_cqp = adj_qb;
+    adj_qmul_a(c.q_off, adj_qb, adj_q_pc);
+    adj_qmul(qa, s.r, adj_qa, adj_q_c, adj_qb);
+    adj_qmul_b(qconj(c.q_off), adj_cqp, adj_qa);
+    adj_q_p += qconj(adj_cqp);
+  }
+  {  // r_err = conj(q_p) * q_c
+    qt adj_cqp = Q4(0, 0, 0, 0);
+    adj_qmul(qconj(j.q_p), s.r, adj_cqp, adj_q_c, adj_r_err);
+    adj_q_p += qconj(adj_cqp);
+  }
+  adj_qrot_q(s.r, c.com, adj_q_c, -adj_r_c);  // r_c = x_c - (x_c + rot(q_c, com))
+  own.p += adj_x_err; own.r += adj_q_c; own.w += adj_w_err; own.v += adj_v_err;
+  par = adj_zero();
+  if (c.parent >= 0) {
+    v3 adj_x_p = adj_r_p - adj_x_err;
+    par.p = adj_x_p - adj_r_p;                           // x_p = pp + ..., r_p = x_p - (pp + rc_par)
+    adj_qrot_q(j.qp, c.com_par, par.r, -adj_r_p);
+    adj_qrot_q(j.qp, c.p_pj, par.r, adj_x_p);
+    adj_qmul_a(c.q_pj, par.r, adj_q_p);
+    par.w = -adj_w_err; par.v = -adj_v_err;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// integrate_bodies (integrator_euler.py:21-91) for one body.
+PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m,
+                               const float *I, const float *invI, float dt) {
+  v3 g = V3(m.gx, m.gy, m.gz);
+  float nz = inv_m != 0.0f ? 1.0f : 0.0f;
+  v3 x_com = s.p + qrot(s.r, c.com);                            // :61
+  v3 v1 = s.v + (f0 * inv_m + g * nz) * dt;                     // :64
+  v3 x1 = x_com + v1 * dt;                                      // :65
+  v3 wb = qrot_inv(s.r, s.w);                                   // :68
+  v3 tb = qrot_inv(s.r, t0) - cross(wb, mat_vec(I, wb));        // :69
+  v3 w1 = qrot(s.r, wb + mat_vec(invI, tb) * dt);               // :71
+  qt r1 = qnormalize(s.r + qmul(Q4(w1.x, w1.y, w1.z, 0.f), s.r) * (0.5f * dt));  // :72
+  w1 = w1 * (1.0f - 0.1f * dt);                                 // :75
+  BodyState o;
+  o.w = clamp3(w1, 10.0f); o.v = clamp3(v1, 10.0f);             // :78-88
+  o.r = r1; o.p = x1 - qrot(r1, c.com);                         // :90
+  return o;
+}
+
+PD_DEV void integrate_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m,
+                          const float *I, const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, v3 &adj_t0, v3 &adj_f0,
+                          float &g_inv_m, float *g_I, float *g_invI) {
+  v3 g = V3(m.gx, m.gy, m.gz);
+  float nz = inv_m != 0.0f ? 1.0f : 0.0f;
+  v3 v1 = s.v + (f0 * inv_m + g * nz) * dt;
+  v3 wb = qrot_inv(s.r, s.w);
+  v3 Iwb = mat_vec(I, wb);
+  v3 tb = qrot_inv(s.r, t0) - cross(wb, Iwb);
+  v3 u = wb + mat_vec(invI, tb) * dt;
+  v3 w1 = qrot(s.r, u);
+  qt W = Q4(w1.x, w1.y, w1.z, 0.f);
+  qt rq = s.r + qmul(W, s.r) * (0.5f * dt);
+  qt r1 = qnormalize(rq);
+  v3 w1d = w1 * (1.0f - 0.1f * dt);
+  // reverse
+  qt adj_r1 = gn.r;
+  adj_qrot_q(r1, c.com, adj_r1, -gn.p);
+  v3 adj_v1 = clamp3_pass(v1, gn.v, 10.0f);
+  v3 adj_w1 = clamp3_pass(w1d, gn.w, 10.0f) * (1.0f - 0.1f * dt);
+  qt adj_rq = Q4(0, 0, 0, 0);
+  adj_qnormalize(rq, adj_rq, adj_r1);
+  qt adj_r0 = adj_rq, adj_W = Q4(0, 0, 0, 0);
+  adj_qmul(W, s.r, adj_W, adj_r0, adj_rq * (0.5f * dt));
+  adj_w1 += qvec(adj_W);
+  v3 adj_u = V3(0, 0, 0);
+  adj_qrot(s.r, u, adj_r0, adj_u, adj_w1);
+  v3 adj_wb = adj_u, adj_a = adj_u * dt;
+  add_outer(g_invI, adj_a, tb);
+  v3 adj_tb = matT_vec(invI, adj_a);
+  adj_t0 = V3(0, 0, 0);
+  adj_qrot_inv(s.r, t0, adj_r0, adj_t0, adj_tb);
+  v3 adj_Iwb = V3(0, 0, 0);
+  adj_cross(wb, Iwb, adj_wb, adj_Iwb, -adj_tb);
+  add_outer(g_I, adj_Iwb, wb);
+  adj_wb += matT_vec(I, adj_Iwb);
+  v3 adj_w0 = V3(0, 0, 0);
+  adj_qrot_inv(s.r, s.w, adj_r0, adj_w0, adj_wb);
+  adj_v1 += gn.p * dt;
+  adj_f0 = adj_v1 * (inv_m * dt);
+  g_inv_m += dot(adj_v1, f0) * dt;
+  adj_qrot_q(s.r, c.com, adj_r0, gn.p);
+  a.p = gn.p; a.r = adj_r0; a.w = adj_w0; a.v = adj_v1;
+}

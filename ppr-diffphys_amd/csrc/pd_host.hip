@@ -1,0 +1,354 @@
+// Host side of libpprdiffphys_hip.so: model compiler back end (contact ordering, cull tables,
+// chain topology), device upload, launch wrappers and the C ABI of include/ppr_diffphys.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ppr_diffphys.h"
+#include "pd_args.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string &msg) { g_err = msg; return 1; }
+static int hip_fail(hipError_t e, const char *what) { return fail(std::string(what) + ": " + hipGetErrorString(e)); }
+
+struct pd_model {
+  // host copy of the template
+  int nb = 0, nq = 0, nqd = 0, nc = 0, nmat = 0;
+  std::vector<int> jtype, jparent, qstart, qdstart, cbody, cmat;
+  std::vector<float> X_p, X_c, axis, com, lim_lo, lim_hi, lim_ke, lim_kd, cpoint, cdist, materials;
+  float gravity[3] = {0, 0, 0}, attach_ke = 0, attach_kd = 0;
+  // derived
+  int segw = 0, jt = 0;
+  void *blob = nullptr;
+  PdDevModel dev{};
+  size_t lds_rollout = 0, lds_fk = 0;
+  // timing
+  hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool ev_valid[2] = {false, false};
+};
+
+static bool g_timing = false;
+
+// kd-order: recursively split along the longest axis so that runs of `leaf` consecutive points are compact
+static void kd_order(std::vector<int> &ids, int lo, int hi, const float *pts, int leaf) {
+  int n = hi - lo;
+  if (n <= leaf) return;
+  float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+  for (int i = lo; i < hi; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float v = pts[ids[i] * 3 + k];
+      mn[k] = std::min(mn[k], v); mx[k] = std::max(mx[k], v);
+    }
+  int ax = 0;
+  for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+  std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) { return pts[a * 3 + ax] < pts[b * 3 + ax]; });
+  int half = ((n / 2 + leaf - 1) / leaf) * leaf;
+  if (half >= n) half = n - leaf > 0 ? ((n - 1) / leaf) * leaf : n;
+  if (half <= 0 || half >= n) return;
+  kd_order(ids, lo, lo + half, pts, leaf);
+  kd_order(ids, lo + half, hi, pts, leaf);
+}
+
+static float4 bound_sphere(const std::vector<int> &ids, const float *pts, const float *dist) {
+  if (ids.empty()) return make_float4(0, 0, 0, -1.0f);
+  float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f}, dmax = -1e30f;
+  for (int i : ids) {
+    for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], pts[i * 3 + k]); mx[k] = std::max(mx[k], pts[i * 3 + k]); }
+    dmax = std::max(dmax, dist[i]);
+  }
+  float c[3] = {0.5f * (mn[0] + mx[0]), 0.5f * (mn[1] + mx[1]), 0.5f * (mn[2] + mx[2])};
+  float r = 0.f;
+  for (int i : ids) {
+    float d2 = 0.f;
+    for (int k = 0; k < 3; ++k) { float d = pts[i * 3 + k] - c[k]; d2 += d * d; }
+    r = std::max(r, std::sqrt(d2));
+  }
+  // lower bound of c = p_y + (R x)_y - dist over the set is p_y + (R c)_y - (r + max dist); |dist| margin keeps w >= 0
+  return make_float4(c[0], c[1], c[2], r * 1.0001f + std::max(dmax, 0.0f) + 1e-6f);
+}
+
+static void free_device(pd_model *m) {
+  if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
+}
+
+template <typename T>
+static size_t put(std::vector<unsigned char> &buf, const std::vector<T> &v) {
+  size_t off = (buf.size() + 255) & ~(size_t)255;
+  buf.resize(off + std::max<size_t>(v.size() * sizeof(T), 16));
+  if (!v.empty()) memcpy(buf.data() + off, v.data(), v.size() * sizeof(T));
+  return off;
+}
+
+static int build_device(pd_model *m, int segw) {
+  const int nb = m->nb;
+  if (segw == 0) segw = nb <= 16 ? 16 : (nb <= 32 ? 32 : 64);
+  if (segw != 16 && segw != 32 && segw != 64) return fail("segment width must be 16, 32 or 64");
+  if (nb > segw) return fail("segment width smaller than the number of bodies");
+  // ---- chain topology
+  std::vector<int> depth(nb, 0);
+  std::vector<unsigned long long> children(nb, ~0ull);
+  std::vector<int> nchild(nb, 0);
+  int max_depth = 0, max_children = 0, jt = 0;
+  for (int i = 0; i < nb; ++i) {
+    int p = m->jparent[i];
+    if (p >= i) return fail("parents must precede children");
+    if (p >= 0) {
+      depth[i] = depth[p] + 1;
+      if (nchild[p] >= 8) return fail("more than 8 children per body is not supported");
+      children[p] &= ~(0xffull << (8 * nchild[p]));
+      children[p] |= (unsigned long long)i << (8 * nchild[p]);
+      nchild[p]++;
+      max_children = std::max(max_children, nchild[p]);
+    }
+    max_depth = std::max(max_depth, depth[i]);
+    switch (m->jtype[i]) {
+      case PD_JOINT_REVOLUTE: jt |= PD_JT_REVOLUTE; break;
+      case PD_JOINT_COMPOUND: jt |= PD_JT_COMPOUND; break;
+      case PD_JOINT_FIXED: jt |= PD_JT_FIXED; break;
+      case PD_JOINT_FREE: break;
+      default: return fail("unsupported joint type " + std::to_string(m->jtype[i]) + " (revolute, fixed, free, compound only)");
+    }
+  }
+  if (jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
+  // ---- contact table: sorted by body, kd-ordered inside a body, big bodies aligned to segw
+  std::vector<float4> pts, pt_mat;
+  std::vector<unsigned char> pt_body;
+  std::vector<int> pt_src;  // original index or -1 for padding
+  std::vector<float4> body_sphere(nb, make_float4(0, 0, 0, -1.0f));
+  const float4 dummy = make_float4(0.f, 0.f, 0.f, -1.0e30f);
+  auto pad_to = [&](size_t mult, int body) {
+    while (pts.size() % mult) { pts.push_back(dummy); pt_mat.push_back(make_float4(0, 0, 0, 0)); pt_body.push_back((unsigned char)body); pt_src.push_back(-1); }
+  };
+  for (int b = 0; b < nb; ++b) {
+    std::vector<int> ids;
+    for (int k = 0; k < m->nc; ++k) if (m->cbody[k] == b) ids.push_back(k);
+    if (ids.empty()) continue;
+    body_sphere[b] = bound_sphere(ids, m->cpoint.data(), m->cdist.data());
+    bool big = (int)ids.size() >= segw;
+    if (big) { pad_to(segw, b); kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), segw); }
+    for (int k : ids) {
+      pts.push_back(make_float4(m->cpoint[k * 3], m->cpoint[k * 3 + 1], m->cpoint[k * 3 + 2], m->cdist[k]));
+      int mi = m->cmat[k];
+      if (mi < 0 || mi >= m->nmat) return fail("contact_material out of range");
+      pt_mat.push_back(make_float4(m->materials[mi * 4], m->materials[mi * 4 + 1], m->materials[mi * 4 + 2], m->materials[mi * 4 + 3]));
+      pt_body.push_back((unsigned char)b);
+      pt_src.push_back(k);
+    }
+    if (big) pad_to(segw, b);
+  }
+  const int nc = (int)pts.size();
+  const int nchunks = (nc + segw - 1) / segw;
+  std::vector<float4> chunk_sphere(std::max(nchunks, 1), make_float4(0, 0, 0, -1.0f));
+  std::vector<unsigned long long> chunk_mask(std::max(nchunks, 1), 0ull);
+  for (int c = 0; c < nchunks; ++c) {
+    std::vector<int> ids;
+    unsigned long long mask = 0;
+    for (int i = c * segw; i < std::min(nc, (c + 1) * segw); ++i)
+      if (pt_src[i] >= 0) { ids.push_back(pt_src[i]); mask |= 1ull << pt_body[i]; }
+    chunk_mask[c] = mask;
+    if (mask && !(mask & (mask - 1))) chunk_sphere[c] = bound_sphere(ids, m->cpoint.data(), m->cdist.data());
+  }
+  const int nc_pad = ((nc + 63) / 64) * 64;
+  pts.resize(std::max(nc_pad, 64), dummy); pt_mat.resize(std::max(nc_pad, 64), make_float4(0, 0, 0, 0)); pt_body.resize(std::max(nc_pad, 64), 0);
+
+  // ---- upload
+  std::vector<unsigned char> buf;
+  size_t o_jtype = put(buf, m->jtype), o_jparent = put(buf, m->jparent), o_qstart = put(buf, m->qstart), o_qdstart = put(buf, m->qdstart);
+  size_t o_depth = put(buf, depth), o_children = put(buf, children);
+  size_t o_Xp = put(buf, m->X_p), o_Xc = put(buf, m->X_c), o_axis = put(buf, m->axis), o_com = put(buf, m->com);
+  size_t o_lo = put(buf, m->lim_lo), o_hi = put(buf, m->lim_hi), o_lke = put(buf, m->lim_ke), o_lkd = put(buf, m->lim_kd);
+  size_t o_pts = put(buf, pts), o_ptb = put(buf, pt_body), o_ptm = put(buf, pt_mat);
+  size_t o_bs = put(buf, body_sphere), o_cs = put(buf, chunk_sphere), o_cm = put(buf, chunk_mask);
+  free_device(m);
+  hipError_t e = hipMalloc(&m->blob, buf.size());
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
+  e = hipMemcpy(m->blob, buf.data(), buf.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(model)");
+  unsigned char *base = (unsigned char *)m->blob;
+  PdDevModel &d = m->dev;
+  d.nb = nb; d.nq = m->nq; d.nqd = m->nqd; d.nc = nc; d.nc_pad = std::max(nc_pad, 64); d.nchunks = nchunks;
+  d.max_children = max_children; d.max_depth = max_depth;
+  d.jtype = (const int *)(base + o_jtype); d.jparent = (const int *)(base + o_jparent);
+  d.qstart = (const int *)(base + o_qstart); d.qdstart = (const int *)(base + o_qdstart);
+  d.depth = (const int *)(base + o_depth); d.children = (const unsigned long long *)(base + o_children);
+  d.X_p = (const float *)(base + o_Xp); d.X_c = (const float *)(base + o_Xc);
+  d.axis = (const float *)(base + o_axis); d.com = (const float *)(base + o_com);
+  d.lim_lo = (const float *)(base + o_lo); d.lim_hi = (const float *)(base + o_hi);
+  d.lim_ke = (const float *)(base + o_lke); d.lim_kd = (const float *)(base + o_lkd);
+  d.pts = (const float4 *)(base + o_pts); d.pt_body = base + o_ptb; d.pt_mat = (const float4 *)(base + o_ptm);
+  d.body_sphere = (const float4 *)(base + o_bs); d.chunk_sphere = (const float4 *)(base + o_cs);
+  d.chunk_mask = (const unsigned long long *)(base + o_cm);
+  d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
+  d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
+  d.env_lds_floats = ((nb * (PD_REC + 6 + 2 * PD_ADJ) + nchunks + 3) / 4) * 4;
+  const int envs_per_block = PD_WAVES * (64 / segw);
+  m->lds_rollout = (size_t)d.nc_pad * 17 + (size_t)envs_per_block * d.env_lds_floats * 4;
+  m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
+  if (m->lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
+  m->segw = segw; m->jt = jt;
+  int lds_max = (int)std::max(m->lds_rollout, m->lds_fk);
+  e = segw == 16 ? pd_set_lds_seg16(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32(jt, lds_max) : pd_set_lds_seg64(jt, lds_max));
+  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(LDS)");
+  return 0;
+}
+
+static hipError_t launch(const pd_model *m, int kind, const void *args, int n_envs, size_t lds, hipStream_t st) {
+  const int epb = PD_WAVES * (64 / m->segw);
+  const int nblocks = (n_envs + epb - 1) / epb;
+  if (nblocks == 0) return hipSuccess;
+  if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, nblocks, lds, st);
+  if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, nblocks, lds, st);
+  return pd_launch_seg64(kind, m->jt, m->dev, args, nblocks, lds, st);
+}
+
+static void timing_begin(pd_model *m, int kind, hipStream_t st) {
+  if (!g_timing) return;
+  if (!m->ev[kind][0]) { (void)hipEventCreate(&m->ev[kind][0]); (void)hipEventCreate(&m->ev[kind][1]); }
+  (void)hipEventRecord(m->ev[kind][0], st);
+}
+static void timing_end(pd_model *m, int kind, hipStream_t st) {
+  if (!g_timing) return;
+  (void)hipEventRecord(m->ev[kind][1], st);
+  m->ev_valid[kind] = true;
+}
+
+static pd_model *g_last_model = nullptr;
+
+extern "C" {
+
+int pd_abi_version(void) { return PD_ABI_VERSION; }
+const char *pd_last_error(void) { return g_err.c_str(); }
+
+int pd_model_create(const pd_model_desc *d, pd_model **out) {
+  if (!d || !out) return fail("null argument");
+  if (d->nb <= 0 || d->nb > 64) return fail("nb must be in 1..64 (one articulation per wavefront segment)");
+  pd_model *m = new pd_model();
+  m->nb = d->nb; m->nq = d->nq; m->nqd = d->nqd; m->nc = d->nc; m->nmat = d->nmat;
+  auto vi = [](const int *p, size_t n) { return std::vector<int>(p, p + n); };
+  auto vf = [](const float *p, size_t n) { return std::vector<float>(p, p + n); };
+  m->jtype = vi(d->joint_type, d->nb); m->jparent = vi(d->joint_parent, d->nb);
+  m->qstart = vi(d->joint_q_start, d->nb); m->qdstart = vi(d->joint_qd_start, d->nb);
+  m->X_p = vf(d->joint_X_p, d->nb * 7); m->X_c = vf(d->joint_X_c, d->nb * 7);
+  m->axis = vf(d->joint_axis, d->nb * 3); m->com = vf(d->body_com, d->nb * 3);
+  m->lim_lo = vf(d->joint_limit_lower, d->nqd); m->lim_hi = vf(d->joint_limit_upper, d->nqd);
+  m->lim_ke = vf(d->joint_limit_ke, d->nqd); m->lim_kd = vf(d->joint_limit_kd, d->nqd);
+  m->cbody = vi(d->contact_body, d->nc); m->cmat = vi(d->contact_material, d->nc);
+  m->cpoint = vf(d->contact_point, (size_t)d->nc * 3); m->cdist = vf(d->contact_dist, d->nc);
+  m->materials = vf(d->shape_materials, (size_t)d->nmat * 4);
+  memcpy(m->gravity, d->gravity, sizeof(float) * 3);
+  m->attach_ke = d->joint_attach_ke; m->attach_kd = d->joint_attach_kd;
+  for (int k = 0; k < d->nc; ++k)
+    if (m->cbody[k] < 0 || m->cbody[k] >= d->nb) { delete m; return fail("contact_body out of range"); }
+  if (build_device(m, 0)) { free_device(m); delete m; return 1; }
+  *out = m;
+  return 0;
+}
+
+void pd_model_destroy(pd_model *m) {
+  if (!m) return;
+  if (g_last_model == m) g_last_model = nullptr;
+  for (int k = 0; k < 2; ++k)
+    for (int j = 0; j < 2; ++j)
+      if (m->ev[k][j]) (void)hipEventDestroy(m->ev[k][j]);
+  free_device(m);
+  delete m;
+}
+
+int pd_model_set_segment_width(pd_model *m, int lanes) {
+  if (!m) return fail("null model");
+  (void)hipDeviceSynchronize();
+  return build_device(m, lanes);
+}
+int pd_model_get_segment_width(const pd_model *m) { return m ? m->segw : 0; }
+
+size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
+  return m ? (size_t)nsteps * 19 * (size_t)bs * m->nb : 0;
+}
+
+int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                       const float *torques, const float *res_f, const float *refs, const float *target_ke,
+                       const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
+                       const int *frame_of_step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, void *stream) {
+  pd_model *m = const_cast<pd_model *>(cm);
+  if (!m) return fail("null model");
+  if (bs < 0 || nsteps < 0) return fail("negative size");
+  if (!q_init || !qd_init || !torques || !res_f || !refs || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia ||
+      !frame_of_step || !ws || !wp_pos || !wp_vel)
+    return fail("null device pointer");
+  RolloutArgs a{};
+  a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
+  a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.res_f = res_f; a.refs = refs;
+  a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
+  a.frame_of_step = frame_of_step; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf;
+  hipStream_t st = (hipStream_t)stream;
+  timing_begin(m, 0, st);
+  hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, m->lds_rollout, st);
+  timing_end(m, 0, st);
+  g_last_model = m;
+  return e == hipSuccess ? 0 : hip_fail(e, "rollout_forward launch");
+}
+
+int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                        const float *torques, const float *refs, const float *target_ke, const float *target_kd,
+                        const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame_of_step,
+                        const float *ws, const float *adj_pos, const float *adj_vel, float *g_q_init, float *g_qd_init,
+                        float *g_torques, float *g_res_f, float *g_refs, float *g_ke, float *g_kd, float *g_inv_mass,
+                        float *g_inertia, float *g_inv_inertia, void *stream) {
+  pd_model *m = const_cast<pd_model *>(cm);
+  if (!m) return fail("null model");
+  if (bs < 0 || nsteps < 0) return fail("negative size");
+  if (!q_init || !qd_init || !torques || !refs || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia ||
+      !frame_of_step || !ws || !adj_pos || !adj_vel || !g_q_init || !g_qd_init || !g_torques || !g_res_f || !g_refs || !g_ke ||
+      !g_kd || !g_inv_mass || !g_inertia || !g_inv_inertia)
+    return fail("null device pointer");
+  RolloutArgs a{};
+  a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
+  a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.refs = refs;
+  a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
+  a.frame_of_step = frame_of_step; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
+  a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
+  a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia;
+  hipStream_t st = (hipStream_t)stream;
+  timing_begin(m, 1, st);
+  hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout, st);
+  timing_end(m, 1, st);
+  g_last_model = m;
+  return e == hipSuccess ? 0 : hip_fail(e, "rollout_backward launch");
+}
+
+int pd_fk_forward(const pd_model *m, int n, const float *joint_q, const float *joint_qd, float *body_q, float *body_qd, void *stream) {
+  if (!m) return fail("null model");
+  if (n < 0) return fail("negative size");
+  if (!joint_q || !joint_qd || !body_q || !body_qd) return fail("null device pointer");
+  FkArgs a{};
+  a.n = n; a.joint_q = joint_q; a.joint_qd = joint_qd; a.body_q = body_q; a.body_qd = body_qd;
+  hipError_t e = launch(m, PD_K_FK_FWD, &a, n, m->lds_fk, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : hip_fail(e, "fk_forward launch");
+}
+
+int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *joint_qd, const float *adj_body_q,
+                   const float *adj_body_qd, float *g_joint_q, float *g_joint_qd, void *stream) {
+  if (!m) return fail("null model");
+  if (n < 0) return fail("negative size");
+  if (!joint_q || !joint_qd || !adj_body_q || !adj_body_qd || !g_joint_q || !g_joint_qd) return fail("null device pointer");
+  FkArgs a{};
+  a.n = n; a.joint_q = joint_q; a.joint_qd = joint_qd; a.adj_body_q = adj_body_q; a.adj_body_qd = adj_body_qd;
+  a.g_joint_q = g_joint_q; a.g_joint_qd = g_joint_qd;
+  hipError_t e = launch(m, PD_K_FK_BWD, &a, n, m->lds_fk, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : hip_fail(e, "fk_backward launch");
+}
+
+void pd_set_timing(int on) { g_timing = on != 0; }
+float pd_last_kernel_ms(int kind) {
+  pd_model *m = g_last_model;
+  if (!m || kind < 0 || kind > 1 || !m->ev_valid[kind]) return -1.0f;
+  float ms = -1.0f;
+  if (hipEventSynchronize(m->ev[kind][1]) != hipSuccess) return -1.0f;
+  if (hipEventElapsedTime(&ms, m->ev[kind][0], m->ev[kind][1]) != hipSuccess) return -1.0f;
+  return ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+// Per-lane spatial algebra for the gfx950 rollout kernels: 3-vectors, quaternions
+// (x,y,z,w), and the reverse-mode rule of every primitive.  Semantics are the Warp
+// built-ins the reference's kernels call: quat_rotate as
+// x(2w^2-1) + 2w(q_v x x) + 2 q_v (q_v . x), Hamilton product, conjugate inverse,
+// normalize(vec3)=0 at zero length, clamp/min adjoints routed to the selected argument.
+// No fast-math: NaN/inf must appear exactly where the reference lets them appear
+// (acos at +-1, asin gimbal); the boundary scrubs them (dp_utils.py:43-57 of the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define PD_DEV __device__ __forceinline__
+
+struct v3 { float x, y, z; };
+struct qt { float x, y, z, w; };
+
+PD_DEV v3 V3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+PD_DEV qt Q4(float x, float y, float z, float w) { qt r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+PD_DEV v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PD_DEV v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PD_DEV v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+PD_DEV v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+PD_DEV v3 &operator+=(v3 &a, v3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+PD_DEV v3 &operator-=(v3 &a, v3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+PD_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PD_DEV v3 cross(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+PD_DEV float length(v3 a) { return sqrtf(dot(a, a)); }
+PD_DEV v3 normalize(v3 a) { float l = length(a); return l > 0.0f ? a * (1.0f / l) : V3(0.f, 0.f, 0.f); }
+
+PD_DEV v3 qvec(qt q) { return V3(q.x, q.y, q.z); }
+PD_DEV qt operator+(qt a, qt b) { return Q4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+PD_DEV qt operator*(qt a, float s) { return Q4(a.x * s, a.y * s, a.z * s, a.w * s); }
+PD_DEV qt &operator+=(qt &a, qt b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; return a; }
+PD_DEV float qdot(qt a, qt b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+PD_DEV qt qconj(qt q) { return Q4(-q.x, -q.y, -q.z, q.w); }
+PD_DEV qt qmul(qt a, qt b) {
+  return Q4(a.w * b.x + b.w * a.x + a.y * b.z - a.z * b.y, a.w * b.y + b.w * a.y + a.z * b.x - a.x * b.z,
+            a.w * b.z + b.w * a.z + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
+}
+PD_DEV qt qnormalize(qt q) { return q * (1.0f / sqrtf(qdot(q, q))); }
+PD_DEV v3 qrot(qt q, v3 v) {
+  v3 u = qvec(q);
+  return v * (2.0f * q.w * q.w - 1.0f) + cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
+}
+PD_DEV v3 qrot_inv(qt q, v3 v) {
+  v3 u = qvec(q);
+  return v * (2.0f * q.w * q.w - 1.0f) - cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
+}
+PD_DEV qt q_axis_angle(v3 axis, float ang) {
+  float s, c;
+  sincosf(ang * 0.5f, &s, &c);
+  return Q4(axis.x * s, axis.y * s, axis.z * s, c);
+}
+PD_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+PD_DEV float clamp_pass(float x, float lo, float hi) { return (x < lo || x > hi) ? 0.0f : 1.0f; }
+PD_DEV v3 clamp3(v3 a, float l) { return V3(clampf(a.x, -l, l), clampf(a.y, -l, l), clampf(a.z, -l, l)); }
+PD_DEV v3 clamp3_pass(v3 a, v3 g, float l) {
+  return V3(g.x * clamp_pass(a.x, -l, l), g.y * clamp_pass(a.y, -l, l), g.z * clamp_pass(a.z, -l, l));
+}
+
+// ---- adjoints: accumulate, like a tape replay ------------------------------------
+PD_DEV void adj_cross(v3 a, v3 b, v3 &adj_a, v3 &adj_b, v3 g) { adj_a += cross(b, g); adj_b += cross(g, a); }
+PD_DEV void adj_cross_a(v3 b, v3 &adj_a, v3 g) { adj_a += cross(b, g); }
+PD_DEV void adj_cross_b(v3 a, v3 &adj_b, v3 g) { adj_b += cross(g, a); }
+PD_DEV void adj_qmul(qt a, qt b, qt &adj_a, qt &adj_b, qt g) { adj_a += qmul(g, qconj(b)); adj_b += qmul(qconj(a), g); }
+PD_DEV void adj_qmul_a(qt b, qt &adj_a, qt g) { adj_a += qmul(g, qconj(b)); }
+PD_DEV void adj_qmul_b(qt a, qt &adj_b, qt g) { adj_b += qmul(qconj(a), g); }
+PD_DEV void adj_qrot_q(qt q, v3 v, qt &adj_q, v3 g) {
+  v3 u = qvec(q);
+  float uv = dot(u, v), ug = dot(u, g);
+  v3 au = cross(v, g) * (2.0f * q.w) + (g * uv + v * ug) * 2.0f;
+  adj_q.x += au.x; adj_q.y += au.y; adj_q.z += au.z;
+  adj_q.w += 4.0f * q.w * dot(v, g) + 2.0f * dot(cross(u, v), g);
+}
+PD_DEV void adj_qrot(qt q, v3 v, qt &adj_q, v3 &adj_v, v3 g) { adj_v += qrot_inv(q, g); adj_qrot_q(q, v, adj_q, g); }
+PD_DEV void adj_qrot_inv_q(qt q, v3 v, qt &adj_q, v3 g) {
+  v3 u = qvec(q);
+  float uv = dot(u, v), ug = dot(u, g);
+  v3 au = cross(v, g) * (-2.0f * q.w) + (g * uv + v * ug) * 2.0f;
+  adj_q.x += au.x; adj_q.y += au.y; adj_q.z += au.z;
+  adj_q.w += 4.0f * q.w * dot(v, g) - 2.0f * dot(cross(u, v), g);
+}
+PD_DEV void adj_qrot_inv(qt q, v3 v, qt &adj_q, v3 &adj_v, v3 g) { adj_v += qrot(q, g); adj_qrot_inv_q(q, v, adj_q, g); }
+PD_DEV void adj_qnormalize(qt q, qt &adj_q, qt g) {
+  float il = 1.0f / sqrtf(qdot(q, q));
+  qt n = q * il;
+  float ng = qdot(n, g);
+  adj_q += (g + n * (-ng)) * il;
+}
+PD_DEV void adj_normalize(v3 a, v3 &adj_a, v3 g) {
+  float l = length(a);
+  if (l > 0.0f) {
+    float il = 1.0f / l;
+    v3 n = a * il;
+    adj_a += (g - n * dot(n, g)) * il;
+  }
+}
+PD_DEV void adj_length(v3 a, v3 &adj_a, float g) { adj_a += normalize(a) * g; }
+PD_DEV void adj_q_axis_angle(v3 axis, float ang, v3 &adj_axis, float &adj_ang, qt g) {
+  float s, c;
+  sincosf(ang * 0.5f, &s, &c);
+  v3 gv = qvec(g);
+  adj_axis += gv * s;
+  adj_ang += 0.5f * (c * dot(axis, gv) - s * g.w);
+}
+PD_DEV void adj_q_axis_angle_ang(v3 axis, float ang, float &adj_ang, qt g) {
+  float s, c;
+  sincosf(ang * 0.5f, &s, &c);
+  adj_ang += 0.5f * (c * dot(axis, qvec(g)) - s * g.w);
+}
+
+PD_DEV v3 mat_vec(const float *M, v3 a) {
+  return V3(M[0] * a.x + M[1] * a.y + M[2] * a.z, M[3] * a.x + M[4] * a.y + M[5] * a.z, M[6] * a.x + M[7] * a.y + M[8] * a.z);
+}
+PD_DEV v3 matT_vec(const float *M, v3 a) {
+  return V3(M[0] * a.x + M[3] * a.y + M[6] * a.z, M[1] * a.x + M[4] * a.y + M[7] * a.z, M[2] * a.x + M[5] * a.y + M[8] * a.z);
+}
+PD_DEV void add_outer(float *M, v3 a, v3 b) {
+  M[0] += a.x * b.x; M[1] += a.x * b.y; M[2] += a.x * b.z;
+  M[3] += a.y * b.x; M[4] += a.y * b.y; M[5] += a.y * b.z;
+  M[6] += a.z * b.x; M[7] += a.z * b.y; M[8] += a.z * b.z;
+}

@@ -1,0 +1,122 @@
+"""The two autograd boundaries of the reference, backed by the HIP library.
+
+``ForwardWarp`` and ``ForwardKinematics`` keep the reference's names, argument
+order, tensor layouts, side effects and gradient post-processing
+(/root/reference/diffphys/dp_model.py:1022-1130 and :1145-1400) so that
+``phys_model.forward`` can call them unchanged; see INTEGRATION.md.
+
+Differences that are deliberate:
+  * one kernel launch per rollout instead of a Python loop of Warp launches;
+  * ``self.state_steps`` is not needed (the trajectory lives in a workspace
+    tensor owned by the autograd ctx);
+  * ``body_mass`` gets a zero gradient: the reference kernel loads it and never
+    uses it (/root/reference/diffphys/integrator_euler.py:43).
+"""
+import numpy as np
+import torch
+
+from . import hip_backend
+
+
+def convert_ppr_warp(tensor):
+    """[linear, angular] <=> [angular, linear] on the last axis (dp_model.py:1014-1019)."""
+    return torch.cat([tensor[..., 3:6], tensor[..., 0:3], tensor[..., 6:]], -1)
+
+
+def _scrub_nan(t):
+    """remove_nan with clip=False (/root/reference/diffphys/dp_utils.py:43-57): NaN -> 0, inf kept."""
+    return torch.where(t.isnan(), torch.zeros_like(t), t)
+
+
+def frame_of_step_tensor(nsteps, frame2step, device):
+    fos = np.full(nsteps + 1, -1, dtype=np.int32)
+    for f, s in enumerate(frame2step):
+        if not (0 <= s <= nsteps):
+            raise ValueError("frame2step entry %d outside 0..%d" % (s, nsteps))
+        fos[s] = f
+    return torch.from_numpy(fos).to(device)
+
+
+class ForwardKinematics(torch.autograd.Function):
+    """rj_q [T,bs,nq], rj_qd [T,bs,nqd], env -> body_q [bs,T,nb,7], body_qd [bs,T,nb,6], body_q_numpy."""
+
+    @staticmethod
+    def forward(ctx, rj_q, rj_qd, env):
+        is_cuda = rj_q.is_cuda
+        if not is_cuda:  # the reference moves CPU inputs to the GPU (dp_model.py:1030-1035)
+            rj_q, rj_qd = rj_q.cuda(), rj_qd.cuda()
+        num_frames, bs, _ = rj_q.shape
+        dm = hip_backend.device_model(env)
+        jq = rj_q.detach().to(torch.float32).contiguous()
+        jqd = rj_qd.detach().to(torch.float32).contiguous()
+        body_q, body_qd = dm.fk_forward(jq.view(num_frames * bs, -1), jqd.view(num_frames * bs, -1))
+        ctx.dm, ctx.shape, ctx.is_cuda = dm, (num_frames, bs), is_cuda
+        ctx.save_for_backward(jq, jqd)
+        body_q = body_q.view(num_frames, bs, dm.nb, 7).permute(1, 0, 2, 3).contiguous()
+        body_qd = body_qd.view(num_frames, bs, dm.nb, 6).permute(1, 0, 2, 3).contiguous()
+        body_q_numpy = list(body_q[0].detach().cpu().numpy())  # env 0, one array per frame (visualisation)
+        if not is_cuda:
+            body_q, body_qd = body_q.cpu(), body_qd.cpu()
+        return body_q, body_qd, body_q_numpy
+
+    @staticmethod
+    def backward(ctx, adj_body_qs, adj_body_qd, _):
+        jq, jqd = ctx.saved_tensors
+        num_frames, bs = ctx.shape
+        dm = ctx.dm
+        aq = adj_body_qs.to(jq.device, torch.float32).permute(1, 0, 2, 3).contiguous()
+        aqd = adj_body_qd.to(jq.device, torch.float32).permute(1, 0, 2, 3).contiguous()
+        gq, gqd = dm.fk_backward(jq.view(num_frames * bs, -1), jqd.view(num_frames * bs, -1), aq, aqd)
+
+        def post(g, last):  # dp_model.py:1109-1110,1122-1123: NaN -> 0, values > 1 -> 1 (upper clamp only)
+            g = g.view(num_frames, bs, last)
+            g = torch.where(g.isnan(), torch.zeros_like(g), g)
+            g = torch.where(g > 1, torch.ones_like(g), g)
+            return g if ctx.is_cuda else g.cpu()
+
+        return post(gq, dm.nq), post(gqd, dm.nqd), None
+
+
+class ForwardWarp(torch.autograd.Function):
+    """ForwardWarp.apply(q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass,
+    body_inv_mass, body_inertia, body_inv_inertia, self) -> (wp_pos [F,bs*nb,7], wp_vel [F,bs*nb,6]).
+
+    Read from ``self``: ``env``, ``steps_idx``, ``frame2step``, ``dt``, ``num_envs``.
+    Written to ``self``: ``grfs``, ``jafs`` (lists of F tensors [bs*nb,6]), ``sim_trajs`` (F numpy [nb,7], env 0)."""
+
+    @staticmethod
+    def forward(ctx, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia,
+                body_inv_inertia, self):
+        env = self.env
+        dm = hip_backend.device_model(env)
+        bs = int(self.num_envs)
+        nsteps = len(self.steps_idx)
+        frame2step = list(self.frame2step)
+        dev = q_init.device
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
+                              body_inv_inertia)]
+        fos = frame_of_step_tensor(nsteps, frame2step, dev)
+        wp_pos, wp_vel, grf, jaf, ws = dm.rollout_forward(bs, nsteps, self.dt, *inp, frame_of_step=fos,
+                                                          nframes=len(frame2step))
+        ctx.dm, ctx.meta = dm, (bs, nsteps, float(self.dt), len(frame2step))
+        ctx.save_for_backward(ws, fos, *inp)
+        ctx.mass_shape = body_mass.shape
+        # side outputs consumed by phys_model.query() (dp_model.py:855-860)
+        self.grfs = list(grf.unbind(0))
+        self.jafs = list(jaf.unbind(0))
+        self.sim_trajs = list(wp_pos[:, : dm.nb].detach().cpu().numpy())
+        return wp_pos, wp_vel
+
+    @staticmethod
+    def backward(ctx, adj_body_qs, adj_body_qd):
+        ws, fos, q_init, qd_init, torques, res_f, refs, ke, kd, inv_m, inertia, inv_inertia = ctx.saved_tensors
+        bs, nsteps, dt, nframes = ctx.meta
+        g = ctx.dm.rollout_backward(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia, fos,
+                                    nframes, ws, adj_body_qs.to(torch.float32).contiguous(),
+                                    adj_body_qd.to(torch.float32).contiguous())
+        s = _scrub_nan
+        return (s(g["q_init"]), s(g["qd_init"]), s(g["torques"]).view_as(torques), s(g["res_f"]).view_as(res_f),
+                s(g["refs"]).view_as(refs), s(g["target_ke"]), s(g["target_kd"]),
+                torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), s(g["body_inv_mass"]),
+                s(g["body_inertia"]).view_as(inertia), s(g["body_inv_inertia"]).view_as(inv_inertia), None)

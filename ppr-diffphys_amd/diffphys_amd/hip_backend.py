@@ -1,0 +1,208 @@
+"""ctypes binding of ``lib/libpprdiffphys_hip.so`` (C ABI: include/ppr_diffphys.h).
+
+PyTorch is used here only as plumbing: device memory (``tensor.data_ptr()``) and
+the current HIP stream.  There is NO fallback: if the library is missing or a
+tensor is not a contiguous float32 CUDA(HIP) tensor, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
+_lib = None
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [
+        ("nb", ctypes.c_int), ("nq", ctypes.c_int), ("nqd", ctypes.c_int), ("nc", ctypes.c_int), ("nmat", ctypes.c_int),
+        ("joint_type", _ip), ("joint_parent", _ip), ("joint_q_start", _ip), ("joint_qd_start", _ip),
+        ("joint_X_p", _fp), ("joint_X_c", _fp), ("joint_axis", _fp), ("body_com", _fp),
+        ("joint_limit_lower", _fp), ("joint_limit_upper", _fp), ("joint_limit_ke", _fp), ("joint_limit_kd", _fp),
+        ("contact_body", _ip), ("contact_point", _fp), ("contact_dist", _fp), ("contact_material", _ip),
+        ("shape_materials", _fp), ("gravity", ctypes.c_float * 3),
+        ("joint_attach_ke", ctypes.c_float), ("joint_attach_kd", ctypes.c_float),
+    ]
+
+
+def lib():
+    """Loads the HIP library; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                "libpprdiffphys_hip.so not found at %s -- build it with `make -C ppr-diffphys_amd/csrc` "
+                "(there is no CPU fallback for the product path)" % _LIB_PATH
+            )
+        L = ctypes.CDLL(_LIB_PATH)
+        L.pd_last_error.restype = ctypes.c_char_p
+        L.pd_rollout_workspace_floats.restype = ctypes.c_size_t
+        L.pd_rollout_workspace_floats.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.pd_model_create.argtypes = [ctypes.POINTER(_Desc), ctypes.POINTER(ctypes.c_void_p)]
+        L.pd_model_destroy.argtypes = [ctypes.c_void_p]
+        L.pd_model_set_segment_width.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.pd_model_get_segment_width.argtypes = [ctypes.c_void_p]
+        L.pd_last_kernel_ms.restype = ctypes.c_float
+        L.pd_last_kernel_ms.argtypes = [ctypes.c_int]
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        L.pd_rollout_forward.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, vp] + [vp] * 5 + [vp]
+        L.pd_rollout_backward.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, vp] + [vp] * 3 + [vp] * 10 + [vp]
+        L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
+        L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
+        if L.pd_abi_version() != 1:
+            raise RuntimeError("libpprdiffphys_hip.so ABI mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError("ppr_diffphys: " + lib().pd_last_error().decode())
+
+
+def _dev(t, name, shape_numel=None):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch tensor" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if shape_numel is not None and t.numel() != shape_numel:
+        raise ValueError("%s has %d elements, expected %d" % (name, t.numel(), shape_numel))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceModel:
+    """Device copy of one articulation template (``pd_model``)."""
+
+    def __init__(self, tpl):
+        L = lib()
+        f = lambda k: np.ascontiguousarray(tpl[k], dtype=np.float32)
+        i = lambda k: np.ascontiguousarray(tpl[k], dtype=np.int32)
+        self.nb, self.nq, self.nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+        keep = dict(
+            joint_type=i("joint_type"), joint_parent=i("joint_parent"), joint_q_start=i("joint_q_start"),
+            joint_qd_start=i("joint_qd_start"), joint_X_p=f("joint_X_p"), joint_X_c=f("joint_X_c"),
+            joint_axis=f("joint_axis"), body_com=f("body_com"), joint_limit_lower=f("joint_limit_lower"),
+            joint_limit_upper=f("joint_limit_upper"), joint_limit_ke=f("joint_limit_ke"),
+            joint_limit_kd=f("joint_limit_kd"), contact_body=i("contact_body"), contact_point=f("contact_point"),
+            contact_dist=f("contact_dist"), contact_material=i("contact_material"), shape_materials=f("shape_materials"),
+        )
+        d = _Desc()
+        d.nb, d.nq, d.nqd = self.nb, self.nq, self.nqd
+        d.nc, d.nmat = len(keep["contact_body"]), len(keep["shape_materials"])
+        for k, a in keep.items():
+            setattr(d, k, a.ctypes.data_as(_ip if a.dtype == np.int32 else _fp))
+        g = np.asarray(tpl["gravity"], dtype=np.float32)
+        d.gravity = (ctypes.c_float * 3)(float(g[0]), float(g[1]), float(g[2]))
+        d.joint_attach_ke = float(tpl["joint_attach_ke"])
+        d.joint_attach_kd = float(tpl["joint_attach_kd"])
+        h = ctypes.c_void_p()
+        _check(L.pd_model_create(ctypes.byref(d), ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().pd_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_segment_width(self, lanes):
+        _check(lib().pd_model_set_segment_width(self.h, int(lanes)))
+
+    def segment_width(self):
+        return int(lib().pd_model_get_segment_width(self.h))
+
+    def workspace_floats(self, bs, nsteps):
+        return int(lib().pd_rollout_workspace_floats(self.h, bs, nsteps))
+
+    # -- rollout ----------------------------------------------------------------
+    def rollout_forward(self, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass,
+                        body_inertia, body_inv_inertia, frame_of_step, nframes, want_forces=True):
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        dev = q_init.device
+        if frame_of_step.dtype != torch.int32 or not frame_of_step.is_cuda or frame_of_step.numel() != nsteps + 1:
+            raise ValueError("frame_of_step must be an int32 GPU tensor of nsteps+1 entries")
+        ws = torch.empty(self.workspace_floats(bs, nsteps), dtype=torch.float32, device=dev)
+        wp_pos = torch.empty(nframes, bs * nb, 7, dtype=torch.float32, device=dev)
+        wp_vel = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev)
+        grf = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev) if want_forces else None
+        jaf = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev) if want_forces else None
+        _check(lib().pd_rollout_forward(
+            self.h, bs, nsteps, float(dt), _dev(q_init, "q_init", bs * nq), _dev(qd_init, "qd_init", bs * nqd),
+            _dev(torques, "torques", nsteps * bs * nqd), _dev(res_f, "res_f", nsteps * bs * nb * 6),
+            _dev(refs, "refs", nsteps * bs * nqd), _dev(target_ke, "target_ke", bs * nqd),
+            _dev(target_kd, "target_kd", bs * nqd), _dev(body_inv_mass, "body_inv_mass", bs * nb),
+            _dev(body_inertia, "body_inertia", bs * nb * 9), _dev(body_inv_inertia, "body_inv_inertia", bs * nb * 9),
+            nframes, ctypes.c_void_p(frame_of_step.data_ptr()), _dev(ws, "workspace"), _dev(wp_pos, "wp_pos"),
+            _dev(wp_vel, "wp_vel"), _dev(grf, "grf") if want_forces else None, _dev(jaf, "jaf") if want_forces else None,
+            _stream()))
+        return wp_pos, wp_vel, grf, jaf, ws
+
+    def rollout_backward(self, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, body_inv_mass,
+                         body_inertia, body_inv_inertia, frame_of_step, nframes, ws, adj_pos, adj_vel):
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        dev = q_init.device
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        g = dict(q_init=e(bs * nq), qd_init=e(bs * nqd), torques=e(nsteps, bs * nqd), res_f=e(nsteps, bs * nb, 6),
+                 refs=e(nsteps, bs * nqd), target_ke=e(bs * nqd), target_kd=e(bs * nqd), body_inv_mass=e(bs * nb),
+                 body_inertia=e(bs * nb, 3, 3), body_inv_inertia=e(bs * nb, 3, 3))
+        _check(lib().pd_rollout_backward(
+            self.h, bs, nsteps, float(dt), _dev(q_init, "q_init", bs * nq), _dev(qd_init, "qd_init", bs * nqd),
+            _dev(torques, "torques", nsteps * bs * nqd), _dev(refs, "refs", nsteps * bs * nqd),
+            _dev(target_ke, "target_ke", bs * nqd), _dev(target_kd, "target_kd", bs * nqd),
+            _dev(body_inv_mass, "body_inv_mass", bs * nb), _dev(body_inertia, "body_inertia", bs * nb * 9),
+            _dev(body_inv_inertia, "body_inv_inertia", bs * nb * 9), nframes, ctypes.c_void_p(frame_of_step.data_ptr()),
+            _dev(ws, "workspace", self.workspace_floats(bs, nsteps)), _dev(adj_pos, "adj_pos", nframes * bs * nb * 7),
+            _dev(adj_vel, "adj_vel", nframes * bs * nb * 6), _dev(g["q_init"], "g"), _dev(g["qd_init"], "g"),
+            _dev(g["torques"], "g"), _dev(g["res_f"], "g"), _dev(g["refs"], "g"), _dev(g["target_ke"], "g"),
+            _dev(g["target_kd"], "g"), _dev(g["body_inv_mass"], "g"), _dev(g["body_inertia"], "g"),
+            _dev(g["body_inv_inertia"], "g"), _stream()))
+        return g
+
+    # -- FK -----------------------------------------------------------------------
+    def fk_forward(self, joint_q, joint_qd):
+        n = joint_q.numel() // self.nq
+        dev = joint_q.device
+        body_q = torch.empty(n, self.nb, 7, dtype=torch.float32, device=dev)
+        body_qd = torch.empty(n, self.nb, 6, dtype=torch.float32, device=dev)
+        _check(lib().pd_fk_forward(self.h, n, _dev(joint_q, "joint_q", n * self.nq), _dev(joint_qd, "joint_qd", n * self.nqd),
+                                   _dev(body_q, "body_q"), _dev(body_qd, "body_qd"), _stream()))
+        return body_q, body_qd
+
+    def fk_backward(self, joint_q, joint_qd, adj_body_q, adj_body_qd):
+        n = joint_q.numel() // self.nq
+        dev = joint_q.device
+        gq = torch.empty(n, self.nq, dtype=torch.float32, device=dev)
+        gqd = torch.empty(n, self.nqd, dtype=torch.float32, device=dev)
+        _check(lib().pd_fk_backward(self.h, n, _dev(joint_q, "joint_q", n * self.nq), _dev(joint_qd, "joint_qd", n * self.nqd),
+                                    _dev(adj_body_q, "adj_body_q", n * self.nb * 7),
+                                    _dev(adj_body_qd, "adj_body_qd", n * self.nb * 6), _dev(gq, "g"), _dev(gqd, "g"), _stream()))
+        return gq, gqd
+
+
+def set_timing(on):
+    lib().pd_set_timing(1 if on else 0)
+
+
+def last_kernel_ms(kind):
+    return float(lib().pd_last_kernel_ms(int(kind)))
+
+
+def device_model(env):
+    """DeviceModel of a :class:`diffphys_amd.sim.Model`, cached on the model."""
+    if env._handle is None:
+        env._handle = DeviceModel(env.template())
+    return env._handle
