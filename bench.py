@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s (forward + adjoint) of batched Laikago rollouts on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  * one process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE from env)
+  * a "step" = one forward rollout + one adjoint rollout over the rank's batch: bs envs x T sim steps
+  * workload (BASELINE.json metric / SURVEY.md section 8(d) config C4): Laikago, mixed mi-trot / mi-spin
+    mocap targets, bs = 4096 envs PER GPU (weak scaling: envs are independent, batch split only, no
+    collective on the data path), T = 100 sim steps (4 frames, frame2step = 0,33,66,99), dt = 5e-4, fp32
+  * inputs are resident in HBM before the timed region; timed region is bracketed by barrier + synchronize
+  * rank 0 prints ONE JSON line (value = whole-job env-steps/s, max time over ranks)
+
+Extra objects on the line:
+  roofline     dominant kernel (the adjoint rollout): algorithmic HBM bytes per launch / its average launch
+               duration measured live with HIP events on the launch stream (pd_set_timing); peak = 8 TB/s
+  cpu_baseline the C oracle (oracle/ref_c, fp32, OpenMP over envs: "CPU restatement of the reference
+               algorithm, not Warp") timed on this host, rank 0, N = 1 only, on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ppr-diffphys_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_BYTES = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(nb, nqd):
+    """per env-step, fp32.  forward = state spill + controls read;
+    adjoint = state read + controls read + control grads written."""
+    c = 2 * nqd + 6 * nb
+    fwd = 4 * (13 * nb + c)
+    bwd = 4 * (13 * nb + 2 * c)
+    return fwd, bwd
+
+
+def shard_envs(global_bs, world, rank):
+    """Contiguous env slice of a global batch for `rank`."""
+    per = global_bs // world
+    rem = global_bs % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def cpu_baseline(tpl, robot, nsteps, seqs, budget_s=12.0):
+    from diffphys_amd import synth
+    from oracle import ref_c
+
+    ref_c.build()
+    rc = ref_c.RefC(tpl, np.float32)
+
+    def run(bs):
+        inp = synth.make_inputs(tpl, robot, bs=bs, nsteps=nsteps, seed=123, seqs=seqs)
+        t0 = time.perf_counter()
+        st = rc.rollout_forward(inp, nsteps, inp["frame2step"], inp["dt"])
+        rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+        return time.perf_counter() - t0
+
+    threads = rc.num_threads()
+    probe_bs = 8 * threads
+    run(probe_bs)  # warm (page faults, OpenMP pool)
+    tp = run(probe_bs)
+    bs = int(min(4096, max(probe_bs, probe_bs * budget_s / max(tp, 1e-6))))
+    bs = max(threads, (bs // threads) * threads)
+    t = run(bs)
+    return {
+        "value": bs * nsteps / t,
+        "unit": "env-steps/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "C oracle fp32 (CPU restatement of the reference algorithm, not Warp), OpenMP over envs: "
+        "%d envs x %d steps fwd+adjoint in %.1f s" % (bs, nsteps, t),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--T", type=int, default=100, help="sim steps per rollout")
+    ap.add_argument("--robot", default="laikago")
+    ap.add_argument("--segw", type=int, default=0, help="lanes per articulation (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from diffphys_amd import dp_model, hip_backend, robots, synth
+
+    tpl = robots.load_template(args.robot)
+    seqs = ("mi-trot", "mi-spin") if args.robot == "laikago" else ("mi-pace",)
+    bs, T = args.bs, args.T
+    # each rank builds ITS slice of the global batch (seed differs per rank => different envs)
+    inp = synth.make_inputs(tpl, args.robot, bs=bs, nsteps=T, seed=1000 + rank, seqs=seqs)
+    dm = hip_backend.DeviceModel(tpl)
+    if args.segw:
+        dm.set_segment_width(args.segw)
+    t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
+    f2s = inp["frame2step"]
+    fos = dp_model.frame_of_step_tensor(T, f2s, dev)
+    fwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass",
+                               "body_inertia", "body_inv_inertia")]
+    bwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "refs", "target_ke", "target_kd", "body_inv_mass",
+                               "body_inertia", "body_inv_inertia")]
+    adj_pos = torch.from_numpy(inp["adj_pos"]).to(dev)
+    adj_vel = torch.from_numpy(inp["adj_vel"]).to(dev)
+
+    def step():
+        out = dm.rollout_forward(bs, T, inp["dt"], *fwd_args, frame_of_step=fos, nframes=len(f2s))
+        return dm.rollout_backward(bs, T, inp["dt"], *bwd_args, fos, len(f2s), out[4], adj_pos, adj_vel)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    bad = int(torch.isnan(g["q_init"]).sum().item())
+
+    # per-kernel device time (HIP events on the launch stream), outside the timed region
+    hip_backend.set_timing(True)
+    kf, kb = [], []
+    for _ in range(max(5, min(args.steps, 20))):
+        step()
+        torch.cuda.synchronize()
+        kf.append(hip_backend.last_kernel_ms(0))
+        kb.append(hip_backend.last_kernel_ms(1))
+    hip_backend.set_timing(False)
+    fwd_ms, bwd_ms = float(np.mean(kf)), float(np.mean(kb))
+
+    if rank == 0:
+        nb, nqd = int(tpl["nb"]), int(tpl["nqd"])
+        bf, bb = algorithmic_bytes(nb, nqd)
+        ach_bwd = bs * T * bb / (bwd_ms * 1e-3)
+        ach_fwd = bs * T * bf / (fwd_ms * 1e-3)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("k_rollout_bwd", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "env-steps/sec (fwd+adjoint), Laikago 12-DoF, batch=4096, 1/2/4/8 MI355X",
+            "value": world * bs * T * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s, mixed %s mocap targets, %d envs per GPU x %d sim steps (4 frames), dt=5e-4, "
+                "fwd+adjoint, batch split only (no collective)" % (args.robot, "/".join(seqs), bs, T),
+                "global_batch": world * bs,
+                "envs_per_gpu": bs,
+                "sim_steps": T,
+                "segment_lanes": dm.segment_width(),
+                "nan_grads": bad,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_rollout_bwd",
+                "achieved": ach_bwd / 1e9,
+                "peak": HBM_PEAK_BYTES / 1e9,
+                "unit": "GB/s",
+                "frac": ach_bwd / HBM_PEAK_BYTES,
+                "traffic": traffic,
+                "avg_launch_ms": bwd_ms,
+                "algorithmic_bytes_per_env_step": bb,
+                "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,
+                               "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_env_step": bf},
+                "note": "VALU/latency-bound, not HBM-bound: see DESIGN.md section 5",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tpl, args.robot, T, seqs)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

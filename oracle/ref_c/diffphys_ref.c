@@ -105,6 +105,9 @@ static inline qt q_axis_angle(v3 axis, real ang) {
   real s = R_SIN(ang * (real)0.5), c = R_COS(ang * (real)0.5);
   return Q(axis.x * s, axis.y * s, axis.z * s, c);
 }
+/* d/dx acos(x) = -1/sqrt(1-x^2), d/dx asin(x) = +1/sqrt(1-x^2); like Warp's builtin adjoints the
+ * contribution is dropped (not inf) where sqrt(1-x^2) is not > 0.  POLICY, see DESIGN.md section 6. */
+static inline real inv_sqrt_1mx2(real x) { real d = R_SQRT((real)1 - x * x); return d > (real)0 ? (real)1 / d : (real)0; }
 static inline real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 static inline real clamp_pass(real x, real lo, real hi) { return (x < lo || x > hi) ? (real)0 : (real)1; }
 
@@ -464,7 +467,7 @@ static void quat_decompose_adj(qt q, const real *g, qt *adj_q) {
   v3 a0 = V(0, 0, 0), a1 = a0, a2 = a0;
   real gphi = -g[0], gth = -g[1], gpsi = -g[2];
   { real y = c2.y, x = c2.z, d = x * x + y * y; a2.y += gphi * x / d; a2.z += -gphi * y / d; }
-  { real s = -c2.x; a2.x += -gth / R_SQRT((real)1 - s * s); }
+  { real s = -c2.x; a2.x += -gth * inv_sqrt_1mx2(s); }
   { real y = c1.x, x = c0.x, d = x * x + y * y; a1.x += gpsi * x / d; a0.x += -gpsi * y / d; }
   adj_qrot(q, ex, adj_q, NULL, a0); adj_qrot(q, ey, adj_q, NULL, a1); adj_qrot(q, ez, adj_q, NULL, a2);
 }
@@ -593,7 +596,7 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
       v3 adj_rv = V(0, 0, 0);
       adj_vnormalize(rv, &adj_rv, adj_nrm);
       adj_r_err.x += adj_rv.x; adj_r_err.y += adj_rv.y; adj_r_err.z += adj_rv.z;
-      adj_r_err.w += -(real)2 * adj_ac / R_SQRT((real)1 - c.r_err.w * c.r_err.w);
+      adj_r_err.w += -(real)2 * adj_ac * inv_sqrt_1mx2(c.r_err.w);
     }
     if (c.ty == JOINT_REVOLUTE) {
       v3 axis = ld3(t->axis + i * 3);
@@ -622,7 +625,7 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
       /* qd = dot(w_err, axis_p) */
       vacc(&adj_w_err, vscale(axis_p, adj_qd)); vacc(&adj_axis_p, vscale(c.w_err, adj_qd));
       /* q = acos(twist.w)*2*sgn */
-      qt adj_twist = Q(0, 0, 0, -adj_q * (real)2 * sgn / R_SQRT((real)1 - twist.w * twist.w));
+      qt adj_twist = Q(0, 0, 0, -adj_q * (real)2 * sgn * inv_sqrt_1mx2(twist.w));
       qt adj_tq = Q(0, 0, 0, 0);
       adj_qnormalize(tq, &adj_tq, adj_twist);
       real adj_da = vdot(qv(adj_tq), axis);

@@ -88,6 +88,33 @@ def dot(a, b):
     return (a * b).sum(-1)
 
 
+class _GuardedArc(torch.autograd.Function):
+    """acos / asin whose adjoint drops the contribution (instead of inf) where sqrt(1-x^2) is not > 0,
+    like Warp's builtin adjoints.  POLICY, see DESIGN.md section 6."""
+
+    @staticmethod
+    def forward(ctx, x, is_acos):
+        ctx.save_for_backward(x)
+        ctx.is_acos = is_acos
+        return torch.acos(x) if is_acos else torch.asin(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        d = torch.sqrt(1.0 - x * x)
+        ok = d > 0
+        inv = torch.where(ok, 1.0 / torch.where(ok, d, torch.ones_like(d)), torch.zeros_like(d))
+        return (-g * inv if ctx.is_acos else g * inv), None
+
+
+def acos_g(x):
+    return _GuardedArc.apply(x, True)
+
+
+def asin_g(x):
+    return _GuardedArc.apply(x, False)
+
+
 # ------------------------------------------------------------------- template
 class Template:
     """Template arrays as torch tensors of a chosen dtype (ints stay python lists)."""
@@ -218,7 +245,7 @@ def quat_decompose(q):
     c0, c1, c2 = q_rot(q, e[0].expand(bs, 3)), q_rot(q, e[1].expand(bs, 3)), q_rot(q, e[2].expand(bs, 3))
     # mat33(c0,c1,c2) fills columns: R[r,c] = c_c[r]
     phi = torch.atan2(c2[:, 1], c2[:, 2])
-    theta = torch.asin(-c2[:, 0])
+    theta = asin_g(-c2[:, 0])
     psi = torch.atan2(c1[:, 0], c0[:, 0])
     return -torch.stack([phi, theta, psi], -1)
 
@@ -256,7 +283,7 @@ def eval_body_joints(T, body_q, body_qd, body_f, target, act, target_ke, target_
         t_total = torch.zeros(bs, 3, dtype=T.dtype)
         f_total = torch.zeros(bs, 3, dtype=T.dtype)
         if ty == JOINT_FIXED:  # :385-390
-            ang_err = safe_normalize(r_err[:, :3]) * (torch.acos(r_err[:, 3]) * 2.0)[:, None]
+            ang_err = safe_normalize(r_err[:, :3]) * (acos_g(r_err[:, 3]) * 2.0)[:, None]
             f_total = f_total + x_err * ake + v_err * akd
             t_total = t_total + q_rot(q_p, ang_err) * ake + w_err * akd * ads
         elif ty == JOINT_REVOLUTE:  # :392-409
@@ -266,7 +293,7 @@ def eval_body_joints(T, body_q, body_qd, body_f, target, act, target_ke, target_
             a = dot(r_err[:, :3], axis)[:, None] * axis
             twist = q_normalize(torch.cat([a, r_err[:, 3:]], -1))
             sgn = torch.where(dot(axis, twist[:, :3]) < 0, -1.0, 1.0).to(T.dtype)
-            q = torch.acos(twist[:, 3]) * 2.0 * sgn
+            q = acos_g(twist[:, 3]) * 2.0 * sgn
             qd = dot(w_err, axis_p)
             sl = slice(qds, qds + 1)
             t_total = eval_joint_force(

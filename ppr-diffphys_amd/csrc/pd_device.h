@@ -305,7 +305,7 @@ PD_DEV void quat_decompose_adj(qt q, const float *g, qt &adj_q) {
   v3 a0 = V3(0, 0, 0), a1 = a0, a2 = a0;
   float gphi = -g[0], gth = -g[1], gpsi = -g[2];
   { float y = c2.y, x = c2.z, d = x * x + y * y; a2.y += gphi * x / d; a2.z += -gphi * y / d; }
-  { float s = -c2.x; a2.x += -gth / sqrtf(1.0f - s * s); }
+  { float s = -c2.x; a2.x += -gth * inv_sqrt_1mx2(s); }
   { float y = c1.x, x = c0.x, d = x * x + y * y; a1.x += gpsi * x / d; a0.x += -gpsi * y / d; }
   adj_qrot_q(q, ex, adj_q, a0); adj_qrot_q(q, ey, adj_q, a1); adj_qrot_q(q, ez, adj_q, a2);
 }
@@ -414,7 +414,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     v3 adj_rv = V3(0, 0, 0);
     adj_normalize(rv, adj_rv, adj_ang_err * ac);
     adj_r_err.x += adj_rv.x; adj_r_err.y += adj_rv.y; adj_r_err.z += adj_rv.z;
-    adj_r_err.w += -2.0f * dot(adj_ang_err, nrm) / sqrtf(1.0f - j.r_err.w * j.r_err.w);
+    adj_r_err.w += -2.0f * dot(adj_ang_err, nrm) * inv_sqrt_1mx2(j.r_err.w);
   }
   if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
     v3 axis_p = qrot(j.q_p, c.axis), axis_c = qrot(s.r, c.axis);
@@ -438,7 +438,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     a_tgt[0] = 0.f; a_act[0] = 0.f; a_ke[0] = 0.f; a_kd[0] = 0.f;
     joint_force_adj(q, qd, tgt[0], ke[0], kd[0], lo, up, lke, lkd, adj_jf, adj_q, adj_qd, a_tgt[0], a_ke[0], a_kd[0], a_act[0]);
     adj_w_err += axis_p * adj_qd; adj_axis_p += j.w_err * adj_qd;
-    qt adj_twist = Q4(0, 0, 0, -adj_q * 2.0f * sgn / sqrtf(1.0f - twist.w * twist.w));
+    qt adj_twist = Q4(0, 0, 0, -adj_q * 2.0f * sgn * inv_sqrt_1mx2(twist.w));
     qt adj_tq = Q4(0, 0, 0, 0);
     adj_qnormalize(tq, adj_tq, adj_twist);
     float adj_da = dot(qvec(adj_tq), c.axis);

@@ -50,6 +50,9 @@ PD_DEV qt q_axis_angle(v3 axis, float ang) {
   sincosf(ang * 0.5f, &s, &c);
   return Q4(axis.x * s, axis.y * s, axis.z * s, c);
 }
+// 1/sqrt(1-x^2) for the acos/asin adjoints; 0 (contribution dropped, not inf) where sqrt(1-x^2) is not > 0,
+// as Warp's builtin adjoints do.  POLICY, see DESIGN.md section 6.
+PD_DEV float inv_sqrt_1mx2(float x) { float d = sqrtf(1.0f - x * x); return d > 0.0f ? 1.0f / d : 0.0f; }
 PD_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 PD_DEV float clamp_pass(float x, float lo, float hi) { return (x < lo || x > hi) ? 0.0f : 1.0f; }
 PD_DEV v3 clamp3(v3 a, float l) { return V3(clampf(a.x, -l, l), clampf(a.y, -l, l), clampf(a.z, -l, l)); }

@@ -78,9 +78,12 @@ def lowest_contact_y(tpl, joint_q):
     return y.min(-1)
 
 
-def make_inputs(tpl, robot, bs, nsteps, seed=0, seqs=("mi-pace",), steps_per_frame=33, dt=DT, dtype=np.float32):
+def make_inputs(tpl, robot, bs, nsteps, seed=0, seqs=("mi-pace",), steps_per_frame=33, dt=DT, dtype=np.float32,
+                penetration=0.0):
     """Returns a dict with the 11 inputs (numpy), ``frame2step`` and the upstream
-    gradient seeds ``adj_pos`` / ``adj_vel`` of SURVEY.md section 8(d)."""
+    gradient seeds ``adj_pos`` / ``adj_vel`` of SURVEY.md section 8(d).  ``penetration`` lowers the root by
+    that many metres below the "lowest point touches y = 0" pose (parity tests use a few mm so that the
+    initial contacts are not sitting exactly on the non-differentiable c = 0 boundary)."""
     rng = np.random.RandomState(seed)
     nb, nq, nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
     ndof = nqd - 6
@@ -110,7 +113,7 @@ def make_inputs(tpl, robot, bs, nsteps, seed=0, seqs=("mi-pace",), steps_per_fra
         refs[:, :, 6:] = q_init[None, :, 7:] + 0.3 * np.sin(2 * np.pi * 2.0 * (t * dt)[:, None, None] + phase[None])
     q_init[:, 3:7] = root_q
     h = -lowest_contact_y(tpl, q_init)
-    q_init[:, 1] = h
+    q_init[:, 1] = h - penetration
     qd_init = np.zeros((bs, nqd))
     torques = np.zeros((nsteps, bs * nqd))
     res_f = np.zeros((nsteps, bs * nb, 6))

@@ -1,0 +1,158 @@
+"""Host-side logic: model compiler, URDF/mesh readers, dataloader, synthetic workloads, C-ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+from diffphys_amd import dataloader, robots, sim, synth
+from diffphys_amd.import_urdf import parse_urdf
+
+REF_DATA = "/root/reference/data/urdf_templates"
+
+URDF = """<?xml version="1.0"?>
+<robot name="toy">
+  <link name="base"><collision><origin xyz="0 0.1 0" rpy="0 0 0"/><geometry><box size="0.4 0.2 0.2"/></geometry></collision></link>
+  <link name="arm"><collision><origin xyz="0 -0.1 0" rpy="0 0 0"/><geometry><sphere radius="0.05"/></geometry></collision></link>
+  <link name="leg_R"><collision><geometry><sphere radius="0.01"/></geometry></collision></link>
+  <link name="leg_P"><collision><geometry><sphere radius="0.01"/></geometry></collision></link>
+  <link name="leg_Y"><collision><origin xyz="0 -0.2 0"/><geometry><mesh filename="tet.obj"/></geometry></collision></link>
+  <link name="tip"><collision><geometry><cylinder radius="0.02" length="0.1"/></geometry></collision></link>
+  <joint name="j_arm" type="continuous"><parent link="base"/><child link="arm"/><axis xyz="0 0 1"/><origin xyz="0.2 0 0" rpy="0 0 0.5"/><limit effort="1" velocity="1"/></joint>
+  <joint name="j_leg_R" type="revolute"><parent link="base"/><child link="leg_R"/><axis xyz="1 0 0"/><origin xyz="-0.2 0 0" rpy="0.1 0 0"/><limit lower="-1.5" upper="1.5" effort="1" velocity="1"/></joint>
+  <joint name="j_leg_P" type="revolute"><parent link="leg_R"/><child link="leg_P"/><axis xyz="0 1 0"/></joint>
+  <joint name="j_leg_Y" type="revolute"><parent link="leg_P"/><child link="leg_Y"/><axis xyz="0 0 1"/></joint>
+  <joint name="j_tip" type="fixed"><parent link="leg_Y"/><child link="tip"/><origin xyz="0 -0.4 0"/></joint>
+</robot>
+"""
+OBJ = "v 0 0 0\nv 0.1 0 0\nv 0 0.1 0\nv 0 0 0.1\nv 0 0 0\nf 1 3 2\nf 1 2 4\nf 2 3 4\nf 1 4 3\n"
+
+
+@pytest.fixture()
+def toy(tmp_path):
+    (tmp_path / "toy.urdf").write_text(URDF)
+    (tmp_path / "tet.obj").write_text(OBJ)
+    b = sim.ModelBuilder()
+    parse_urdf(str(tmp_path / "toy.urdf"), b, xform=sim.transform((0, 0.5, 0), sim.quat_identity()), floating=True, density=1000.0,
+               armature=0.01, stiffness=220.0, damping=2.0, shape_ke=1e4, shape_kd=0.0, shape_kf=1e2, shape_mu=1.0, limit_ke=0.0, limit_kd=0.0)
+    return b
+
+
+def test_parse_urdf_joint_mapping(toy):
+    b = toy
+    # root FREE, continuous->REVOLUTE, *_R -> COMPOUND with the *_Y link as child, *_P/*_Y skipped, fixed->FIXED
+    assert b.joint_type == [sim.JOINT_FREE, sim.JOINT_REVOLUTE, sim.JOINT_COMPOUND, sim.JOINT_FIXED]
+    assert b.joint_parent == [-1, 0, 0, 2]
+    assert b.joint_q_start == [0, 7, 8, 11] and b.joint_qd_start == [0, 6, 7, 10]
+    assert b.joint_coord_count == 11 and b.joint_dof_count == 10
+    assert b.joint_q[:7] == [0.0, 0.5, 0.0, 0.0, 0.0, 0.0, 1.0]
+    # limits: continuous keeps +-1e3, the compound joint takes the _R joint's limits on all three axes
+    assert b.joint_limit_lower[6] == -1e3 and b.joint_limit_upper[6] == 1e3
+    assert b.joint_limit_lower[7:10] == [-1.5] * 3 and b.joint_limit_upper[7:10] == [1.5] * 3
+    assert np.allclose(b.joint_X_p[1].p, [0.2, 0, 0]) and np.allclose(b.joint_X_p[1].q, sim.quat_rpy(0, 0, 0.5))
+
+
+def test_mass_properties_and_contacts(toy):
+    b = toy
+    # box 0.4 x 0.2 x 0.2 at density 1000, com = collision origin, inertia = armature + box inertia
+    m = 1000 * 0.4 * 0.2 * 0.2
+    assert abs(b.body_mass[0] - m) < 1e-9 and np.allclose(b.body_com[0], [0, 0.1, 0])
+    assert np.allclose(np.diag(b.body_inertia[0]), 0.01 + m / 12 * np.array([0.2**2 + 0.2**2, 0.4**2 + 0.2**2, 0.4**2 + 0.2**2]))
+    # tetrahedron (duplicate vertex merged): volume 0.1^3/6
+    assert abs(b.body_mass[2] - 1000 * 0.1**3 / 6) < 1e-9
+    assert len(b.shape_geo_src[2].vertices) == 4
+    top = sim.ModelBuilder()
+    top.add_rigid_articulation(b)
+    top.add_rigid_articulation(b)
+    env = top.finalize("cpu")
+    env.collide(None)
+    # box 8 corners + sphere 1 + mesh 4 vertices + capsule 2
+    assert len(env.t_contact_body) == 8 + 1 + 4 + 2 and env.contact_count == 2 * 15
+    assert list(env.t_contact_body) == [0] * 8 + [1] + [2] * 4 + [3] * 2
+    assert np.allclose(env.t_contact_point[8], [0, -0.1, 0]) and abs(env.t_contact_dist[8] - 0.05) < 1e-7
+    assert np.allclose(sorted(env.t_contact_point[:8, 1]), [0.0] * 4 + [0.2] * 4)
+    assert env.body_count == 8 and env.num_envs == 2 and env.body_com.shape == (8, 3)
+    with pytest.raises(NotImplementedError):
+        top.add_rigid_articulation(sim.ModelBuilder())
+
+
+@pytest.mark.parametrize("name,nb,nq,nqd,nc", [("laikago", 13, 19, 18, 3838), ("human", 19, 61, 60, 152), ("quad", 26, 82, 81, 208)])
+def test_compiled_templates(name, nb, nq, nqd, nc):
+    """Committed templates have the sizes of SURVEY.md section 8; if the reference data is mounted, recompiling reproduces them."""
+    tpl = robots.load_template(name)
+    assert (int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"]), len(tpl["contact_body"])) == (nb, nq, nqd, nc)
+    assert tpl["joint_type"][0] == sim.JOINT_FREE and tpl["joint_parent"][0] == -1
+    assert np.all(tpl["joint_parent"][1:] < np.arange(1, nb))
+    if os.path.isdir(REF_DATA):
+        env, _, info = robots.make_env(name, REF_DATA, 1, device="cpu")
+        fresh = env.template()
+        for k, v in fresh.items():
+            assert np.allclose(np.asarray(v, np.float64), np.asarray(tpl[k], np.float64), rtol=0, atol=1e-7), k
+    if name == "human":
+        assert np.allclose(tpl["body_mass"], 1.0)
+    if name == "laikago":
+        assert abs(float(tpl["body_mass"].sum()) - 7.7) < 0.1 and float(tpl["joint_attach_ke"]) == 16000.0
+
+
+def test_dataloader_and_bullet2gl():
+    dl = dataloader.DataLoader({"seqname": "mi-pace"})
+    assert dl.amp_info.shape == (39, 85) and abs(dl.frame_interval - 0.01667) < 1e-9
+    assert list(dl.data_info["offset"]) == [0, 39]
+    msm = dataloader.parse_amp(dl.amp_info[:2].copy())
+    pos0, orn0 = msm["pos"].copy(), msm["orn"].copy()
+    dataloader.bullet2gl(msm, False)
+    assert np.allclose(msm["pos"], pos0[:, [1, 2, 0]]) and np.allclose(msm["orn"][:, :3], orn0[:, [1, 2, 0]])
+    assert np.allclose(msm["orn"][:, 3], orn0[:, 3]) and msm["jang"].shape == (2, 12)
+
+
+def test_synth_inputs_shapes_and_ground_touch():
+    tpl = robots.load_template("laikago")
+    inp = synth.make_inputs(tpl, "laikago", bs=5, nsteps=67, seed=0, seqs=("mi-trot", "mi-spin"))
+    assert inp["frame2step"] == [0, 33, 66]
+    assert inp["refs"].shape == (67, 5 * 18) and inp["res_f"].shape == (67, 5 * 13, 6) and inp["body_inertia"].shape == (65, 3, 3)
+    assert np.all(inp["refs"].reshape(67, 5, 18)[:, :, :6] == 0)
+    low = synth.lowest_contact_y(tpl, inp["q_init"].reshape(5, -1).astype(np.float64))
+    assert np.abs(low).max() < 1e-6
+    again = synth.make_inputs(tpl, "laikago", bs=5, nsteps=67, seed=0, seqs=("mi-trot", "mi-spin"))
+    assert all(np.array_equal(inp[k], again[k]) for k in synth.INPUT_NAMES)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The built library loads without a GPU and exports exactly what include/ppr_diffphys.h declares."""
+    from diffphys_amd import hip_backend
+
+    hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pd_[a-z_]+)\s*\(", hdr)))
+    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and len(names) >= 13
+    lib = hip_backend.lib()
+    for n in names:
+        assert hasattr(lib, n), "missing symbol " + n
+    assert lib.pd_abi_version() == 1
+    lib.pd_rollout_workspace_floats.restype = ctypes.c_size_t
+    assert lib.pd_rollout_workspace_floats(None, 4, 10) == 0
+
+
+def test_boundary_rejects_bad_tensors():
+    """No silent fallback: CPU tensors / wrong dtype raise instead of computing somewhere else."""
+    import torch
+    from diffphys_amd import hip_backend
+
+    with pytest.raises(ValueError):
+        hip_backend._dev(torch.zeros(4), "x")
+    with pytest.raises(TypeError):
+        hip_backend._dev(np.zeros(4), "x")
+
+
+def test_frame_of_step():
+    from diffphys_amd.dp_model import convert_ppr_warp, frame_of_step_tensor
+    import torch
+
+    fos = frame_of_step_tensor(100, [0, 33, 66, 99], "cpu")
+    assert fos.shape == (101,) and fos[33] == 1 and fos[99] == 3 and fos[100] == -1 and int((fos >= 0).sum()) == 4
+    with pytest.raises(ValueError):
+        frame_of_step_tensor(10, [11], "cpu")
+    x = torch.arange(8.0)
+    assert convert_ppr_warp(x).tolist() == [3, 4, 5, 0, 1, 2, 6, 7]
