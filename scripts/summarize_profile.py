@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (rocprofv3 csv output of scripts/profile_gpu.sh) into committed summaries:
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.csv, profiles/<tag>_summary.md and profiles/pmc_summary.json
+(HBM bytes per launch with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md section HBM)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = [r for r in csv.DictReader(open(stats))]
+with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows[:6]:
+        w.writerow([r["Name"][:80], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+acc = collections.defaultdict(list)
+meta = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "rollout" not in r["Kernel_Name"]:
+                continue
+            k = "k_rollout_bwd" if "bwd" in r["Kernel_Name"] else "k_rollout_fwd"
+            acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            meta[k] = dict(grid=r["Grid_Size"], wg=r["Workgroup_Size"], lds=r["LDS_Block_Size"], vgpr=r["VGPR_Count"],
+                           agpr=r["Accum_VGPR_Count"], sgpr=r["SGPR_Count"], scratch=r["Scratch_Size"], name=r["Kernel_Name"])
+with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "counter", "launches", "mean_per_launch"])
+    for (k, c), v in sorted(acc.items()):
+        w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
+
+mean = lambda k, c: sum(acc[(k, c)]) / max(1, len(acc[(k, c)]))
+avg_ns = {("k_rollout_bwd" if "bwd" in r["Name"] else "k_rollout_fwd"): float(r["AverageNs"]) for r in rows if "rollout" in r["Name"]}
+summary = {}
+lines = ["# rocprofv3 summary `%s` (bench.py --steps 10 --warmup 2, 1x MI355X)\n" % tag,
+         "Source: `scripts/profile_gpu.sh %s` on the GPU box; raw csv under `gpurun_out/prof_%s/` (scratch)." % (tag, tag), ""]
+for k in ("k_rollout_fwd", "k_rollout_bwd"):
+    if k not in avg_ns:
+        continue
+    fetch_kb, write_kb = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
+    hbm = fetch_kb * 1024 * 2 + write_kb * 1024  # gfx950: FETCH_SIZE counts 128-B requests at 64 B
+    summary[k] = dict(avg_launch_ns=avg_ns[k], fetch_size_kb_raw=fetch_kb, write_size_kb=write_kb, hbm_bytes_per_launch=hbm,
+                      meta=meta.get(k, {}))
+    wc = mean(k, "SQ_WAVE_CYCLES")
+    lines += ["## %s  (%s)" % (k, meta.get(k, {}).get("name", "")),
+              "* average launch %.1f us; grid %s x wg %s; VGPR %s (+%s accum), SGPR %s, scratch %s" % (
+                  avg_ns[k] / 1e3, meta[k]["grid"], meta[k]["wg"], meta[k]["vgpr"], meta[k]["agpr"], meta[k]["sgpr"], meta[k]["scratch"]),
+              "* HBM: FETCH_SIZE %.0f KB raw (x2 gfx950 correction -> %.1f MB), WRITE_SIZE %.0f KB (%.1f MB) => %.1f MB per launch, %.0f GB/s" % (
+                  fetch_kb, fetch_kb * 2048 / 1e6, write_kb, write_kb * 1024 / 1e6, hbm / 1e6, hbm / avg_ns[k]),
+              "* SQ: waves %.0f, VALU insts %.3g, SALU %.3g, LDS %.3g, VMEM rd %.3g wr %.3g" % (
+                  mean(k, "SQ_WAVES"), mean(k, "SQ_INSTS_VALU"), mean(k, "SQ_INSTS_SALU"), mean(k, "SQ_INSTS_LDS"),
+                  mean(k, "SQ_INSTS_VMEM_RD"), mean(k, "SQ_INSTS_VMEM_WR")),
+              "* wave cycles (quad-cycles) %.3g: waiting (SQ_WAIT_ANY) %.0f%%, issuing (SQ_ACTIVE_INST_ANY) %.0f%%, issue-stalled (SQ_WAIT_INST_ANY) %.0f%%" % (
+                  wc, 100 * mean(k, "SQ_WAIT_ANY") / wc, 100 * mean(k, "SQ_ACTIVE_INST_ANY") / wc, 100 * mean(k, "SQ_WAIT_INST_ANY") / wc),
+              "* LDS: bank-conflict cycles %.3g of %.3g active (%.0f%%)" % (
+                  mean(k, "SQ_LDS_BANK_CONFLICT"), mean(k, "SQ_LDS_IDX_ACTIVE"),
+                  100 * mean(k, "SQ_LDS_BANK_CONFLICT") / max(1.0, mean(k, "SQ_LDS_IDX_ACTIVE"))), ""]
+open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines))
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print("\n".join(lines))

@@ -160,7 +160,8 @@ def test_edge_shapes(bs, T, f2s, dev, oracle_libs):
     st = rc.rollout_forward(inp, T, f2s, inp["dt"])
     gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
     assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-5
-    for k in ("q_init", "refs", "target_ke", "body_inertia"):
+    # (target_ke is left out here: with refs == current angles its gradient is fp32 round-off of (q - target) ~ 1e-10)
+    for k in ("q_init", "qd_init", "refs", "res_f", "body_inertia"):
         ref = gr[k]
         if np.abs(ref).max() > 0:
             assert relmax(out["grads"][k].reshape(ref.shape), ref) < 2e-2, k
