@@ -14,21 +14,24 @@
 enum { PD_JOINT_REVOLUTE = 1, PD_JOINT_FIXED = 3, PD_JOINT_FREE = 4, PD_JOINT_COMPOUND = 5 };
 enum { PD_JT_REVOLUTE = 1, PD_JT_COMPOUND = 2, PD_JT_FIXED = 4 };  // template mask bits
 
-#define PD_REC 20  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16] Ry[16:19]
+// LDS strides are odd so that lanes (= bodies) hit distinct banks with 4-byte accesses.
+#define PD_REC 21  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16] Ry[16:19]
 #define PD_ADJ 13  // floats of a body-state adjoint: p q w v
+#define PD_W6 7    // stride of a 6-float wrench slot
 
 struct PdDevModel {
-  int nb, nq, nqd, nc, nc_pad, nchunks, max_children, max_depth;
+  int nb, nq, nqd, nc, ntiles, max_children, max_depth;
   const int *jtype, *jparent, *qstart, *qdstart, *depth;  // [nb]
   const unsigned long long *children;                     // [nb] 8 child ids packed, 0xff = none
   const float *X_p, *X_c, *axis, *com;                    // [nb*7] [nb*7] [nb*3] [nb*3]
   const float *lim_lo, *lim_hi, *lim_ke, *lim_kd;         // [nqd]
-  const float4 *pts;                                      // [nc_pad] (x,y,z,dist), sorted by body
-  const unsigned char *pt_body;                           // [nc_pad]
-  const float4 *pt_mat;                                   // [nc_pad] (ke,kd,kf,mu)
-  const float4 *body_sphere;                              // [nb] centre + radius (r < 0: no points)
-  const float4 *chunk_sphere;                             // [nchunks] (r < 0: spans several bodies)
-  const unsigned long long *chunk_mask;                   // [nchunks] bodies present in the chunk
+  // ground-contact candidates, grouped by body and cut into tiles of <= SEGW spatially compact points
+  const float4 *pts;                                      // [nc] (x,y,z,dist)
+  const float4 *pt_mat;                                   // [nc] (ke,kd,kf,mu)
+  const float4 *body_sphere;                              // [nb] bounding sphere of the body's points (w < 0: none)
+  const float4 *tile_sphere;                              // [ntiles] bounding sphere (centre, radius + max dist)
+  const int4 *tile_info;                                  // [ntiles] (first point, count, body, 0)
+  const int2 *body_tiles;                                 // [nb] (first tile, tile count)
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
 };
@@ -66,6 +69,7 @@ struct BodyConst {
   unsigned long long children;
   v3 com, axis, p_pj, com_par;
   qt q_pj, q_off;
+  float4 sphere;  // bounding sphere of this body's contact candidates
 };
 
 PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
@@ -75,6 +79,7 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
   c.com = ld3(m.com + b * 3); c.axis = ld3(m.axis + b * 3);
   c.p_pj = ld3(m.X_p + b * 7); c.q_pj = ld4(m.X_p + b * 7 + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
+  c.sphere = m.body_sphere[b];
   return c;
 }
 

@@ -113,46 +113,34 @@ static int build_device(pd_model *m, int segw) {
     }
   }
   if (jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
-  // ---- contact table: sorted by body, kd-ordered inside a body, big bodies aligned to segw
-  std::vector<float4> pts, pt_mat;
-  std::vector<unsigned char> pt_body;
-  std::vector<int> pt_src;  // original index or -1 for padding
+  // ---- contact table: grouped by body, kd-ordered inside a body, cut into tiles of <= segw points
+  std::vector<float4> pts, pt_mat, tile_sphere;
+  std::vector<int4> tile_info;
+  std::vector<int2> body_tiles(nb, make_int2(0, 0));
   std::vector<float4> body_sphere(nb, make_float4(0, 0, 0, -1.0f));
-  const float4 dummy = make_float4(0.f, 0.f, 0.f, -1.0e30f);
-  auto pad_to = [&](size_t mult, int body) {
-    while (pts.size() % mult) { pts.push_back(dummy); pt_mat.push_back(make_float4(0, 0, 0, 0)); pt_body.push_back((unsigned char)body); pt_src.push_back(-1); }
-  };
   for (int b = 0; b < nb; ++b) {
     std::vector<int> ids;
     for (int k = 0; k < m->nc; ++k) if (m->cbody[k] == b) ids.push_back(k);
+    body_tiles[b] = make_int2((int)tile_info.size(), 0);
     if (ids.empty()) continue;
     body_sphere[b] = bound_sphere(ids, m->cpoint.data(), m->cdist.data());
-    bool big = (int)ids.size() >= segw;
-    if (big) { pad_to(segw, b); kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), segw); }
-    for (int k : ids) {
-      pts.push_back(make_float4(m->cpoint[k * 3], m->cpoint[k * 3 + 1], m->cpoint[k * 3 + 2], m->cdist[k]));
-      int mi = m->cmat[k];
-      if (mi < 0 || mi >= m->nmat) return fail("contact_material out of range");
-      pt_mat.push_back(make_float4(m->materials[mi * 4], m->materials[mi * 4 + 1], m->materials[mi * 4 + 2], m->materials[mi * 4 + 3]));
-      pt_body.push_back((unsigned char)b);
-      pt_src.push_back(k);
+    kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), segw);
+    for (size_t t0 = 0; t0 < ids.size(); t0 += segw) {
+      std::vector<int> tid(ids.begin() + t0, ids.begin() + std::min(ids.size(), t0 + segw));
+      tile_sphere.push_back(bound_sphere(tid, m->cpoint.data(), m->cdist.data()));
+      tile_info.push_back(make_int4((int)pts.size(), (int)tid.size(), b, 0));
+      body_tiles[b].y++;
+      for (int k : tid) {
+        pts.push_back(make_float4(m->cpoint[k * 3], m->cpoint[k * 3 + 1], m->cpoint[k * 3 + 2], m->cdist[k]));
+        int mi = m->cmat[k];
+        if (mi < 0 || mi >= m->nmat) return fail("contact_material out of range");
+        pt_mat.push_back(make_float4(m->materials[mi * 4], m->materials[mi * 4 + 1], m->materials[mi * 4 + 2], m->materials[mi * 4 + 3]));
+      }
     }
-    if (big) pad_to(segw, b);
   }
-  const int nc = (int)pts.size();
-  const int nchunks = (nc + segw - 1) / segw;
-  std::vector<float4> chunk_sphere(std::max(nchunks, 1), make_float4(0, 0, 0, -1.0f));
-  std::vector<unsigned long long> chunk_mask(std::max(nchunks, 1), 0ull);
-  for (int c = 0; c < nchunks; ++c) {
-    std::vector<int> ids;
-    unsigned long long mask = 0;
-    for (int i = c * segw; i < std::min(nc, (c + 1) * segw); ++i)
-      if (pt_src[i] >= 0) { ids.push_back(pt_src[i]); mask |= 1ull << pt_body[i]; }
-    chunk_mask[c] = mask;
-    if (mask && !(mask & (mask - 1))) chunk_sphere[c] = bound_sphere(ids, m->cpoint.data(), m->cdist.data());
-  }
-  const int nc_pad = ((nc + 63) / 64) * 64;
-  pts.resize(std::max(nc_pad, 64), dummy); pt_mat.resize(std::max(nc_pad, 64), make_float4(0, 0, 0, 0)); pt_body.resize(std::max(nc_pad, 64), 0);
+  const int nc = (int)pts.size(), ntiles = (int)tile_info.size();
+  if (pts.empty()) { pts.push_back(make_float4(0, 0, 0, 0)); pt_mat.push_back(make_float4(0, 0, 0, 0)); }
+  if (tile_info.empty()) { tile_info.push_back(make_int4(0, 0, 0, 0)); tile_sphere.push_back(make_float4(0, 0, 0, -1.0f)); }
 
   // ---- upload
   std::vector<unsigned char> buf;
@@ -160,8 +148,8 @@ static int build_device(pd_model *m, int segw) {
   size_t o_depth = put(buf, depth), o_children = put(buf, children);
   size_t o_Xp = put(buf, m->X_p), o_Xc = put(buf, m->X_c), o_axis = put(buf, m->axis), o_com = put(buf, m->com);
   size_t o_lo = put(buf, m->lim_lo), o_hi = put(buf, m->lim_hi), o_lke = put(buf, m->lim_ke), o_lkd = put(buf, m->lim_kd);
-  size_t o_pts = put(buf, pts), o_ptb = put(buf, pt_body), o_ptm = put(buf, pt_mat);
-  size_t o_bs = put(buf, body_sphere), o_cs = put(buf, chunk_sphere), o_cm = put(buf, chunk_mask);
+  size_t o_pts = put(buf, pts), o_ptm = put(buf, pt_mat);
+  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_sphere), o_ti = put(buf, tile_info), o_bt = put(buf, body_tiles);
   free_device(m);
   hipError_t e = hipMalloc(&m->blob, buf.size());
   if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
@@ -169,7 +157,7 @@ static int build_device(pd_model *m, int segw) {
   if (e != hipSuccess) return hip_fail(e, "hipMemcpy(model)");
   unsigned char *base = (unsigned char *)m->blob;
   PdDevModel &d = m->dev;
-  d.nb = nb; d.nq = m->nq; d.nqd = m->nqd; d.nc = nc; d.nc_pad = std::max(nc_pad, 64); d.nchunks = nchunks;
+  d.nb = nb; d.nq = m->nq; d.nqd = m->nqd; d.nc = nc; d.ntiles = ntiles;
   d.max_children = max_children; d.max_depth = max_depth;
   d.jtype = (const int *)(base + o_jtype); d.jparent = (const int *)(base + o_jparent);
   d.qstart = (const int *)(base + o_qstart); d.qdstart = (const int *)(base + o_qdstart);
@@ -178,14 +166,15 @@ static int build_device(pd_model *m, int segw) {
   d.axis = (const float *)(base + o_axis); d.com = (const float *)(base + o_com);
   d.lim_lo = (const float *)(base + o_lo); d.lim_hi = (const float *)(base + o_hi);
   d.lim_ke = (const float *)(base + o_lke); d.lim_kd = (const float *)(base + o_lkd);
-  d.pts = (const float4 *)(base + o_pts); d.pt_body = base + o_ptb; d.pt_mat = (const float4 *)(base + o_ptm);
-  d.body_sphere = (const float4 *)(base + o_bs); d.chunk_sphere = (const float4 *)(base + o_cs);
-  d.chunk_mask = (const unsigned long long *)(base + o_cm);
+  d.pts = (const float4 *)(base + o_pts); d.pt_mat = (const float4 *)(base + o_ptm);
+  d.body_sphere = (const float4 *)(base + o_bs); d.tile_sphere = (const float4 *)(base + o_ts);
+  d.tile_info = (const int4 *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
-  d.env_lds_floats = ((nb * (PD_REC + 6 + 2 * PD_ADJ) + nchunks + 3) / 4) * 4;
+  d.env_lds_floats = (nb * (PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles) | 1;  // odd: segments start on different banks
   const int envs_per_block = PD_WAVES * (64 / segw);
-  m->lds_rollout = (size_t)d.nc_pad * 17 + (size_t)envs_per_block * d.env_lds_floats * 4;
+  m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)((nb + 1) & ~1) * 8 +
+                   (size_t)envs_per_block * d.env_lds_floats * 4;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (m->lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   m->segw = segw; m->jt = jt;

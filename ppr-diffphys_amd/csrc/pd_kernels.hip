@@ -21,69 +21,82 @@ PD_DEV unsigned long long seg_ballot(bool pred, int seg) {
 }
 
 // Ground-contact sweep for one segment (= one env).  Three-level cull, all conservative, then the
-// exact test of the reference inside on_hit:
-//   L1  per body   : bounding sphere of all its candidate points vs y = 0        (lane = body)
-//   L2  per chunk  : chunk = SEGW consecutive points (sorted by body); body mask + chunk sphere (lane = chunk)
-//   L3  per point  : y-row test  c = p_y + Ry . x - dist                          (lane = point)
+// exact test of the reference inside on_hit.  Tables live in LDS (copied once per workgroup):
+//   L1  per body  : bounding sphere of all its candidate points vs y = 0          (lane = body)
+//   L2  per tile  : tile = <= SEGW spatially compact points of ONE body; sphere test (lane = tile of a surviving body)
+//   L3  per point : y-row test  c = p_y + Ry . x - dist                            (lane = point of a surviving tile)
 // on_hit(point index, body, record pointer, point float4) runs for lanes whose L3 value is <= eps.
+struct SweepTables {
+  const float4 *pts, *tsphere;
+  const int4 *tinfo;
+  const int2 *btiles;
+};
+
 template <int SEGW, typename F>
-PD_DEV void sweep_contacts(const PdDevModel &m, const float4 *pts, const unsigned char *ptb, const float *rec, int *list,
-                           bool env_ok, bool is_body, int seg, int l, F &&on_hit) {
+PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, float4 sphere, const float *rec, int *list, bool is_body,
+                           int seg, int l, F &&on_hit) {
   if (m.nc == 0) return;
   bool surv = false;
-  if (is_body) {
-    float4 sp = m.body_sphere[l];
-    if (sp.w >= 0.0f) {
-      const float *r = rec + l * PD_REC;
-      float ylow = r[1] + (r[16] * sp.x + r[17] * sp.y + r[18] * sp.z) - sp.w;
-      surv = !(ylow > 1e-4f * (1.0f + sp.w));
-    }
+  if (is_body && sphere.w >= 0.0f) {
+    const float *r = rec + l * PD_REC;
+    float ylow = r[1] + (r[16] * sphere.x + r[17] * sphere.y + r[18] * sphere.z) - sphere.w;
+    surv = !(ylow > 1e-4f * (1.0f + sphere.w));
   }
   unsigned long long wave_any = __ballot(surv);
   if (wave_any == 0ull) return;
-  const unsigned long long M = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;
+  unsigned long long mb = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;
+  const unsigned long long lt = (1ull << l) - 1ull;
   int nlist = 0;
-  for (int c0 = 0; c0 < m.nchunks; c0 += SEGW) {
-    int c = c0 + l;
-    bool pass = false;
-    if (env_ok && c < m.nchunks && M != 0ull) {
-      unsigned long long cm = m.chunk_mask[c];
-      pass = (cm & M) != 0ull;
-      if (pass) {
-        float4 sp = m.chunk_sphere[c];
-        if (sp.w >= 0.0f) {  // single-body chunk: sphere test against that body's pose
-          int b = __ffsll((long long)cm) - 1;
-          const float *r = rec + b * PD_REC;
-          float ylow = r[1] + (r[16] * sp.x + r[17] * sp.y + r[18] * sp.z) - sp.w;
-          pass = !(ylow > 1e-4f * (1.0f + sp.w));
-        }
-      }
+  while (__ballot(mb != 0ull) != 0ull) {  // one surviving body per segment per iteration
+    int bb = 0, nt = 0, t_first = 0;
+    if (mb != 0ull) {
+      bb = __ffsll((long long)mb) - 1;
+      mb &= mb - 1ull;
+      int2 bt = T.btiles[bb];
+      t_first = bt.x; nt = bt.y;
     }
-    unsigned long long ps = seg_ballot<SEGW>(pass, seg);
-    if (pass) list[nlist + __popcll(ps & ((1ull << l) - 1ull))] = c;
-    nlist += __popcll(ps);
+    const float *r = rec + bb * PD_REC;
+    const float py = r[1], ryx = r[16], ryy = r[17], ryz = r[18];
+    for (int t0 = 0; __ballot(t0 < nt) != 0ull; t0 += SEGW) {
+      int t = t0 + l;
+      bool pass = t < nt;
+      if (pass) {
+        float4 sp = T.tsphere[t_first + t];
+        float ylow = py + (ryx * sp.x + ryy * sp.y + ryz * sp.z) - sp.w;
+        pass = !(ylow > 1e-4f * (1.0f + sp.w));
+      }
+      unsigned long long ps = seg_ballot<SEGW>(pass, seg);
+      if (pass) list[nlist + __popcll(ps & lt)] = t_first + t;
+      nlist += __popcll(ps);
+    }
   }
   WAVE_SYNC();
   for (int k = 0; __ballot(k < nlist) != 0ull; ++k) {
     if (k < nlist) {
-      int pt = list[k] * SEGW + l;
-      if (pt < m.nc) {
-        float4 P = pts[pt];
-        int b = ptb[pt];
-        const float *r = rec + b * PD_REC;
+      int4 ti = T.tinfo[list[k]];
+      if (l < ti.y) {
+        float4 P = T.pts[ti.x + l];
+        const float *r = rec + ti.z * PD_REC;
         float cq = r[1] + (r[16] * P.x + r[17] * P.y + r[18] * P.z) - P.w;
-        if (cq <= 1e-4f) on_hit(pt, b, r, P);
+        if (cq <= 1e-4f) on_hit(ti.x + l, ti.z, r, P);
       }
     }
   }
 }
 
-PD_DEV void lds_copy_points(const PdDevModel &m, float4 *pts, unsigned char *ptb) {
-  for (int i = threadIdx.x; i < m.nc_pad; i += PD_BLOCK) pts[i] = m.pts[i];
-  const unsigned int *src = (const unsigned int *)m.pt_body;
-  unsigned int *dst = (unsigned int *)ptb;
-  for (int i = threadIdx.x; i < m.nc_pad / 4; i += PD_BLOCK) dst[i] = src[i];
+// Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.
+PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot) {
+  const int nc4 = m.nc > 0 ? m.nc : 1, nt4 = m.ntiles > 0 ? m.ntiles : 1, nbp = (m.nb + 1) & ~1;
+  float4 *pts = (float4 *)smem;
+  float4 *tsp = pts + nc4;
+  int4 *tin = (int4 *)(tsp + nt4);
+  int2 *btl = (int2 *)(tin + nt4);
+  for (int i = threadIdx.x; i < m.nc; i += PD_BLOCK) pts[i] = m.pts[i];
+  for (int i = threadIdx.x; i < m.ntiles; i += PD_BLOCK) { tsp[i] = m.tile_sphere[i]; tin[i] = m.tile_info[i]; }
+  for (int i = threadIdx.x; i < m.nb; i += PD_BLOCK) btl[i] = m.body_tiles[i];
   __syncthreads();
+  T.pts = pts; T.tsphere = tsp; T.tinfo = tin; T.btiles = btl;
+  return (float *)(btl + nbp) + (size_t)env_slot * m.env_lds_floats;
 }
 
 // =============================================================================================
@@ -100,12 +113,10 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
 
-  float4 *pts = (float4 *)smem;
-  unsigned char *ptb = smem + (size_t)m.nc_pad * 16;
-  float *scratch = (float *)(ptb + m.nc_pad) + (size_t)(wave * EPW + seg) * m.env_lds_floats;
-  float *rec = scratch, *facc = rec + nb * PD_REC, *pcon = facc + nb * 6;
-  int *list = (int *)(pcon + nb * 6);
-  lds_copy_points(m, pts, ptb);
+  SweepTables tabs;
+  float *scratch = lds_setup(m, smem, tabs, wave * EPW + seg);
+  float *rec = scratch, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
+  int *list = (int *)(pcon + nb * PD_W6);
 
   const BodyConst c = load_body_const(m, b);
   const int ec = env_ok ? env : 0;       // clamped env for safe addressing
@@ -123,7 +134,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
   }
   if (is_body) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) facc[b * 6 + k] = 0.f;
+    for (int k = 0; k < 6; ++k) facc[b * PD_W6 + k] = 0.f;
   }
 
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
@@ -138,18 +149,29 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
   }
 
   float *traj_q = a.ws, *traj_qd = a.ws + (size_t)a.nsteps * 7 * N, *traj_f = a.ws + (size_t)a.nsteps * 13 * N;
-  for (int step = 0; step < a.nsteps; ++step) {
-    // controls of this step
-    float tgt[ND], act[ND];
-    const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
+  // Controls are software-prefetched one step ahead: with one wavefront per SIMD there is no other
+  // wave to hide the HBM latency of a load issued at its point of use.
+  float n_tgt[ND], n_act[ND], n_rf[6];
+  auto load_controls = [&](int step) {
+    const int sc = step < a.nsteps ? step : a.nsteps - 1;
+    const size_t o = (size_t)sc * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
       bool on = k < ndof;
-      tgt[k] = on ? a.refs[oc + k] : 0.f;
-      act[k] = on ? a.torques[oc + k] : 0.f;
+      n_tgt[k] = on ? a.refs[o + k] : 0.f;
+      n_act[k] = on ? a.torques[o + k] : 0.f;
     }
-    const float *rf = a.res_f + ((size_t)step * N + idx) * 6;
-    v3 ft = V3(rf[0], rf[1], rf[2]), ff = V3(rf[3], rf[4], rf[5]);  // clear_forces + wp_add
+    const float *rf = a.res_f + ((size_t)sc * N + idx) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) n_rf[k] = rf[k];
+  };
+  if (a.nsteps > 0) load_controls(0);
+  for (int step = 0; step < a.nsteps; ++step) {
+    float tgt[ND], act[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
+    v3 ft = V3(n_rf[0], n_rf[1], n_rf[2]), ff = V3(n_rf[3], n_rf[4], n_rf[5]);  // clear_forces + wp_add
+    load_controls(step + 1);
     // spill the state for the adjoint (SoA planes: lanes of a wave write consecutive floats)
     if (is_body) {
       float *tq = traj_q + (size_t)step * 7 * N + idx, *td = traj_qd + (size_t)step * 6 * N + idx;
@@ -159,17 +181,17 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
       td[(size_t)3 * N] = s.v.x; td[(size_t)4 * N] = s.v.y; td[(size_t)5 * N] = s.v.z;
     }
     // ---- eval_body_contacts
-    sweep_contacts<SEGW>(m, pts, ptb, rec, list, env_ok, is_body, seg, l, [&](int pt, int pb, const float *r, float4 P) {
+    sweep_contacts<SEGW>(m, tabs, c.sphere, rec, list, is_body, seg, l, [&](int pt, int pb, const float *r, float4 P) {
       ContactOut o;
       if (contact_point_fwd(r, P, m.pt_mat[pt], o)) {
-        float *f = facc + pb * 6;
+        float *f = facc + pb * PD_W6;
         atomicAdd(f + 0, -o.t.x); atomicAdd(f + 1, -o.t.y); atomicAdd(f + 2, -o.t.z);
         atomicAdd(f + 3, -o.f.x); atomicAdd(f + 4, -o.f.y); atomicAdd(f + 5, -o.f.z);
       }
     });
     WAVE_SYNC();
     if (is_body) {
-      float *f = facc + b * 6;
+      float *f = facc + b * PD_W6;
       ft += V3(f[0], f[1], f[2]); ff += V3(f[3], f[4], f[5]);
 #pragma unroll
       for (int k = 0; k < 6; ++k) f[k] = 0.f;
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
     if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT>(m, c, s, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
     if (is_body) {
-      float *pc = pcon + b * 6;
+      float *pc = pcon + b * PD_W6;
       pc[0] = wp_t.x; pc[1] = wp_t.y; pc[2] = wp_t.z; pc[3] = wp_f.x; pc[4] = wp_f.y; pc[5] = wp_f.z;
     }
     WAVE_SYNC();
@@ -188,7 +210,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
     for (int k = 0; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
       if (is_body && cid != 0xff) {
-        const float *pc = pcon + cid * 6;
+        const float *pc = pcon + cid * PD_W6;
         ft += V3(pc[0], pc[1], pc[2]); ff += V3(pc[3], pc[4], pc[5]);
       }
     }
@@ -234,12 +256,10 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
 
-  float4 *pts = (float4 *)smem;
-  unsigned char *ptb = smem + (size_t)m.nc_pad * 16;
-  float *scratch = (float *)(ptb + m.nc_pad) + (size_t)(wave * EPW + seg) * m.env_lds_floats;
-  float *rec = scratch, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * 6, *cacc = cslot + nb * PD_ADJ;
+  SweepTables tabs;
+  float *scratch = lds_setup(m, smem, tabs, wave * EPW + seg);
+  float *rec = scratch, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
   int *list = (int *)(cacc + nb * PD_ADJ);
-  lds_copy_points(m, pts, ptb);
 
   const BodyConst c = load_body_const(m, b);
   const int ec = env_ok ? env : 0;
@@ -270,6 +290,25 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
 
+  // The stored state, wrench and controls of the NEXT iteration (step - 1) are software-prefetched.
+  float n_s[19], n_tgt[ND], n_act[ND];
+  auto load_step = [&](int step) {
+    const int sc = step >= 0 ? step : 0;
+    const float *tq = traj_q + (size_t)sc * 7 * N + idx, *td = traj_qd + (size_t)sc * 6 * N + idx;
+    const float *tf = traj_f + (size_t)sc * 6 * N + idx;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) n_s[k] = tq[(size_t)k * N];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { n_s[7 + k] = td[(size_t)k * N]; n_s[13 + k] = tf[(size_t)k * N]; }
+    const size_t o = (size_t)sc * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      bool on = k < ndof;
+      n_tgt[k] = on ? a.refs[o + k] : 0.f;
+      n_act[k] = on ? a.torques[o + k] : 0.f;
+    }
+  };
+  if (a.nsteps > 0) load_step(a.nsteps - 1);
   for (int step = a.nsteps - 1; step >= 0; --step) {
     {  // seeds of state step+1 (dp_model.py:1264-1271)
       int fr = a.frame_of_step[step + 1];
@@ -279,21 +318,14 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
         gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
       }
     }
-    const float *tq = traj_q + (size_t)step * 7 * N + idx, *td = traj_qd + (size_t)step * 6 * N + idx;
-    const float *tf = traj_f + (size_t)step * 6 * N + idx;
-    s.p = V3(tq[0], tq[(size_t)N], tq[(size_t)2 * N]);
-    s.r = Q4(tq[(size_t)3 * N], tq[(size_t)4 * N], tq[(size_t)5 * N], tq[(size_t)6 * N]);
-    s.w = V3(td[0], td[(size_t)N], td[(size_t)2 * N]);
-    s.v = V3(td[(size_t)3 * N], td[(size_t)4 * N], td[(size_t)5 * N]);
-    v3 t0 = V3(tf[0], tf[(size_t)N], tf[(size_t)2 * N]), f0 = V3(tf[(size_t)3 * N], tf[(size_t)4 * N], tf[(size_t)5 * N]);
+    s.p = V3(n_s[0], n_s[1], n_s[2]); s.r = Q4(n_s[3], n_s[4], n_s[5], n_s[6]);
+    s.w = V3(n_s[7], n_s[8], n_s[9]); s.v = V3(n_s[10], n_s[11], n_s[12]);
+    v3 t0 = V3(n_s[13], n_s[14], n_s[15]), f0 = V3(n_s[16], n_s[17], n_s[18]);
     float tgt[ND], act[ND];
-    const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
 #pragma unroll
-    for (int k = 0; k < ND; ++k) {
-      bool on = k < ndof;
-      tgt[k] = on ? a.refs[oc + k] : 0.f;
-      act[k] = on ? a.torques[oc + k] : 0.f;
-    }
+    for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
+    const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
+    load_step(step - 1);
     if (is_body) stage_record(rec, b, s, c.com);
     // ---- adjoint of integrate_bodies
     BodyAdj ga = adj_zero();
@@ -302,7 +334,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
     if (is_body) {
       float *o = a.g_res_f + ((size_t)step * N + idx) * 6;  // adjoint of wp_add
       o[0] = adj_t0.x; o[1] = adj_t0.y; o[2] = adj_t0.z; o[3] = adj_f0.x; o[4] = adj_f0.y; o[5] = adj_f0.z;
-      float *f = adjf + b * 6;
+      float *f = adjf + b * PD_W6;
       f[0] = adj_t0.x; f[1] = adj_t0.y; f[2] = adj_t0.z; f[3] = adj_f0.x; f[4] = adj_f0.y; f[5] = adj_f0.z;
     }
     WAVE_SYNC();
@@ -313,7 +345,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
     for (int k = 0; k < ND; ++k) { a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f; }
     if (is_body && c.type != PD_JOINT_FREE) {
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
-      if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * 6); gp_f = ld3(adjf + c.parent * 6 + 3); }
+      if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
       joint_adj<JT>(m, c, s, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
     }
     if (is_body) {
@@ -329,9 +361,9 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
       }
     }
     // ---- adjoint of eval_body_contacts
-    sweep_contacts<SEGW>(m, pts, ptb, rec, list, env_ok, is_body, seg, l, [&](int pt, int pb, const float *r, float4 P) {
+    sweep_contacts<SEGW>(m, tabs, c.sphere, rec, list, is_body, seg, l, [&](int pt, int pb, const float *r, float4 P) {
       BodyAdj o;
-      if (contact_point_adj(r, P, m.pt_mat[pt], ld3(m.com + pb * 3), ld3(adjf + pb * 6), ld3(adjf + pb * 6 + 3), o)) {
+      if (contact_point_adj(r, P, m.pt_mat[pt], ld3(m.com + pb * 3), ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o)) {
         float *d = cacc + pb * PD_ADJ;
         atomicAdd(d + 0, o.p.x); atomicAdd(d + 1, o.p.y); atomicAdd(d + 2, o.p.z);
         atomicAdd(d + 3, o.r.x); atomicAdd(d + 4, o.r.y); atomicAdd(d + 5, o.r.z); atomicAdd(d + 6, o.r.w);
