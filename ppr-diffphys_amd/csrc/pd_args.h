@@ -17,6 +17,7 @@ struct RolloutArgs {
   // backward only
   const float *adj_pos, *adj_vel;
   float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
+  unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
 };
 
 

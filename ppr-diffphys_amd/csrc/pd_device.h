@@ -15,7 +15,7 @@ enum { PD_JOINT_REVOLUTE = 1, PD_JOINT_FIXED = 3, PD_JOINT_FREE = 4, PD_JOINT_CO
 enum { PD_JT_REVOLUTE = 1, PD_JT_COMPOUND = 2, PD_JT_FIXED = 4 };  // template mask bits
 
 // LDS strides are odd so that lanes (= bodies) hit distinct banks with 4-byte accesses.
-#define PD_REC 21  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16] Ry[16:19]
+#define PD_REC 17  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16]
 #define PD_ADJ 13  // floats of a body-state adjoint: p q w v
 #define PD_W6 7    // stride of a 6-float wrench slot
 
@@ -27,11 +27,13 @@ struct PdDevModel {
   const float *lim_lo, *lim_hi, *lim_ke, *lim_kd;         // [nqd]
   // ground-contact candidates, grouped by body and cut into tiles of <= SEGW spatially compact points
   const float4 *pts;                                      // [nc] (x,y,z,dist)
-  const float4 *pt_mat;                                   // [nc] (ke,kd,kf,mu)
+  const unsigned char *pt_mat;                            // [nc padded to 16] material index of each point
+  const float4 *materials;                                // [nmat] (ke,kd,kf,mu)
   const float4 *body_sphere;                              // [nb] bounding sphere of the body's points (w < 0: none)
   const float4 *tile_sphere;                              // [ntiles] bounding sphere (centre, radius + max dist)
-  const int4 *tile_info;                                  // [ntiles] (first point, count, body, 0)
+  const int *tile_pack;                                   // [ntiles] first point | count << 16 | body << 24
   const int2 *body_tiles;                                 // [nb] (first tile, tile count)
+  int nmat;
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
 };
@@ -70,6 +72,7 @@ struct BodyConst {
   v3 com, axis, p_pj, com_par;
   qt q_pj, q_off;
   float4 sphere;  // bounding sphere of this body's contact candidates
+  int tile_first, tile_count;
 };
 
 PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
@@ -80,16 +83,29 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
   c.p_pj = ld3(m.X_p + b * 7); c.q_pj = ld4(m.X_p + b * 7 + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
   c.sphere = m.body_sphere[b];
+  c.tile_first = m.body_tiles[b].x; c.tile_count = m.body_tiles[b].y;
   return c;
 }
 
-PD_DEV void stage_record(float *rec, int b, const BodyState &s, v3 com) {
+// Returns the cull vector (p_y, Ry): Ry = second row of R(q), so the world height of a body-frame point x is
+// p_y + Ry . x.  It is also stored 16-byte aligned in cull[b] so the sweeps fetch it with one ds_read_b128.
+PD_DEV float4 stage_record(float *rec, float4 *cull, int b, const BodyState &s, v3 com) {
   float *r = rec + b * PD_REC;
   v3 rc = qrot(s.r, com);
-  v3 Ry = qrot_inv(s.r, V3(0.f, 1.f, 0.f));  // second row of R(q): world-y of a body-frame point is Ry . x
+  v3 Ry = qrot_inv(s.r, V3(0.f, 1.f, 0.f));
   r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
   r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
-  r[13] = rc.x; r[14] = rc.y; r[15] = rc.z; r[16] = Ry.x; r[17] = Ry.y; r[18] = Ry.z;
+  r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
+  float4 cv = make_float4(s.p.y, Ry.x, Ry.y, Ry.z);
+  cull[b] = cv;
+  return cv;
+}
+PD_DEV void stage_record(float *rec, int b, const BodyState &s, v3 com) {  // FK-only kernels: no cull vector
+  float *r = rec + b * PD_REC;
+  v3 rc = qrot(s.r, com);
+  r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
+  r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
+  r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,9 +246,10 @@ PD_DEV bool contact_point_fwd(const float *r, float4 P, float4 mat, ContactOut &
 }
 
 // Adjoint: g_t, g_f = adjoint of the body's wrench accumulator; returns the contribution to (p,q,w,v).
-PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 com, v3 g_t, v3 g_f, BodyAdj &out) {
+PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g_f, BodyAdj &out) {
   v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
   qt q = ld4(r + 3);
+  v3 com = qrot_inv(q, rc);  // body-frame COM back from the staged rc = rot(q, com): no table read on the hit path
   v3 cpt = V3(P.x, P.y, P.z);
   v3 cp = (p + qrot(q, cpt)) - V3(0.f, P.w, 0.f);
   float c = cp.y;

@@ -114,33 +114,40 @@ static int build_device(pd_model *m, int segw) {
   }
   if (jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
   // ---- contact table: grouped by body, kd-ordered inside a body, cut into tiles of <= segw points
-  std::vector<float4> pts, pt_mat, tile_sphere;
-  std::vector<int4> tile_info;
+  std::vector<float4> pts, tile_sphere, mats;
+  std::vector<unsigned char> pt_mat;
+  std::vector<int> tile_pack;
   std::vector<int2> body_tiles(nb, make_int2(0, 0));
   std::vector<float4> body_sphere(nb, make_float4(0, 0, 0, -1.0f));
   for (int b = 0; b < nb; ++b) {
     std::vector<int> ids;
     for (int k = 0; k < m->nc; ++k) if (m->cbody[k] == b) ids.push_back(k);
-    body_tiles[b] = make_int2((int)tile_info.size(), 0);
+    body_tiles[b] = make_int2((int)tile_pack.size(), 0);
     if (ids.empty()) continue;
     body_sphere[b] = bound_sphere(ids, m->cpoint.data(), m->cdist.data());
     kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), segw);
     for (size_t t0 = 0; t0 < ids.size(); t0 += segw) {
       std::vector<int> tid(ids.begin() + t0, ids.begin() + std::min(ids.size(), t0 + segw));
       tile_sphere.push_back(bound_sphere(tid, m->cpoint.data(), m->cdist.data()));
-      tile_info.push_back(make_int4((int)pts.size(), (int)tid.size(), b, 0));
+      tile_pack.push_back((int)pts.size() | ((int)tid.size() << 16) | (b << 24));
       body_tiles[b].y++;
       for (int k : tid) {
         pts.push_back(make_float4(m->cpoint[k * 3], m->cpoint[k * 3 + 1], m->cpoint[k * 3 + 2], m->cdist[k]));
         int mi = m->cmat[k];
         if (mi < 0 || mi >= m->nmat) return fail("contact_material out of range");
-        pt_mat.push_back(make_float4(m->materials[mi * 4], m->materials[mi * 4 + 1], m->materials[mi * 4 + 2], m->materials[mi * 4 + 3]));
+        pt_mat.push_back((unsigned char)mi);
       }
     }
   }
-  const int nc = (int)pts.size(), ntiles = (int)tile_info.size();
-  if (pts.empty()) { pts.push_back(make_float4(0, 0, 0, 0)); pt_mat.push_back(make_float4(0, 0, 0, 0)); }
-  if (tile_info.empty()) { tile_info.push_back(make_int4(0, 0, 0, 0)); tile_sphere.push_back(make_float4(0, 0, 0, -1.0f)); }
+  const int nc = (int)pts.size(), ntiles = (int)tile_pack.size();
+  if (nc > 65535) return fail("more than 65535 contact candidates per articulation is not supported");
+  if (m->nmat > 255) return fail("more than 255 contact materials is not supported");
+  for (int i = 0; i < m->nmat; ++i)
+    mats.push_back(make_float4(m->materials[i * 4], m->materials[i * 4 + 1], m->materials[i * 4 + 2], m->materials[i * 4 + 3]));
+  if (mats.empty()) mats.push_back(make_float4(0, 0, 0, 0));
+  if (pts.empty()) pts.push_back(make_float4(0, 0, 0, 0));
+  pt_mat.resize(((std::max(nc, 1) + 15) / 16) * 16, 0);
+  if (tile_pack.empty()) { tile_pack.push_back(0); tile_sphere.push_back(make_float4(0, 0, 0, -1.0f)); }
 
   // ---- upload
   std::vector<unsigned char> buf;
@@ -148,8 +155,8 @@ static int build_device(pd_model *m, int segw) {
   size_t o_depth = put(buf, depth), o_children = put(buf, children);
   size_t o_Xp = put(buf, m->X_p), o_Xc = put(buf, m->X_c), o_axis = put(buf, m->axis), o_com = put(buf, m->com);
   size_t o_lo = put(buf, m->lim_lo), o_hi = put(buf, m->lim_hi), o_lke = put(buf, m->lim_ke), o_lkd = put(buf, m->lim_kd);
-  size_t o_pts = put(buf, pts), o_ptm = put(buf, pt_mat);
-  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_sphere), o_ti = put(buf, tile_info), o_bt = put(buf, body_tiles);
+  size_t o_pts = put(buf, pts), o_ptm = put(buf, pt_mat), o_mats = put(buf, mats);
+  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_sphere), o_ti = put(buf, tile_pack), o_bt = put(buf, body_tiles);
   free_device(m);
   hipError_t e = hipMalloc(&m->blob, buf.size());
   if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
@@ -166,14 +173,17 @@ static int build_device(pd_model *m, int segw) {
   d.axis = (const float *)(base + o_axis); d.com = (const float *)(base + o_com);
   d.lim_lo = (const float *)(base + o_lo); d.lim_hi = (const float *)(base + o_hi);
   d.lim_ke = (const float *)(base + o_lke); d.lim_kd = (const float *)(base + o_lkd);
-  d.pts = (const float4 *)(base + o_pts); d.pt_mat = (const float4 *)(base + o_ptm);
+  d.pts = (const float4 *)(base + o_pts); d.pt_mat = base + o_ptm; d.materials = (const float4 *)(base + o_mats);
+  d.nmat = m->nmat;
   d.body_sphere = (const float4 *)(base + o_bs); d.tile_sphere = (const float4 *)(base + o_ts);
-  d.tile_info = (const int4 *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
+  d.tile_pack = (const int *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
-  d.env_lds_floats = (nb * (PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles) | 1;  // odd: segments start on different banks
+  // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list
+  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles + 8 * segw + 3) / 4) * 4 + 4;
   const int envs_per_block = PD_WAVES * (64 / segw);
-  m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)((nb + 1) & ~1) * 8 +
+  m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 16 + (size_t)std::max(m->nmat, 1) * 16 +
+                   (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
                    (size_t)envs_per_block * d.env_lds_floats * 4;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (m->lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
@@ -205,6 +215,7 @@ static void timing_end(pd_model *m, int kind, hipStream_t st) {
 }
 
 static pd_model *g_last_model = nullptr;
+static unsigned long long *g_dbg = nullptr;  // diagnostic builds only
 
 extern "C" {
 
@@ -271,7 +282,7 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.res_f = res_f; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
-  a.frame_of_step = frame_of_step; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf;
+  a.frame_of_step = frame_of_step; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, m->lds_rollout, st);
@@ -299,7 +310,7 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = frame_of_step; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
-  a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia;
+  a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout, st);
@@ -330,6 +341,8 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *
   return e == hipSuccess ? 0 : hip_fail(e, "fk_backward launch");
 }
 
+// Not part of the public header: buffer for -DPD_STAMPS diagnostic builds ([blocks*waves][8] u64).
+void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
 void pd_set_timing(int on) { g_timing = on != 0; }
 float pd_last_kernel_ms(int kind) {
   pd_model *m = g_last_model;

@@ -6,6 +6,28 @@
 #include "pd_device.h"
 #include "pd_args.h"
 
+// In-kernel phase stamps (diagnostic build only, never in the shipped library): cdna_hip_programming.md section 7.
+#ifdef PD_STAMPS
+#define STAMP_DECL unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = pd_memtime()
+#define STAMP_ARGS , unsigned long long *st_acc, unsigned long long &st_t
+#define STAMP_PASS , st_acc, st_t
+#define STAMP(i) do { unsigned long long t2_ = pd_memtime(); st_acc[i] += t2_ - st_t; st_t = t2_; } while (0)
+#define STAMP_FLUSH(a) do { if ((a).dbg && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((size_t)blockIdx.x * PD_WAVES + (threadIdx.x >> 6)) * 16 + i_] = st_acc[i_]; } while (0)
+__device__ __forceinline__ unsigned long long pd_memtime() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(a)
+#define STAMP_ARGS
+#define STAMP_PASS
+#endif
+
 
 template <int SEGW>
 struct Seg {
@@ -20,34 +42,94 @@ PD_DEV unsigned long long seg_ballot(bool pred, int seg) {
   return (b >> (seg * SEGW)) & Seg<SEGW>::MASK;
 }
 
-// Ground-contact sweep for one segment (= one env).  Three-level cull, all conservative, then the
-// exact test of the reference inside on_hit.  Tables live in LDS (copied once per workgroup):
-//   L1  per body  : bounding sphere of all its candidate points vs y = 0          (lane = body)
-//   L2  per tile  : tile = <= SEGW spatially compact points of ONE body; sphere test (lane = tile of a surviving body)
-//   L3  per point : y-row test  c = p_y + Ry . x - dist                            (lane = point of a surviving tile)
-// on_hit(point index, body, record pointer, point float4) runs for lanes whose L3 value is <= eps.
+// Stream compaction inside a segment: returns this lane's slot among the segment's lanes with pred set
+// (v_mbcnt on the ballot masked to the segment: 4 VALU ops) and adds the segment's count to `total`.
+struct SegMask { unsigned lo, hi; };
+template <int SEGW>
+PD_DEV SegMask seg_mask(int seg) {
+  unsigned long long mk = Seg<SEGW>::MASK << (seg * SEGW);
+  SegMask s; s.lo = (unsigned)mk; s.hi = (unsigned)(mk >> 32);
+  return s;
+}
+PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
+  unsigned long long b = __ballot(pred);
+  unsigned lo = (unsigned)b & sm.lo, hi = (unsigned)(b >> 32) & sm.hi;
+  int slot = total + (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+  total += __popc(lo) + __popc(hi);
+  return slot;
+}
+
+// Ground-contact sweep for one segment (= one env).  Conservative three-level cull, then the exact
+// test of the reference inside on_hit.  All tables are in LDS (copied once per workgroup):
+//   L1  per body  : bounding sphere of all its candidate points vs y = 0               (lane = body)
+//   L2  per tile  : tile = <= SEGW spatially compact points of ONE body; sphere test    (lane = tile of a surviving body)
+//   L3  per point : y-row test  c = p_y + Ry . x - dist, four tiles per iteration so that their LDS reads overlap;
+//                   survivors are compacted into a per-env hit list                      (lane = point)
+//   hit pass      : lanes = compacted hits (dense), on_hit(record, point, material) does the reference's arithmetic
+// With one wavefront per SIMD nothing else hides LDS latency, so the structure minimises DEPENDENT LDS round trips.
+#define PD_HIT_CAP_TILES 8  // hit-list capacity in units of SEGW
+
 struct SweepTables {
-  const float4 *pts, *tsphere;
-  const int4 *tinfo;
+  const float4 *pts, *tsphere, *mats;
+  const unsigned char *pmat;
+  const int *tpack;
   const int2 *btiles;
 };
 
+PD_DEV bool cull_above(float4 cv, float4 sp) {  // true when the whole sphere is provably above y = 0
+  float ylow = cv.x + (cv.y * sp.x + cv.z * sp.y + cv.w * sp.z) - sp.w;
+  return ylow > 1e-4f * (1.0f + sp.w);
+}
+
 template <int SEGW, typename F>
-PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, float4 sphere, const float *rec, int *list, bool is_body,
-                           int seg, int l, F &&on_hit) {
-  if (m.nc == 0) return;
-  bool surv = false;
-  if (is_body && sphere.w >= 0.0f) {
-    const float *r = rec + l * PD_REC;
-    float ylow = r[1] + (r[16] * sphere.x + r[17] * sphere.y + r[18] * sphere.z) - sphere.w;
-    surv = !(ylow > 1e-4f * (1.0f + sphere.w));
+PD_DEV void sweep_flush(const SweepTables &T, const float *rec, const int *hits, int &nh, int l, F &&on_hit) {
+  for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW) {
+    int j = j0 + l;
+    if (j < nh) {
+      int e = hits[j];
+      int pt = e & 0xffff, pb = (e >> 24) & 0x3f;
+      on_hit(pb, rec + pb * PD_REC, T.pts[pt], T.mats[T.pmat[pt]]);
+    }
   }
+  nh = 0;
+}
+
+#define PD_L2_SERIAL 8  // bodies with at most this many tiles test their own tiles lane-serially
+
+// cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
+template <int SEGW, typename F>
+PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
+                           const float4 *cull, int *list, int *hits, bool is_body, int seg, int l, F &&on_hit STAMP_ARGS) {
+  if (m.nc == 0) return;
+  const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
   unsigned long long wave_any = __ballot(surv);
+  STAMP(8);
   if (wave_any == 0ull) return;
-  unsigned long long mb = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;
-  const unsigned long long lt = (1ull << l) - 1ull;
+  const SegMask sm = seg_mask<SEGW>(seg);
   int nlist = 0;
-  while (__ballot(mb != 0ull) != 0ull) {  // one surviving body per segment per iteration
+  // ---- L2, small bodies: every surviving body lane walks its own (few) tiles, four at a time
+  {
+    const int myn = (surv && c.tile_count <= PD_L2_SERIAL) ? c.tile_count : 0;
+    for (int i0 = 0; __ballot(i0 < myn) != 0ull; i0 += 4) {
+      float4 sp[4];
+      int pk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int t = c.tile_first + (i0 + u < myn ? i0 + u : 0);
+        sp[u] = T.tsphere[t];
+        pk[u] = T.tpack[t];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool pass = (i0 + u < myn) && !cull_above(cv, sp[u]);
+        int slot = seg_slot(pass, sm, nlist);
+        if (pass) list[slot] = pk[u];
+      }
+    }
+  }
+  // ---- L2, big bodies (rarely survive L1): the segment's lanes share one body's tiles
+  unsigned long long mb = seg_ballot<SEGW>(surv && c.tile_count > PD_L2_SERIAL, seg);
+  while (__ballot(mb != 0ull) != 0ull) {
     int bb = 0, nt = 0, t_first = 0;
     if (mb != 0ull) {
       bb = __ffsll((long long)mb) - 1;
@@ -55,48 +137,73 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, float4 sph
       int2 bt = T.btiles[bb];
       t_first = bt.x; nt = bt.y;
     }
-    const float *r = rec + bb * PD_REC;
-    const float py = r[1], ryx = r[16], ryy = r[17], ryz = r[18];
+    const float4 cb = cull[bb];
     for (int t0 = 0; __ballot(t0 < nt) != 0ull; t0 += SEGW) {
       int t = t0 + l;
       bool pass = t < nt;
+      int pk = 0;
       if (pass) {
-        float4 sp = T.tsphere[t_first + t];
-        float ylow = py + (ryx * sp.x + ryy * sp.y + ryz * sp.z) - sp.w;
-        pass = !(ylow > 1e-4f * (1.0f + sp.w));
+        pk = T.tpack[t_first + t];
+        pass = !cull_above(cb, T.tsphere[t_first + t]);
       }
-      unsigned long long ps = seg_ballot<SEGW>(pass, seg);
-      if (pass) list[nlist + __popcll(ps & lt)] = t_first + t;
-      nlist += __popcll(ps);
+      int slot = seg_slot(pass, sm, nlist);
+      if (pass) list[slot] = pk;
     }
   }
+  STAMP(9);
   WAVE_SYNC();
-  for (int k = 0; __ballot(k < nlist) != 0ull; ++k) {
-    if (k < nlist) {
-      int4 ti = T.tinfo[list[k]];
-      if (l < ti.y) {
-        float4 P = T.pts[ti.x + l];
-        const float *r = rec + ti.z * PD_REC;
-        float cq = r[1] + (r[16] * P.x + r[17] * P.y + r[18] * P.z) - P.w;
-        if (cq <= 1e-4f) on_hit(ti.x + l, ti.z, r, P);
+  // ---- L3: point cull, four tiles per iteration
+  int nh = 0;
+  for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += 4) {
+    int e[4];
+    bool hit[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = (k0 + u < nlist) ? list[k0 + u] : 0;  // count field 0 => no lane is valid
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int pt0 = e[u] & 0xffff, n = (e[u] >> 16) & 0xff, pb = (e[u] >> 24) & 0x3f;
+      hit[u] = false;
+      if (l < n) {
+        float4 P = T.pts[pt0 + l];
+        float4 cb = cull[pb];
+        hit[u] = cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f;
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int slot = seg_slot(hit[u], sm, nh);
+      if (hit[u]) hits[slot] = ((e[u] & 0xffff) + l) | (e[u] & 0x3f000000);
+    }
+    if (__ballot(nh > (PD_HIT_CAP_TILES - 4) * SEGW) != 0ull) {  // rare: keep room for the next four tiles
+      WAVE_SYNC();
+      sweep_flush<SEGW>(T, rec, hits, nh, l, on_hit);
+      WAVE_SYNC();
+    }
   }
+  STAMP(10);
+  WAVE_SYNC();
+  sweep_flush<SEGW>(T, rec, hits, nh, l, on_hit);
+  STAMP(11);
 }
 
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.
 PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot) {
-  const int nc4 = m.nc > 0 ? m.nc : 1, nt4 = m.ntiles > 0 ? m.ntiles : 1, nbp = (m.nb + 1) & ~1;
+  const int nc4 = m.nc > 0 ? m.nc : 1, nt4 = m.ntiles > 0 ? m.ntiles : 1, nm4 = m.nmat > 0 ? m.nmat : 1;
+  const int nbp = (m.nb + 1) & ~1, ncb = (nc4 + 15) & ~15, ntp = (nt4 + 3) & ~3;
   float4 *pts = (float4 *)smem;
   float4 *tsp = pts + nc4;
-  int4 *tin = (int4 *)(tsp + nt4);
-  int2 *btl = (int2 *)(tin + nt4);
+  float4 *mat = tsp + nt4;
+  int *tpk = (int *)(mat + nm4);
+  int2 *btl = (int2 *)(tpk + ntp);
+  unsigned char *pmt = (unsigned char *)(btl + nbp);
   for (int i = threadIdx.x; i < m.nc; i += PD_BLOCK) pts[i] = m.pts[i];
-  for (int i = threadIdx.x; i < m.ntiles; i += PD_BLOCK) { tsp[i] = m.tile_sphere[i]; tin[i] = m.tile_info[i]; }
+  for (int i = threadIdx.x; i < m.ntiles; i += PD_BLOCK) { tsp[i] = m.tile_sphere[i]; tpk[i] = m.tile_pack[i]; }
+  for (int i = threadIdx.x; i < m.nmat; i += PD_BLOCK) mat[i] = m.materials[i];
   for (int i = threadIdx.x; i < m.nb; i += PD_BLOCK) btl[i] = m.body_tiles[i];
+  for (int i = threadIdx.x; i < ncb / 4; i += PD_BLOCK) ((unsigned int *)pmt)[i] = ((const unsigned int *)m.pt_mat)[i];
   __syncthreads();
-  T.pts = pts; T.tsphere = tsp; T.tinfo = tin; T.btiles = btl;
-  return (float *)(btl + nbp) + (size_t)env_slot * m.env_lds_floats;
+  T.pts = pts; T.tsphere = tsp; T.mats = mat; T.tpack = tpk; T.btiles = btl; T.pmat = pmt;
+  return (float *)(pmt + ncb) + (size_t)env_slot * m.env_lds_floats;  // env_lds_floats is a multiple of 4: 16-B aligned
 }
 
 // =============================================================================================
@@ -115,8 +222,9 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
 
   SweepTables tabs;
   float *scratch = lds_setup(m, smem, tabs, wave * EPW + seg);
-  float *rec = scratch, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
-  int *list = (int *)(pcon + nb * PD_W6);
+  float4 *cull = (float4 *)scratch;
+  float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
+  int *list = (int *)(pcon + nb * PD_W6), *hits = list + m.ntiles;
 
   const BodyConst c = load_body_const(m, b);
   const int ec = env_ok ? env : 0;       // clamped env for safe addressing
@@ -140,10 +248,11 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
+  float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
   for (int d = 0; d <= m.max_depth; ++d) {
     if (is_body && c.depth == d) {
       s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
-      stage_record(rec, b, s, c.com);
+      cv = stage_record(rec, cull, b, s, c.com);
     }
     WAVE_SYNC();
   }
@@ -166,6 +275,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
     for (int k = 0; k < 6; ++k) n_rf[k] = rf[k];
   };
   if (a.nsteps > 0) load_controls(0);
+  STAMP_DECL;
   for (int step = 0; step < a.nsteps; ++step) {
     float tgt[ND], act[ND];
 #pragma unroll
@@ -180,15 +290,16 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
       td[0] = s.w.x; td[(size_t)N] = s.w.y; td[(size_t)2 * N] = s.w.z;
       td[(size_t)3 * N] = s.v.x; td[(size_t)4 * N] = s.v.y; td[(size_t)5 * N] = s.v.z;
     }
+    STAMP(0);
     // ---- eval_body_contacts
-    sweep_contacts<SEGW>(m, tabs, c.sphere, rec, list, is_body, seg, l, [&](int pt, int pb, const float *r, float4 P) {
+    sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, [&](int pb, const float *r, float4 P, float4 mat) {
       ContactOut o;
-      if (contact_point_fwd(r, P, m.pt_mat[pt], o)) {
+      if (contact_point_fwd(r, P, mat, o)) {
         float *f = facc + pb * PD_W6;
         atomicAdd(f + 0, -o.t.x); atomicAdd(f + 1, -o.t.y); atomicAdd(f + 2, -o.t.z);
         atomicAdd(f + 3, -o.f.x); atomicAdd(f + 4, -o.f.y); atomicAdd(f + 5, -o.f.z);
       }
-    });
+    } STAMP_PASS);
     WAVE_SYNC();
     if (is_body) {
       float *f = facc + b * PD_W6;
@@ -198,6 +309,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
     }
     const int fr = a.frame_of_step[step];
     v3 grf_t = ft, grf_f = ff;
+    STAMP(1);
     // ---- eval_body_joints
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
     if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT>(m, c, s, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
@@ -205,6 +317,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
       float *pc = pcon + b * PD_W6;
       pc[0] = wp_t.x; pc[1] = wp_t.y; pc[2] = wp_t.z; pc[3] = wp_f.x; pc[4] = wp_f.y; pc[5] = wp_f.z;
     }
+    STAMP(2);
     WAVE_SYNC();
     ft -= wc_t; ff -= wc_f;
     for (int k = 0; k < m.max_children; ++k) {
@@ -234,12 +347,16 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
         }
       }
     }
+    STAMP(3);
     // ---- integrate_bodies
     s = integrate_fwd(m, c, s, ft, ff, inv_m, I, invI, a.dt);
+    STAMP(4);
     WAVE_SYNC();
-    if (is_body) stage_record(rec, b, s, c.com);
+    if (is_body) cv = stage_record(rec, cull, b, s, c.com);
     WAVE_SYNC();
+    STAMP(5);
   }
+  STAMP_FLUSH(a);
 }
 
 // =============================================================================================
@@ -258,8 +375,9 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
 
   SweepTables tabs;
   float *scratch = lds_setup(m, smem, tabs, wave * EPW + seg);
-  float *rec = scratch, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
-  int *list = (int *)(cacc + nb * PD_ADJ);
+  float4 *cull = (float4 *)scratch;
+  float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
+  int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.ntiles;
 
   const BodyConst c = load_body_const(m, b);
   const int ec = env_ok ? env : 0;
@@ -309,6 +427,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
     }
   };
   if (a.nsteps > 0) load_step(a.nsteps - 1);
+  STAMP_DECL;
   for (int step = a.nsteps - 1; step >= 0; --step) {
     {  // seeds of state step+1 (dp_model.py:1264-1271)
       int fr = a.frame_of_step[step + 1];
@@ -326,7 +445,9 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
     const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
     load_step(step - 1);
-    if (is_body) stage_record(rec, b, s, c.com);
+    float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (is_body) cv = stage_record(rec, cull, b, s, c.com);
+    STAMP(0);
     // ---- adjoint of integrate_bodies
     BodyAdj ga = adj_zero();
     v3 adj_t0, adj_f0;
@@ -337,6 +458,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
       float *f = adjf + b * PD_W6;
       f[0] = adj_t0.x; f[1] = adj_t0.y; f[2] = adj_t0.z; f[3] = adj_f0.x; f[4] = adj_f0.y; f[5] = adj_f0.z;
     }
+    STAMP(1);
     WAVE_SYNC();
     // ---- adjoint of eval_body_joints
     BodyAdj par = adj_zero();
@@ -360,17 +482,19 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
         for (int k = 0; k < 6; ++k) { a.g_refs[oc + k] = 0.f; a.g_torques[oc + k] = 0.f; }
       }
     }
+    STAMP(2);
     // ---- adjoint of eval_body_contacts
-    sweep_contacts<SEGW>(m, tabs, c.sphere, rec, list, is_body, seg, l, [&](int pt, int pb, const float *r, float4 P) {
+    sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, [&](int pb, const float *r, float4 P, float4 mat) {
       BodyAdj o;
-      if (contact_point_adj(r, P, m.pt_mat[pt], ld3(m.com + pb * 3), ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o)) {
+      if (contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o)) {
         float *d = cacc + pb * PD_ADJ;
         atomicAdd(d + 0, o.p.x); atomicAdd(d + 1, o.p.y); atomicAdd(d + 2, o.p.z);
         atomicAdd(d + 3, o.r.x); atomicAdd(d + 4, o.r.y); atomicAdd(d + 5, o.r.z); atomicAdd(d + 6, o.r.w);
         atomicAdd(d + 7, o.w.x); atomicAdd(d + 8, o.w.y); atomicAdd(d + 9, o.w.z);
         atomicAdd(d + 10, o.v.x); atomicAdd(d + 11, o.v.y); atomicAdd(d + 12, o.v.z);
       }
-    });
+    } STAMP_PASS);
+    STAMP(3);
     WAVE_SYNC();
     for (int k = 0; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
@@ -384,7 +508,9 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
     }
     gn = ga;
     WAVE_SYNC();
+    STAMP(4);
   }
+  STAMP_FLUSH(a);
   {  // seeds of state 0
     int fr = a.frame_of_step[0];
     if (fr >= 0) {

@@ -10,7 +10,8 @@ import os
 import numpy as np
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
+# PPR_DIFFPHYS_LIB lets scripts/gpu_stamps.py load the -DPD_STAMPS diagnostic build; the product never sets it.
+_LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
 _fp = ctypes.POINTER(ctypes.c_float)
