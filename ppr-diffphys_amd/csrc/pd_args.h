@@ -2,8 +2,12 @@
 #pragma once
 #include "pd_device.h"
 
-#define PD_BLOCK 256
-#define PD_WAVES (PD_BLOCK / 64)
+// Rollout kernels: 8 waves per workgroup.  Waves 0..3 ("body waves") own the per-body state of 64/SEGW envs each;
+// wave 4+i ("contact wave") runs the ground-contact sweeps for the envs of wave i, concurrently with wave i's joint
+// work, on the same SIMD (a workgroup's waves are dealt to the 4 SIMDs cyclically).  FK kernels: 4 body waves only.
+#define PD_BWAVES 4
+#define PD_BLOCK (2 * PD_BWAVES * 64)
+#define PD_FK_BLOCK (PD_BWAVES * 64)
 
 enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
 

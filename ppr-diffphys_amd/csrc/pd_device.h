@@ -33,7 +33,9 @@ struct PdDevModel {
   const float4 *tile_sphere;                              // [ntiles] bounding sphere (centre, radius + max dist)
   const int *tile_pack;                                   // [ntiles] first point | count << 16 | body << 24
   const int2 *body_tiles;                                 // [nb] (first tile, tile count)
-  int nmat;
+  const int *small_tiles;                                 // [4*64] flat list (tile | body << 16) of the tiles of small bodies, -1 padded
+  unsigned long long big_bodies;                          // bodies whose tiles are NOT in small_tiles
+  int nmat, n_small;
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
 };
@@ -73,6 +75,7 @@ struct BodyConst {
   qt q_pj, q_off;
   float4 sphere;  // bounding sphere of this body's contact candidates
   int tile_first, tile_count;
+  int small_e[4];  // this lane's entries of the small-body tile list (chunk u: entry u*SEGW + lane)
 };
 
 PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {

@@ -140,6 +140,20 @@ static int build_device(pd_model *m, int segw) {
     }
   }
   const int nc = (int)pts.size(), ntiles = (int)tile_pack.size();
+  // small bodies (<= 8 tiles) contribute their tiles to a static flat list of at most 4*segw entries, laid out as
+  // 4 chunks of 64 slots so that lane l of a segment reads entry u*64 + l; the rest are "big" (cooperative L2)
+  std::vector<int> small_tiles(4 * 64, -1);
+  unsigned long long big_bodies = 0ull;
+  int n_small = 0;
+  for (int b = 0; b < nb; ++b) {
+    int nt = body_tiles[b].y;
+    if (nt == 0) continue;
+    if (nt <= 8 && n_small + nt <= 4 * segw) {
+      for (int t = 0; t < nt; ++t, ++n_small) small_tiles[(n_small / segw) * 64 + n_small % segw] = (body_tiles[b].x + t) | (b << 16);
+    } else {
+      big_bodies |= 1ull << b;
+    }
+  }
   if (nc > 65535) return fail("more than 65535 contact candidates per articulation is not supported");
   if (m->nmat > 255) return fail("more than 255 contact materials is not supported");
   for (int i = 0; i < m->nmat; ++i)
@@ -156,7 +170,7 @@ static int build_device(pd_model *m, int segw) {
   size_t o_Xp = put(buf, m->X_p), o_Xc = put(buf, m->X_c), o_axis = put(buf, m->axis), o_com = put(buf, m->com);
   size_t o_lo = put(buf, m->lim_lo), o_hi = put(buf, m->lim_hi), o_lke = put(buf, m->lim_ke), o_lkd = put(buf, m->lim_kd);
   size_t o_pts = put(buf, pts), o_ptm = put(buf, pt_mat), o_mats = put(buf, mats);
-  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_sphere), o_ti = put(buf, tile_pack), o_bt = put(buf, body_tiles);
+  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_sphere), o_ti = put(buf, tile_pack), o_bt = put(buf, body_tiles), o_st = put(buf, small_tiles);
   free_device(m);
   hipError_t e = hipMalloc(&m->blob, buf.size());
   if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
@@ -177,11 +191,12 @@ static int build_device(pd_model *m, int segw) {
   d.nmat = m->nmat;
   d.body_sphere = (const float4 *)(base + o_bs); d.tile_sphere = (const float4 *)(base + o_ts);
   d.tile_pack = (const int *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
+  d.small_tiles = (const int *)(base + o_st); d.big_bodies = big_bodies; d.n_small = n_small;
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
   // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list
   d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles + 8 * segw + 3) / 4) * 4 + 4;
-  const int envs_per_block = PD_WAVES * (64 / segw);
+  const int envs_per_block = PD_BWAVES * (64 / segw);
   m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 16 + (size_t)std::max(m->nmat, 1) * 16 +
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
                    (size_t)envs_per_block * d.env_lds_floats * 4;
@@ -195,7 +210,7 @@ static int build_device(pd_model *m, int segw) {
 }
 
 static hipError_t launch(const pd_model *m, int kind, const void *args, int n_envs, size_t lds, hipStream_t st) {
-  const int epb = PD_WAVES * (64 / m->segw);
+  const int epb = PD_BWAVES * (64 / m->segw);
   const int nblocks = (n_envs + epb - 1) / epb;
   if (nblocks == 0) return hipSuccess;
   if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, nblocks, lds, st);

@@ -12,7 +12,7 @@
 #define STAMP_ARGS , unsigned long long *st_acc, unsigned long long &st_t
 #define STAMP_PASS , st_acc, st_t
 #define STAMP(i) do { unsigned long long t2_ = pd_memtime(); st_acc[i] += t2_ - st_t; st_t = t2_; } while (0)
-#define STAMP_FLUSH(a) do { if ((a).dbg && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((size_t)blockIdx.x * PD_WAVES + (threadIdx.x >> 6)) * 16 + i_] = st_acc[i_]; } while (0)
+#define STAMP_FLUSH(a) do { if ((a).dbg && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((size_t)blockIdx.x * (PD_BLOCK / 64) + (threadIdx.x >> 6)) * 16 + i_] = st_acc[i_]; } while (0)
 __device__ __forceinline__ unsigned long long pd_memtime() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -63,11 +63,12 @@ PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
 // test of the reference inside on_hit.  All tables are in LDS (copied once per workgroup):
 //   L1  per body  : bounding sphere of all its candidate points vs y = 0               (lane = body)
 //   L2  per tile  : tile = <= SEGW spatially compact points of ONE body; sphere test    (lane = tile of a surviving body)
-//   L3  per point : y-row test  c = p_y + Ry . x - dist, four tiles per iteration so that their LDS reads overlap;
+//   L3  per point : y-row test  c = p_y + Ry . x - dist, PD_UNROLL tiles per iteration so that their LDS reads overlap;
 //                   survivors are compacted into a per-env hit list                      (lane = point)
 //   hit pass      : lanes = compacted hits (dense), on_hit(record, point, material) does the reference's arithmetic
 // With one wavefront per SIMD nothing else hides LDS latency, so the structure minimises DEPENDENT LDS round trips.
-#define PD_HIT_CAP_TILES 8  // hit-list capacity in units of SEGW
+#define PD_UNROLL 4          // tiles handled per L3 iteration (their LDS reads are issued back to back)
+#define PD_HIT_CAP_TILES 8   // hit-list capacity in units of SEGW (two L3 iterations)
 
 struct SweepTables {
   const float4 *pts, *tsphere, *mats;
@@ -94,41 +95,35 @@ PD_DEV void sweep_flush(const SweepTables &T, const float *rec, const int *hits,
   nh = 0;
 }
 
-#define PD_L2_SERIAL 8  // bodies with at most this many tiles test their own tiles lane-serially
-
 // cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
 template <int SEGW, typename F>
 PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
                            const float4 *cull, int *list, int *hits, bool is_body, int seg, int l, F &&on_hit STAMP_ARGS) {
   if (m.nc == 0) return;
   const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
-  unsigned long long wave_any = __ballot(surv);
+  const unsigned long long wave_any = __ballot(surv);
   STAMP(8);
   if (wave_any == 0ull) return;
+  const unsigned long long M = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;  // surviving bodies of my env
   const SegMask sm = seg_mask<SEGW>(seg);
   int nlist = 0;
-  // ---- L2, small bodies: every surviving body lane walks its own (few) tiles, four at a time
-  {
-    const int myn = (surv && c.tile_count <= PD_L2_SERIAL) ? c.tile_count : 0;
-    for (int i0 = 0; __ballot(i0 < myn) != 0ull; i0 += 4) {
-      float4 sp[4];
-      int pk[4];
+  // ---- L2, small bodies: lane = entry of the static flat list of their tiles (held in registers)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int t = c.tile_first + (i0 + u < myn ? i0 + u : 0);
-        sp[u] = T.tsphere[t];
-        pk[u] = T.tpack[t];
+  for (int u = 0; u < 4; ++u) {
+    if (u * SEGW < m.n_small) {  // uniform
+      const int e = c.small_e[u];
+      bool pass = e >= 0 && ((M >> (e >> 16)) & 1ull) != 0ull;
+      int pk = 0;
+      if (pass) {
+        pk = T.tpack[e & 0xffff];
+        pass = !cull_above(cull[e >> 16], T.tsphere[e & 0xffff]);
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bool pass = (i0 + u < myn) && !cull_above(cv, sp[u]);
-        int slot = seg_slot(pass, sm, nlist);
-        if (pass) list[slot] = pk[u];
-      }
+      int slot = seg_slot(pass, sm, nlist);
+      if (pass) list[slot] = pk;
     }
   }
   // ---- L2, big bodies (rarely survive L1): the segment's lanes share one body's tiles
-  unsigned long long mb = seg_ballot<SEGW>(surv && c.tile_count > PD_L2_SERIAL, seg);
+  unsigned long long mb = M & m.big_bodies;
   while (__ballot(mb != 0ull) != 0ull) {
     int bb = 0, nt = 0, t_first = 0;
     if (mb != 0ull) {
@@ -152,29 +147,34 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
   }
   STAMP(9);
   WAVE_SYNC();
-  // ---- L3: point cull, four tiles per iteration
+  // ---- L3: point cull, PD_UNROLL tiles per iteration; hits are rare, so each lane collects its hits as a bit
+  // mask and the (usually single) compaction round runs once per iteration instead of once per tile
   int nh = 0;
-  for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += 4) {
-    int e[4];
-    bool hit[4];
+  for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += PD_UNROLL) {
+    int e[PD_UNROLL];
+    unsigned hm = 0u;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) e[u] = (k0 + u < nlist) ? list[k0 + u] : 0;  // count field 0 => no lane is valid
+    for (int u = 0; u < PD_UNROLL; ++u) e[u] = (k0 + u < nlist) ? list[k0 + u] : 0;  // count field 0 => no lane is valid
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < PD_UNROLL; ++u) {
       int pt0 = e[u] & 0xffff, n = (e[u] >> 16) & 0xff, pb = (e[u] >> 24) & 0x3f;
-      hit[u] = false;
       if (l < n) {
         float4 P = T.pts[pt0 + l];
         float4 cb = cull[pb];
-        hit[u] = cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f;
+        if (cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f) hm |= 1u << u;
       }
     }
+    while (__ballot(hm != 0u) != 0ull) {
+      const bool has = hm != 0u;
+      int u = has ? __ffs(hm) - 1 : 0;
+      int eu = e[0];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      int slot = seg_slot(hit[u], sm, nh);
-      if (hit[u]) hits[slot] = ((e[u] & 0xffff) + l) | (e[u] & 0x3f000000);
+      for (int v = 1; v < PD_UNROLL; ++v) eu = (u == v) ? e[v] : eu;
+      int slot = seg_slot(has, sm, nh);
+      if (has) hits[slot] = ((eu & 0xffff) + l) | (eu & 0x3f000000);
+      hm &= hm - 1u;
     }
-    if (__ballot(nh > (PD_HIT_CAP_TILES - 4) * SEGW) != 0ull) {  // rare: keep room for the next four tiles
+    if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) {  // rare: keep room for the next iteration
       WAVE_SYNC();
       sweep_flush<SEGW>(T, rec, hits, nh, l, on_hit);
       WAVE_SYNC();
@@ -187,7 +187,8 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
 }
 
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.
-PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot) {
+template <int NT>
+PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot) {  // all NT threads of the workgroup
   const int nc4 = m.nc > 0 ? m.nc : 1, nt4 = m.ntiles > 0 ? m.ntiles : 1, nm4 = m.nmat > 0 ? m.nmat : 1;
   const int nbp = (m.nb + 1) & ~1, ncb = (nc4 + 15) & ~15, ntp = (nt4 + 3) & ~3;
   float4 *pts = (float4 *)smem;
@@ -196,37 +197,65 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
   int *tpk = (int *)(mat + nm4);
   int2 *btl = (int2 *)(tpk + ntp);
   unsigned char *pmt = (unsigned char *)(btl + nbp);
-  for (int i = threadIdx.x; i < m.nc; i += PD_BLOCK) pts[i] = m.pts[i];
-  for (int i = threadIdx.x; i < m.ntiles; i += PD_BLOCK) { tsp[i] = m.tile_sphere[i]; tpk[i] = m.tile_pack[i]; }
-  for (int i = threadIdx.x; i < m.nmat; i += PD_BLOCK) mat[i] = m.materials[i];
-  for (int i = threadIdx.x; i < m.nb; i += PD_BLOCK) btl[i] = m.body_tiles[i];
-  for (int i = threadIdx.x; i < ncb / 4; i += PD_BLOCK) ((unsigned int *)pmt)[i] = ((const unsigned int *)m.pt_mat)[i];
+  for (int i = threadIdx.x; i < m.nc; i += NT) pts[i] = m.pts[i];
+  for (int i = threadIdx.x; i < m.ntiles; i += NT) { tsp[i] = m.tile_sphere[i]; tpk[i] = m.tile_pack[i]; }
+  for (int i = threadIdx.x; i < m.nmat; i += NT) mat[i] = m.materials[i];
+  for (int i = threadIdx.x; i < m.nb; i += NT) btl[i] = m.body_tiles[i];
+  for (int i = threadIdx.x; i < ncb / 4; i += NT) ((unsigned int *)pmt)[i] = ((const unsigned int *)m.pt_mat)[i];
   __syncthreads();
   T.pts = pts; T.tsphere = tsp; T.mats = mat; T.tpack = tpk; T.btiles = btl; T.pmat = pmt;
   return (float *)(pmt + ncb) + (size_t)env_slot * m.env_lds_floats;  // env_lds_floats is a multiple of 4: 16-B aligned
 }
 
 // =============================================================================================
-template <int SEGW, int JT>
-__global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
+// SPLIT = wave specialisation (8 waves, contact waves beside body waves).  Kernels whose body wave needs more than
+// 256 VGPRs (compound joints) run unsplit: 4 waves per workgroup, one per SIMD, sweeps inline.
+template <int SEGW, int JT, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % PD_BWAVES;
+  const bool contact_wave = SPLIT && (threadIdx.x >> 6) >= PD_BWAVES;  // wave-uniform role
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_WAVES + wave) * EPW + seg;
+  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
   const bool is_body = env_ok && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup(m, smem, tabs, wave * EPW + seg);
+  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
   int *list = (int *)(pcon + nb * PD_W6), *hits = list + m.ntiles;
 
-  const BodyConst c = load_body_const(m, b);
+  BodyConst c = load_body_const(m, b);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
+  auto contact_hit = [&](int pb, const float *r, float4 P, float4 mat) {
+    ContactOut o;
+    if (contact_point_fwd(r, P, mat, o)) {
+      float *f = facc + pb * PD_W6;
+      atomicAdd(f + 0, -o.t.x); atomicAdd(f + 1, -o.t.y); atomicAdd(f + 2, -o.t.z);
+      atomicAdd(f + 3, -o.f.x); atomicAdd(f + 4, -o.f.y); atomicAdd(f + 5, -o.f.z);
+    }
+  };
+  if (SPLIT && contact_wave) {
+    // ---- contact wave: eval_body_contacts for the partner body wave's envs, between barriers A and B of each step
+    STAMP_DECL;
+    for (int step = 0; step < a.nsteps; ++step) {
+      __syncthreads();  // A: records + cull vectors of this step are staged, wrench accumulators are zero
+      STAMP(7);
+      float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+      if (is_body) cv = cull[b];
+      sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, contact_hit STAMP_PASS);
+      STAMP(12);
+      __syncthreads();  // B: contact wrenches are complete
+    }
+    STAMP_FLUSH(a);
+    return;
+  }
   const int ec = env_ok ? env : 0;       // clamped env for safe addressing
   const size_t idx = (size_t)ec * nb + b;  // flat body index (env-major)
   const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
@@ -248,11 +277,10 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
-  float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
   for (int d = 0; d <= m.max_depth; ++d) {
     if (is_body && c.depth == d) {
       s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
-      cv = stage_record(rec, cull, b, s, c.com);
+      stage_record(rec, cull, b, s, c.com);
     }
     WAVE_SYNC();
   }
@@ -291,26 +319,16 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
       td[(size_t)3 * N] = s.v.x; td[(size_t)4 * N] = s.v.y; td[(size_t)5 * N] = s.v.z;
     }
     STAMP(0);
-    // ---- eval_body_contacts
-    sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, [&](int pb, const float *r, float4 P, float4 mat) {
-      ContactOut o;
-      if (contact_point_fwd(r, P, mat, o)) {
-        float *f = facc + pb * PD_W6;
-        atomicAdd(f + 0, -o.t.x); atomicAdd(f + 1, -o.t.y); atomicAdd(f + 2, -o.t.z);
-        atomicAdd(f + 3, -o.f.x); atomicAdd(f + 4, -o.f.y); atomicAdd(f + 5, -o.f.z);
-      }
-    } STAMP_PASS);
-    WAVE_SYNC();
-    if (is_body) {
-      float *f = facc + b * PD_W6;
-      ft += V3(f[0], f[1], f[2]); ff += V3(f[3], f[4], f[5]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) f[k] = 0.f;
+    if (SPLIT) {
+      __syncthreads();  // A: hand this step's records to the contact wave
+    } else {
+      WAVE_SYNC();
+      sweep_contacts<SEGW>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, is_body, seg, l,
+                           contact_hit STAMP_PASS);
     }
     const int fr = a.frame_of_step[step];
-    v3 grf_t = ft, grf_f = ff;
     STAMP(1);
-    // ---- eval_body_joints
+    // ---- eval_body_joints (runs while the contact wave sweeps)
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
     if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT>(m, c, s, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
     if (is_body) {
@@ -319,14 +337,25 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
     }
     STAMP(2);
     WAVE_SYNC();
-    ft -= wc_t; ff -= wc_f;
+    v3 jt = -wc_t, jf = -wc_f;  // joint wrench on this body: own joint first, then children in index order
     for (int k = 0; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
       if (is_body && cid != 0xff) {
         const float *pc = pcon + cid * PD_W6;
-        ft += V3(pc[0], pc[1], pc[2]); ff += V3(pc[3], pc[4], pc[5]);
+        jt += V3(pc[0], pc[1], pc[2]); jf += V3(pc[3], pc[4], pc[5]);
       }
     }
+    STAMP(6);
+    if (SPLIT) __syncthreads();  // B: contact wrenches are complete
+    else WAVE_SYNC();
+    if (is_body) {
+      float *f = facc + b * PD_W6;
+      ft += V3(f[0], f[1], f[2]); ff += V3(f[3], f[4], f[5]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f[k] = 0.f;
+    }
+    const v3 grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
+    ft += jt; ff += jf;
     if (is_body) {
       float *tf = traj_f + (size_t)step * 6 * N + idx;
       tf[0] = ft.x; tf[(size_t)N] = ft.y; tf[(size_t)2 * N] = ft.z;
@@ -352,34 +381,62 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutA
     s = integrate_fwd(m, c, s, ft, ff, inv_m, I, invI, a.dt);
     STAMP(4);
     WAVE_SYNC();
-    if (is_body) cv = stage_record(rec, cull, b, s, c.com);
-    WAVE_SYNC();
+    if (is_body) stage_record(rec, cull, b, s, c.com);
+    if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }
   STAMP_FLUSH(a);
 }
 
 // =============================================================================================
-template <int SEGW, int JT>
-__global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
+template <int SEGW, int JT, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % PD_BWAVES;
+  const bool contact_wave = SPLIT && (threadIdx.x >> 6) >= PD_BWAVES;  // wave-uniform role
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_WAVES + wave) * EPW + seg;
+  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
   const bool is_body = env_ok && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup(m, smem, tabs, wave * EPW + seg);
+  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
   int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.ntiles;
 
-  const BodyConst c = load_body_const(m, b);
+  BodyConst c = load_body_const(m, b);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
+  auto contact_hit = [&](int pb, const float *r, float4 P, float4 mat) {
+    BodyAdj o;
+    if (contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o)) {
+      float *d = cacc + pb * PD_ADJ;
+      atomicAdd(d + 0, o.p.x); atomicAdd(d + 1, o.p.y); atomicAdd(d + 2, o.p.z);
+      atomicAdd(d + 3, o.r.x); atomicAdd(d + 4, o.r.y); atomicAdd(d + 5, o.r.z); atomicAdd(d + 6, o.r.w);
+      atomicAdd(d + 7, o.w.x); atomicAdd(d + 8, o.w.y); atomicAdd(d + 9, o.w.z);
+      atomicAdd(d + 10, o.v.x); atomicAdd(d + 11, o.v.y); atomicAdd(d + 12, o.v.z);
+    }
+  };
+  if (SPLIT && contact_wave) {
+    // ---- contact wave: adjoint of eval_body_contacts for the partner body wave's envs, between barriers A and B
+    STAMP_DECL;
+    for (int step = a.nsteps - 1; step >= 0; --step) {
+      __syncthreads();  // A: records, cull vectors and wrench adjoints (adjf) of this step are staged; cacc is zero
+      STAMP(7);
+      float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+      if (is_body) cv = cull[b];
+      sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, contact_hit STAMP_PASS);
+      STAMP(12);
+      __syncthreads();  // B: contact adjoints are complete
+    }
+    STAMP_FLUSH(a);
+    return;
+  }
   const int ec = env_ok ? env : 0;
   const size_t idx = (size_t)ec * nb + b;
   const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
@@ -445,8 +502,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
     const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
     load_step(step - 1);
-    float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (is_body) cv = stage_record(rec, cull, b, s, c.com);
+    if (is_body) stage_record(rec, cull, b, s, c.com);
     STAMP(0);
     // ---- adjoint of integrate_bodies
     BodyAdj ga = adj_zero();
@@ -459,8 +515,9 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
       f[0] = adj_t0.x; f[1] = adj_t0.y; f[2] = adj_t0.z; f[3] = adj_f0.x; f[4] = adj_f0.y; f[5] = adj_f0.z;
     }
     STAMP(1);
-    WAVE_SYNC();
-    // ---- adjoint of eval_body_joints
+    if (SPLIT) __syncthreads();  // A: hand records + wrench adjoints to the contact wave
+    else WAVE_SYNC();
+    // ---- adjoint of eval_body_joints (runs while the contact wave sweeps)
     BodyAdj par = adj_zero();
     float a_tgt[ND], a_act[ND], a_ke[ND], a_kd[ND];
 #pragma unroll
@@ -483,22 +540,18 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
       }
     }
     STAMP(2);
-    // ---- adjoint of eval_body_contacts
-    sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, [&](int pb, const float *r, float4 P, float4 mat) {
-      BodyAdj o;
-      if (contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o)) {
-        float *d = cacc + pb * PD_ADJ;
-        atomicAdd(d + 0, o.p.x); atomicAdd(d + 1, o.p.y); atomicAdd(d + 2, o.p.z);
-        atomicAdd(d + 3, o.r.x); atomicAdd(d + 4, o.r.y); atomicAdd(d + 5, o.r.z); atomicAdd(d + 6, o.r.w);
-        atomicAdd(d + 7, o.w.x); atomicAdd(d + 8, o.w.y); atomicAdd(d + 9, o.w.z);
-        atomicAdd(d + 10, o.v.x); atomicAdd(d + 11, o.v.y); atomicAdd(d + 12, o.v.z);
-      }
-    } STAMP_PASS);
-    STAMP(3);
     WAVE_SYNC();
     for (int k = 0; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
       if (is_body && cid != 0xff) adj_add_from(ga, cslot + cid * PD_ADJ);
+    }
+    STAMP(3);
+    if (SPLIT) {
+      __syncthreads();  // B: contact adjoints are complete
+    } else {
+      sweep_contacts<SEGW>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, is_body, seg, l,
+                           contact_hit STAMP_PASS);
+      WAVE_SYNC();
     }
     if (is_body) {
       float *d = cacc + b * PD_ADJ;
@@ -507,7 +560,7 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
       for (int k = 0; k < PD_ADJ; ++k) d[k] = 0.f;
     }
     gn = ga;
-    WAVE_SYNC();
+    if (!SPLIT) WAVE_SYNC();
     STAMP(4);
   }
   STAMP_FLUSH(a);
@@ -559,12 +612,12 @@ __global__ __launch_bounds__(PD_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutA
 // =============================================================================================
 // Batched FK (ForwardKinematics, dp_model.py:1022-1130): n articulations, one per segment.
 template <int SEGW, int JT, bool BWD>
-__global__ __launch_bounds__(PD_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
+__global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_WAVES + wave) * EPW + seg;
+  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
   const bool is_body = env < a.n && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1, nb = m.nb;
   const int ec = env < a.n ? env : 0;
@@ -619,20 +672,26 @@ __global__ __launch_bounds__(PD_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
 #define PD_CAT2(a, b) a##b
 #define PD_CAT(a, b) PD_CAT2(a, b)
 
+// Wave specialisation is used where the body wave fits 256 VGPRs (revolute-only articulations, measured +17 %);
+// compound-joint kernels spill at 2 waves/SIMD and are 2x slower split, so they stay unsplit.
+constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
+
 template <int JT>
 static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st) {
   switch (kind) {
     case PD_K_ROLLOUT_FWD:
-      hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+      hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(pd_split(JT) ? PD_BLOCK : PD_FK_BLOCK), lds, st, m,
+                         *(const RolloutArgs *)args);
       break;
     case PD_K_ROLLOUT_BWD:
-      hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+      hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(pd_split(JT) ? PD_BLOCK : PD_FK_BLOCK), lds, st, m,
+                         *(const RolloutArgs *)args);
       break;
     case PD_K_FK_FWD:
-      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, false>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const FkArgs *)args);
+      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, false>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const FkArgs *)args);
       break;
     case PD_K_FK_BWD:
-      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, true>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const FkArgs *)args);
+      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, true>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const FkArgs *)args);
       break;
     default:
       return hipErrorInvalidValue;
@@ -643,8 +702,8 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int
 template <int JT>
 static hipError_t set_lds_jt(int bytes) {
   hipError_t e;
-  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   return hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

@@ -18,24 +18,32 @@ f2s = inp["frame2step"]; fos = dp_model.frame_of_step_tensor(T, f2s, dev)
 fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
 ba = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
 ap = torch.from_numpy(inp["adj_pos"]).to(dev); av = torch.from_numpy(inp["adj_vel"]).to(dev)
-nw = (bs * segw // 64 + 3) // 4 * 4 + 64
+nw = ((bs * segw // 64 + 3) // 4) * 8 + 64
 dbg = torch.zeros(nw * 16, dtype=torch.int64, device=dev)
 L = hip_backend.lib()
 L.pd_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
 for it in range(2):
     out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame_of_step=fos, nframes=len(f2s))
 torch.cuda.synchronize()
-f = dbg.view(-1, 16).cpu().numpy().astype(np.float64); f = f[f.sum(1) > 0]
+f_all = dbg.view(-1, 16).cpu().numpy().astype(np.float64)[: (nw // 8) * 8]
 dbg.zero_()
 g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, len(f2s), out[4], ap, av)
 torch.cuda.synchronize()
-b = dbg.view(-1, 16).cpu().numpy().astype(np.float64); b = b[b.sum(1) > 0]
-fn = ["top: controls+spill stores", "contact sweep + facc", "joints fwd + pcon write", "child gather + traj_f/frame stores", "integrate", "stage record"]
-bn = ["top: seeds+unpack+prefetch+stage", "integrate adj + g_res_f", "joints adj + stores", "contact sweep adj", "gathers + tail"]
-for lab, arr, names in (("FWD", f, fn), ("BWD", b, bn)):
-    tot = arr.sum(1).mean()
-    print("%s  waves=%d  cycles/step (100 MHz memtime ticks x?) mean total per wave per step = %.0f" % (lab, len(arr), tot / T))
-    for i, n in enumerate(names):
-        print("   %-40s %6.1f%%   %8.0f ticks/step" % (n, 100 * arr[:, i].mean() / tot, arr[:, i].mean() / T))
-    for i, n in ((8, "sweep: L1 body cull"), (9, "sweep: L2 tile cull (body loop)"), (10, "sweep: L3 point cull"), (11, "sweep: hit pass")):
-        print("      (inside) %-32s %6.1f%%   %8.0f ticks/step" % (n, 100 * arr[:, i].mean() / tot, arr[:, i].mean() / T))
+b_all = dbg.view(-1, 16).cpu().numpy().astype(np.float64)[: (nw // 8) * 8]
+def rows(arr, contact):
+    r = arr.reshape(-1, 8, 16)[:, 4:] if contact else arr.reshape(-1, 8, 16)[:, :4]
+    r = r.reshape(-1, 16)
+    return r[r.sum(1) > 0]
+
+fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints fwd + pcon write"), (6, "child gather"),
+      (3, "wait at barrier B + facc + traj_f/frame stores"), (4, "integrate"), (5, "stage record")]
+bn = [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"), (2, "wait A + joints adj + stores"),
+      (3, "child gather"), (4, "wait B + cacc gather")]
+cn = [(7, "wait at barrier A (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
+for lab, arr in (("FWD", f_all), ("BWD", b_all)):
+    for who, names, contact in (("body wave", fn if lab == "FWD" else bn, False), ("contact wave", cn, True)):
+        r = rows(arr, contact)
+        tot = r.sum(1).mean()
+        print("%s %-12s waves=%d  cycles per step = %.0f" % (lab, who, len(r), tot / T))
+        for i, n in names:
+            print("      %-48s %6.1f%%   %8.0f cycles/step" % (n, 100 * r[:, i].mean() / tot, r[:, i].mean() / T))
