@@ -1,0 +1,73 @@
+"""Loss / frame utilities around the simulator boundary.
+Same names and semantics as /root/reference/diffphys/dp_utils.py (cited per function)."""
+import torch
+
+from .dataloader import bullet2gl  # noqa: F401  (re-exported like the reference's dp_utils)
+from .geom_utils import axis_angle_to_matrix, quaternion_invert, quaternion_to_matrix, rot_angle, se3_mat2vec, se3_vec2mat
+
+
+def compose_delta(target_q, delta_root):
+    """delta (bs,T,6 axis-angle) applied on the left of target (bs,T,7)   dp_utils.py:22-31"""
+    return se3_mat2vec(se3_vec2mat(delta_root) @ se3_vec2mat(target_q))
+
+
+def remove_nan(t, bs=None, clip=False):
+    """in place NaN -> 0 (and optional +-0.01 clip)   dp_utils.py:43-57"""
+    t[t.isnan()] = 0
+    if clip:
+        t.clamp_(-0.01, 0.01)
+
+
+def rotate_frame(global_q, target_q):
+    """T = T_global @ T_target   dp_utils.py:60-73"""
+    gm = se3_vec2mat(global_q)
+    if global_q.dim() == 1:
+        gm = gm[None, None]
+    return se3_mat2vec(gm @ se3_vec2mat(target_q), outdim=target_q.shape[-1])
+
+
+def rotate_frame_vel(global_q, target_qd):
+    """rotate (linear, angular) halves by the rotation of global_q   dp_utils.py:76-84"""
+    gq = global_q.clone()
+    gq[..., :3] = 0
+    rev = torch.cat([target_qd[..., 3:], target_qd[..., :3]], -1)
+    return torch.cat([rotate_frame(gq, target_qd)[..., :3], rotate_frame(gq, rev)[..., :3]], -1)
+
+
+def reduce_loss(loss_seq, clip=False, th=0):
+    """(bs,T) -> scalar; with clip, a rollout's loss is zeroed after it first exceeds 10x its median   dp_utils.py:93-110"""
+    if clip:
+        for i in range(len(loss_seq)):
+            if th == 0:
+                sub = loss_seq[i]
+                pos = sub[sub > 0]
+                th = pos.median() * 10 if pos.numel() > 0 else 0
+            if th != 0:
+                over = loss_seq[i] > th
+                if bool(over.any()):
+                    loss_seq[i, int(over.float().argmax()):] = 0
+    if loss_seq.sum() > 0:
+        return loss_seq[loss_seq > 0].mean()
+    return loss_seq.mean()
+
+
+def se3_loss(pred, gt, rot_ratio=0.1):
+    """|dp|^2 + rot_ratio * angle(R_pred R_gt^T); quaternion (real-last) or axis-angle rotations   dp_utils.py:113-138"""
+    nanid = torch.logical_or(pred.sum(-1).isnan(), gt.sum(-1).isnan())
+    trn = (pred[..., :3] - gt[..., :3]).pow(2).sum(-1)
+    rp, rg = pred[..., 3:], gt[..., 3:]
+    if rp.shape[-1] == 3:
+        rp, rgi = axis_angle_to_matrix(rp), axis_angle_to_matrix(rg).transpose(-1, -2)
+    else:
+        rp = quaternion_to_matrix(rp[..., [3, 0, 1, 2]])
+        rgi = quaternion_to_matrix(quaternion_invert(rg[..., [3, 0, 1, 2]]))
+    loss = trn + rot_angle(rp @ rgi) * rot_ratio
+    return torch.where(nanid, torch.zeros_like(loss), loss)
+
+
+def compute_com(body_q, part_com, part_mass):
+    """mass-weighted COM of one articulation (numpy)   dp_utils.py:86-90"""
+    from scipy.spatial.transform import Rotation as R
+
+    c = (R.from_quat(body_q[:, 3:]).as_matrix() @ part_com)[..., 0] + body_q[:, :3]
+    return (c * part_mass[:, None]).sum(0) / part_mass.sum()

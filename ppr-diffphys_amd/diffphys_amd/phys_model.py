@@ -1,0 +1,370 @@
+"""Host plumbing of the motion-imitation optimisation on top of the HIP boundary
+(SURVEY.md section 8 row f3).  Mirrors ``phys_model`` of the reference
+(/root/reference/diffphys/dp_model.py:56-1011): same attributes, method names,
+tensor flow, loss terms, optimiser / scheduler, gradient guards and checkpoint
+queue, so that ``main.py`` of the reference can drive it with the same flags.
+
+Not reproduced (out of scope): rendering / mesh posing
+(``query`` returns trajectories only; the foot-height regulariser uses the
+ground-contact candidates instead of the visual meshes), lab4d coupling.
+
+Harness quirks of the reference that are kept on purpose:
+  (i)  ``convert_ppr_warp`` is applied to the FLAT qd_init vector, so only env 0's root twist is swapped;
+  (ii) torques / res_f are reshaped [bs,T,.] -> [T,.] without the permute the other tensors get (both are zero);
+  (iii) the model stays in train() mode during "eval" rollouts, so init noise is added there too;
+  (iv) mocap rows (incl. quaternions) are interpolated linearly and not re-normalised.
+"""
+import os
+from copy import deepcopy
+
+import numpy as np
+import scipy.interpolate
+import torch
+import torch.nn as nn
+
+from . import robots, sim
+from .dataloader import bullet2gl, parse_amp
+from .dp_model import ForwardKinematics, ForwardWarp, convert_ppr_warp
+from .dp_utils import compose_delta, reduce_loss, rotate_frame, rotate_frame_vel, se3_loss
+from .geom_utils import fid_reindex
+from .time_mlp import TimeMLPWrapper, interp_wt, match_param_name
+
+
+def get_local_rank():
+    try:
+        return int(os.environ["LOCAL_RANK"])
+    except Exception:
+        return 0
+
+
+class phys_model(nn.Module):
+    def __init__(self, opts, dataloader, dt=5e-4, device="cuda", urdf_root=None):
+        super().__init__()
+        self.opts = opts
+        self.save_dir = os.path.join(opts["logroot"], "%s-%s" % (opts["seqname"], opts["logname"]))
+        self.total_iters = int(opts["num_rounds"] * opts["iters_per_round"] * opts["ratio_phys_cycle"]) + opts["warmup_iters"] + 1
+        self.progress = 0
+        self.dt = dt
+        self.noise_std = opts["noise_std"]
+        self.device = device
+        self.preset_data(dataloader)
+
+        name = opts["urdf_template"]
+        if name not in robots.PRESETS:
+            raise NotImplementedError(name)
+        self.in_bullet = False
+        # articulation template: compiled from the URDF when its directory is given, else the committed npz
+        if urdf_root is not None:
+            env, _, info = robots.make_env(name, urdf_root, 1, device="cpu")
+            self.template = env.template()
+            self.template["kp"], self.template["kd"] = np.float32(info["kp"]), np.float32(info["kd"])
+        else:
+            self.template = robots.load_template(name)
+        tpl = self.template
+        self.joint_attach_ke, self.joint_attach_kd = float(tpl["joint_attach_ke"]), float(tpl["joint_attach_kd"])
+        self.n_dof = int(tpl["nq"]) - 7
+        self.n_links = int(tpl["nb"])
+        kp, kd = float(tpl["kp"]), float(tpl["kd"])
+        nqd = int(tpl["nqd"])
+        self.target_ke = nn.Parameter(torch.tensor([0.0] * 6 + [kp] * (nqd - 6), dtype=torch.float32))
+        self.target_kd = nn.Parameter(torch.tensor([0.0] * 6 + [kd] * (nqd - 6), dtype=torch.float32))
+        self.body_mass = nn.Parameter(torch.tensor(tpl["body_mass"], dtype=torch.float32))
+        self.register_buffer("norm_body_inertia", torch.tensor(tpl["body_inertia"], dtype=torch.float32))
+        self.register_buffer("c_body", torch.tensor(tpl["contact_body"], dtype=torch.long), persistent=False)
+        self.register_buffer("c_point", torch.tensor(tpl["contact_point"], dtype=torch.float32), persistent=False)
+        self.register_buffer("c_dist", torch.tensor(tpl["contact_dist"], dtype=torch.float32), persistent=False)
+
+        self.add_nn_modules()
+        self.to(device)
+        self.init_global_q()
+        self.add_optimizer(opts)
+        self.model_cache, self.optimizer_cache, self.scheduler_cache = [None, None], [None, None], [None, None]
+        self.grad_queue = {}
+
+    # ------------------------------------------------------------------ setup
+    def preset_data(self, dataloader):
+        amp_info = dataloader.amp_info
+        self.frame_offset_raw = dataloader.data_info["offset"]
+        self.frame_interval = dataloader.frame_interval
+        self.frame_info = None
+        self.total_frames = len(amp_info)
+        self.steps_per_fr_interval = int(self.frame_interval / self.dt)
+        self.amp_info_func = scipy.interpolate.interp1d(np.arange(self.total_frames), amp_info, kind="linear",
+                                                        fill_value="extrapolate", axis=0)
+
+    def add_nn_modules(self):
+        n = self.total_frames
+        self.root_pose_mlp = TimeMLPWrapper(n, out_channels=6, D=8, skips=[4], time_scale=0.1, output_scale=0.5)
+        self.joint_angle_mlp = TimeMLPWrapper(n, out_channels=self.n_dof)
+        self.vel_mlp = TimeMLPWrapper(n, out_channels=6 + self.n_dof, output_scale=5.0)
+        self.torque_mlp = TimeMLPWrapper(n, out_channels=self.n_dof)
+        self.residual_f_mlp = TimeMLPWrapper(n, out_channels=6 * self.n_links)
+
+    def _make_env(self, num_envs):
+        env = sim.Model.from_template(self.template, num_envs, self.device)
+        env.ground = True
+        env.joint_attach_ke, env.joint_attach_kd = self.joint_attach_ke, self.joint_attach_kd
+        return env
+
+    def init_global_q(self):
+        self.frame2step = [0]
+        self.num_envs = 1
+        self.env = self._make_env(1)
+        self.global_q = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0], device=self.device)
+        steps_fr = torch.tensor([[0.0]], device=self.device)
+        with torch.no_grad():
+            _, _, queried_q, queried_qd, _, _ = self.get_batch_input(steps_fr)
+            pos, _, _ = ForwardKinematics.apply(queried_q[:, None], queried_qd[:, None], self.env)
+            foot_height = float(self.get_foot_height(pos)[0, 0])
+        self.global_q = nn.Parameter(torch.tensor([0.0, -foot_height, 0.0, 0.0, 0.0, 0.0, 1.0], dtype=torch.float32, device=self.device))
+
+    def set_progress(self, num_iters):
+        self.progress = num_iters / self.total_iters
+        if "reg_cam_prior_wt" in self.opts:
+            self.set_loss_weight("reg_cam_prior_wt", (0, 0.5), (1, 0), self.progress)
+
+    def set_loss_weight(self, loss_name, anchor_x, anchor_y, current_steps, type="linear"):
+        if "%s_init" % loss_name not in self.opts:
+            self.opts["%s_init" % loss_name] = self.opts[loss_name]
+        self.opts[loss_name] = self.opts["%s_init" % loss_name] * interp_wt(anchor_x, anchor_y, current_steps, type=type)
+
+    def reinit_envs(self, num_envs, frames_per_wdw, is_eval=False, overwrite=False):
+        self.num_envs, self.frames_per_wdw = num_envs, frames_per_wdw
+        self.steps_idx = range(self.steps_per_fr_interval * (frames_per_wdw - 1) + 1)
+        self.steps_idx_fr = torch.tensor(list(self.steps_idx), device=self.device) / self.steps_per_fr_interval
+        self.frame2step = [i for i in range(len(self.steps_idx)) if i % self.steps_per_fr_interval == 0]
+        env_name = "eval_env" if is_eval else "train_env"
+        if hasattr(self, env_name) and not overwrite and getattr(self, env_name).num_envs == num_envs:
+            self.env = getattr(self, env_name)
+        else:
+            self.env = self._make_env(num_envs)  # the trajectory store lives in the autograd ctx, not in per-step States
+            setattr(self, env_name, self.env)
+
+    # -------------------------------------------------------------- optimiser
+    def get_lr_dict(self):
+        lr_base = self.opts["phys_learning_rate"]
+        lr_explicit = lr_base * 10
+        startwith = {k: lr_explicit for k in ("global_q", "target_ke", "target_kd", "attach_ke", "attach_kd", "body_mass")}
+        startwith.update({k: lr_base for k in ("root_pose_mlp", "joint_angle_mlp", "vel_mlp", "torque_mlp", "residual_f_mlp")})
+        return startwith, {"root_pose_mlp.base_quat": lr_explicit}
+
+    def get_optimizable_param_list(self):
+        startwith, with_ = self.get_lr_dict()
+        refs, params, lrs = [], [], []
+        for name, p in self.named_parameters():
+            m_loose, lr_loose = match_param_name(name, with_, type="with")
+            m_strict, lr_strict = match_param_name(name, startwith, type="startwith")
+            lr = lr_loose if m_loose > 0 else (lr_strict if m_strict > 0 else 0.0)
+            if lr > 0:
+                refs.append({name: p})
+                params.append({"params": p})
+                lrs.append(lr)
+        return refs, params, lrs
+
+    def add_optimizer(self, opts):
+        self.params_ref_list, params_list, lr_list = self.get_optimizable_param_list()
+        self.optimizer = torch.optim.AdamW(params_list, lr=opts["phys_learning_rate"], weight_decay=1e-4)
+        total_iters = max(2, self.total_iters)
+        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
+            self.optimizer, lr_list, total_iters, pct_start=2.0 / total_iters, cycle_momentum=False,
+            anneal_strategy="linear", final_div_factor=1e2, div_factor=25)
+
+    def update(self):
+        grad_dict = self.check_grad()
+        self.optimizer.step()
+        self.scheduler.step()
+        self.optimizer.zero_grad()
+        return grad_dict
+
+    def check_grad(self, thresh=10.0):
+        """global-norm guard with rollback to the model cached two rounds ago, then per-parameter
+        median-based clipping (dp_model.py:936-1000)"""
+        params_list = [p for d in self.params_ref_list for p in d.values() if p.requires_grad and p.grad is not None]
+        grad_norm = torch.nn.utils.clip_grad_norm_(params_list, thresh)
+        if grad_norm > thresh:
+            self.optimizer.zero_grad()
+            if get_local_rank() == 0:
+                print("large grad: %.2f, clear gradients" % grad_norm)
+            if self.model_cache[0] is not None:
+                self.load_state_dict(self.model_cache[0])
+                self.optimizer.load_state_dict(self.optimizer_cache[0])
+                self.scheduler.load_state_dict(self.scheduler_cache[0])
+            return {}
+        grad_dict, queue_length, scale_threshold = {}, 10, 5.0
+        for d in self.params_ref_list:
+            ((name, p),) = d.items()
+            if not (p.requires_grad and p.grad is not None):
+                continue
+            grad = p.grad.reshape(-1).norm(2, -1)
+            grad_dict["grad/" + name] = grad
+            q = self.grad_queue.setdefault(name, [])
+            if len(q) > queue_length:
+                med = torch.stack(q[:-1]).median()
+                grad_dict["grad_med/" + name] = med
+                if grad > scale_threshold * med:
+                    torch.nn.utils.clip_grad_norm_(p, med)
+                else:
+                    q.append(grad)
+                    q.pop(0)
+            else:
+                q.append(grad)
+        return grad_dict
+
+    def clear_grad(self):
+        self.optimizer.zero_grad()
+        if self.model_cache[0] is not None:
+            self.load_state_dict(self.model_cache[0])
+            self.optimizer.load_state_dict(self.optimizer_cache[0])
+            self.scheduler.load_state_dict(self.scheduler_cache[0])
+
+    def save_checkpoint(self, steps_count):
+        for c in (self.model_cache, self.optimizer_cache, self.scheduler_cache):
+            c[0] = c[1]
+        self.model_cache[1] = deepcopy(self.state_dict())
+        self.optimizer_cache[1] = deepcopy(self.optimizer.state_dict())
+        self.scheduler_cache[1] = deepcopy(self.scheduler.state_dict())
+        if get_local_rank() == 0:
+            os.makedirs(self.save_dir, exist_ok=True)
+            path = "%s/ckpt_phys_%04d.pth" % (self.save_dir, steps_count)
+            torch.save(self.model_cache[1], path)
+            torch.save(self.model_cache[1], "%s/ckpt_phys_latest.pth" % self.save_dir)
+
+    def load_checkpoint(self, model_path):
+        self.load_state_dict(torch.load(model_path, map_location="cpu"), strict=False)
+
+    # ------------------------------------------------------------ data query
+    def get_mocap_data(self, steps_fr):
+        msm = parse_amp(self.amp_info_func(steps_fr))
+        msm = {k: np.array(v, copy=True) for k, v in msm.items()}
+        bullet2gl(msm, self.in_bullet)
+        return msm
+
+    def get_net_pred(self, steps_fr):
+        bs, nstep = steps_fr.shape
+        t = steps_fr.reshape(-1)
+        torques = self.torque_mlp(t)
+        torques = torch.cat([torch.zeros_like(torques[:, :1].repeat(1, 6)), torques], 1).view(bs, nstep, -1) * 0
+        res_f = self.residual_f_mlp(t).view(bs, nstep, -1, 6)
+        res_f = torch.cat([res_f[..., :3] * 10, res_f[..., 3:]], -1).view(bs, nstep, -1) * 0
+        delta_root = self.root_pose_mlp(t).view(bs, nstep, -1)
+        delta_ja_ref = self.joint_angle_mlp(t).view(bs, nstep, -1)
+        state_qd = self.vel_mlp(t).view(bs, nstep, -1)
+        return torques, delta_root, delta_ja_ref, state_qd, res_f
+
+    @staticmethod
+    def rearrange_pred(queried_q, queried_ja, queried_qd, torques, res_f):
+        bs, nstep, _ = queried_q.shape
+        queried_q = torch.cat([queried_q, queried_ja], -1).permute(1, 0, 2).reshape(nstep, -1)
+        queried_qd = queried_qd.permute(1, 0, 2).reshape(nstep, -1)
+        ref_ja = torch.cat([torch.zeros_like(queried_ja[..., :1].repeat(1, 1, 6)), queried_ja], -1).permute(1, 0, 2).reshape(nstep, -1)
+        return ref_ja, queried_q, queried_qd, torques.reshape(nstep, -1), res_f.reshape(nstep, -1, 6)  # quirk (ii)
+
+    def get_foot_height(self, state_body_q):
+        """lowest ground-contact candidate per (env, frame); the reference poses the visual meshes instead"""
+        X = state_body_q[..., self.c_body, :]
+        q, p = X[..., 3:], X[..., :3]
+        qv, w = q[..., :3], q[..., 3:]
+        pt = self.c_point.expand(qv.shape)
+        rot = pt * (2 * w * w - 1) + 2 * w * torch.cross(qv, pt, dim=-1) + 2 * qv * (qv * pt).sum(-1, keepdim=True)
+        return (p[..., 1] + rot[..., 1] - self.c_dist).min(-1)[0]
+
+    def compute_frame_start(self):
+        fs = torch.tensor(np.random.rand(self.num_envs), device=self.device)
+        return (fs * (self.total_frames - self.frames_per_wdw)).round().long()
+
+    def fk_pos_vel(self, target_q, target_ja, target_qd, target_jad):
+        q = torch.cat([target_q, target_ja], -1).permute(1, 0, 2).contiguous()
+        qd = convert_ppr_warp(torch.cat([target_qd, target_jad], -1).permute(1, 0, 2).contiguous())
+        body_q, body_qd, msm = ForwardKinematics.apply(q, qd, self.env)
+        return body_q, convert_ppr_warp(body_qd), msm
+
+    def get_batch_input(self, steps_fr):
+        device = steps_fr.device
+        msm = self.get_mocap_data(steps_fr.detach().cpu().numpy())
+        t = lambda k: torch.tensor(msm[k], dtype=torch.float32, device=device)
+        target_ja, target_jad = t("jang"), t("jvel")
+        target_q = torch.cat([t("pos"), t("orn")], -1)
+        target_qd = torch.cat([t("vel"), t("avel")], -1)
+        target_q = rotate_frame(self.global_q, target_q)
+        target_qd = rotate_frame_vel(self.global_q, target_qd)
+        f2s = self.frame2step
+        target_position, target_velocity, self.target_trajs = self.fk_pos_vel(
+            target_q[:, f2s], target_ja[:, f2s], target_qd[:, f2s], target_jad[:, f2s])
+        torques, delta_q, delta_ja, queried_qd, res_f = self.get_net_pred(steps_fr)
+        queried_q = compose_delta(target_q, delta_q)
+        queried_ja = target_ja + delta_ja
+        ref_ja, queried_q, queried_qd, torques, res_f = self.rearrange_pred(queried_q, queried_ja, queried_qd, torques, res_f)
+        return target_position, ref_ja, queried_q, queried_qd, torques, res_f
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, frame_start=None):
+        frame_start = self.compute_frame_start() if frame_start is None else frame_start[: self.num_envs]
+        steps_fr = frame_start[:, None] + self.steps_idx_fr[None]
+        vidid, _ = fid_reindex(steps_fr[:, self.frame2step], len(self.frame_offset_raw) - 1, self.frame_offset_raw)
+        outseq_idx = (vidid[:, :1] - vidid) != 0
+        target_position, ref_ja, queried_q, queried_qd, torques, res_f = self.get_batch_input(steps_fr)
+
+        res_fin = res_f.clone()
+        q_init = queried_q[0].reshape(-1)
+        qd_init = queried_qd[0]
+        if self.training and self.noise_std > 0:  # quirk (iii): also during "eval" rollouts
+            noise_ratio = np.clip(1 - 1.5 * self.progress, 0, 1)
+            noise = torch.tensor(np.random.normal(size=q_init.shape, scale=self.noise_std * noise_ratio), dtype=torch.float32,
+                                 device=self.device).view(self.num_envs, -1)
+            noise[:, :3] = 0
+            noise[:, 3:7] *= 5
+            q_init = q_init + noise.reshape(-1)
+        n = self.num_envs
+        target_ke = self.target_ke[None].repeat(n, 1).view(-1)
+        target_kd = self.target_kd[None].repeat(n, 1).view(-1)
+        body_mass = self.body_mass[None].repeat(n, 1).view(-1)
+        body_inv_mass = 1.0 / body_mass
+        body_inertia = self.norm_body_inertia[None].repeat(n, 1, 1, 1).view(-1, 3, 3) * body_mass[..., None, None]
+        body_inv_inertia = body_inertia.inverse().contiguous()
+        qd_init = convert_ppr_warp(qd_init)  # quirk (i): flat vector
+        res_fin = convert_ppr_warp(res_fin)
+        sim_position, sim_velocity = ForwardWarp.apply(q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass,
+                                                       body_inv_mass, body_inertia, body_inv_inertia, self)
+        sim_velocity = convert_ppr_warp(sim_velocity)
+
+        F_ = self.frames_per_wdw
+        queried_q = queried_q[self.frame2step].reshape(F_, n, -1)
+        queried_qd = convert_ppr_warp(queried_qd[self.frame2step].reshape(F_, n, -1))
+        queried_position, queried_velocity, self.pid_ref = ForwardKinematics.apply(queried_q, queried_qd, self.env)
+        queried_velocity = convert_ppr_warp(queried_velocity)
+        foot_height = self.get_foot_height(queried_position)
+
+        target_position = target_position.reshape(n, F_, -1, 7)
+        sim_position = sim_position.reshape(F_, n, -1, 7).permute(1, 0, 2, 3)
+        sim_velocity = sim_velocity.reshape(F_, n, -1, 6).permute(1, 0, 2, 3)
+
+        loss_dict = {}
+        loss_traj = se3_loss(sim_position, target_position).mean(-1)
+        loss_traj = torch.where(outseq_idx, torch.zeros_like(loss_traj), loss_traj)
+        loss_dict["traj"] = reduce_loss(loss_traj, clip=True)
+        loss_pos = se3_loss(queried_position, sim_position.detach()).mean(-1)
+        loss_dict["pos_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_pos), loss_pos))
+        loss_vel = se3_loss(queried_velocity, sim_velocity.detach()).mean(-1)
+        loss_dict["vel_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_vel), loss_vel))
+        loss_dict["reg_torque"] = torques.pow(2).mean()
+        loss_dict["reg_res_f"] = res_f.pow(2).mean()
+        loss_dict["reg_foot"] = foot_height.pow(2).mean()
+
+        total_loss = 0
+        for k, v in loss_dict.items():
+            total_loss = total_loss + v * self.opts[k + "_wt"]
+        out = {"loss_" + k: v for k, v in loss_dict.items()}
+        if bool(total_loss.isnan()):
+            raise FloatingPointError("total_loss is NaN")  # the reference drops into pdb here (dp_model.py:832)
+        out["total_loss"] = total_loss
+        return out
+
+    def backward(self, loss):
+        loss.backward()
+
+    @torch.no_grad()
+    def query(self, img_size=None):
+        """simulated / target / control-reference body trajectories of env 0 plus forces (no mesh posing)"""
+        return {"sim_traj": np.stack(self.sim_trajs, 0), "target_traj": np.stack(self.target_trajs, 0),
+                "control_ref": np.stack(self.pid_ref, 0), "grf": torch.stack(self.grfs, 0).cpu().numpy(),
+                "jaf": torch.stack(self.jafs, 0).cpu().numpy()}

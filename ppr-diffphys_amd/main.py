@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Motion-imitation optimisation loop on the HIP rollout (mirrors /root/reference/main.py:50-105;
+same flag names and defaults, argparse instead of absl, no renderer).
+
+    python ppr-diffphys_amd/main.py --urdf_template laikago --seqname mi-pace --logname 0
+
+The mocap sequence is read from ./data/motion_sequences/<seq>/amp-<seq>.txt when present (the
+reference's layout) and from the compiled fixture otherwise.
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+
+from diffphys_amd.dataloader import DataLoader  # noqa: E402
+from diffphys_amd.phys_model import phys_model  # noqa: E402
+
+
+def get_opts(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--local_rank", type=int, default=0)
+    ap.add_argument("--ngpu", type=int, default=1)
+    ap.add_argument("--accu_steps", type=int, default=1)
+    ap.add_argument("--seqname", default="mi-pace")
+    ap.add_argument("--logroot", default="logdir/")
+    ap.add_argument("--logname", default="dynamics")
+    ap.add_argument("--phys_learning_rate", type=float, default=1e-4)
+    ap.add_argument("--num_rounds", type=int, default=5)
+    ap.add_argument("--warmup_iters", type=int, default=0)
+    ap.add_argument("--urdf_template", default="laikago")
+    ap.add_argument("--num_freq", type=int, default=10)
+    ap.add_argument("--t_embed_dim", type=int, default=128)
+    ap.add_argument("--iters_per_round", type=int, default=20)
+    ap.add_argument("--ratio_phys_cycle", type=float, default=1.0)
+    ap.add_argument("--noise_std", type=float, default=2e-3)
+    ap.add_argument("--traj_wt", type=float, default=0.01)
+    ap.add_argument("--pos_state_wt", type=float, default=0.01)
+    ap.add_argument("--vel_state_wt", type=float, default=1e-4)
+    ap.add_argument("--pos_distill_wt", type=float, default=0.0)
+    ap.add_argument("--reg_torque_wt", type=float, default=0.0)
+    ap.add_argument("--reg_res_f_wt", type=float, default=0.0)
+    ap.add_argument("--reg_foot_wt", type=float, default=0.0)
+    ap.add_argument("--reg_root_wt", type=float, default=0.0)
+    ap.add_argument("--num_envs", type=int, default=10, help="envs per training iteration (main.py:86 of the reference)")
+    ap.add_argument("--frames_per_wdw", type=int, default=24)
+    ap.add_argument("--urdf_root", default=None, help="directory with laikago/laikago.urdf etc. (default: compiled templates)")
+    return vars(ap.parse_args(argv))
+
+
+def main(argv=None):
+    opts = get_opts(argv)
+    loader = DataLoader(opts)
+    model = phys_model(opts, loader, urdf_root=opts["urdf_root"]).cuda()
+    model.train()
+    for it in range(model.total_iters):
+        if it % opts["iters_per_round"] == 0:
+            model.save_checkpoint(it)
+            model.reinit_envs(1, frames_per_wdw=model.total_frames, is_eval=True)  # evaluation rollout over the whole clip
+            with torch.no_grad():
+                ev = model.forward(frame_start=torch.zeros(1, dtype=torch.long, device=model.device))
+            print("[eval %4d] traj loss %.5f" % (it, float(ev["loss_traj"])))
+            model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"], is_eval=False)
+        t0 = time.time()
+        model.set_progress(it)
+        loss_dict = model.forward()
+        model.backward(loss_dict["total_loss"])
+        model.update()
+        torch.cuda.synchronize()
+        print("[iter %4d] total %.6f traj %.5f pos_state %.5f  (%.3f s)" % (
+            it, float(loss_dict["total_loss"]), float(loss_dict["loss_traj"]), float(loss_dict["loss_pos_state"]), time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

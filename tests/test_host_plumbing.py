@@ -1,0 +1,68 @@
+"""CPU tests of the loss / frame utilities and MLP plumbing."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial.transform import Rotation as R
+
+from diffphys_amd import dp_utils, geom_utils
+from diffphys_amd.time_mlp import TimeMLPWrapper, interp_wt, match_param_name
+
+
+def test_quaternion_matrix_roundtrip_against_scipy():
+    rng = np.random.RandomState(0)
+    q_xyzw = rng.randn(50, 4)
+    q_xyzw /= np.linalg.norm(q_xyzw, axis=1, keepdims=True)
+    m_ref = R.from_quat(q_xyzw).as_matrix()
+    q_wxyz = torch.tensor(q_xyzw[:, [3, 0, 1, 2]])
+    m = geom_utils.quaternion_to_matrix(q_wxyz)
+    assert np.allclose(m.numpy(), m_ref, atol=1e-12)
+    back = geom_utils.matrix_to_quaternion(m)
+    sign = torch.sign((back * q_wxyz).sum(-1, keepdim=True))
+    assert torch.allclose(back * sign, q_wxyz, atol=1e-10)
+    aa = torch.tensor(R.from_quat(q_xyzw).as_rotvec())
+    assert np.allclose(geom_utils.axis_angle_to_matrix(aa).numpy(), m_ref, atol=1e-10)
+    assert torch.allclose(geom_utils.quaternion_to_axis_angle(geom_utils.axis_angle_to_quaternion(aa)), aa, atol=1e-10)
+
+
+def test_se3_vec_mat_roundtrip_and_rotate_frame():
+    rng = np.random.RandomState(1)
+    v = torch.tensor(rng.randn(4, 3, 7))
+    v[..., 3:] = v[..., 3:] / v[..., 3:].norm(dim=-1, keepdim=True)
+    m = geom_utils.se3_vec2mat(v)
+    assert torch.allclose(m[..., 3, :], torch.tensor([0.0, 0, 0, 1]).expand(4, 3, 4).to(m.dtype))
+    v2 = geom_utils.se3_mat2vec(m)
+    sign = torch.sign((v2[..., 3:] * v[..., 3:]).sum(-1, keepdim=True))
+    assert torch.allclose(v2[..., :3], v[..., :3]) and torch.allclose(v2[..., 3:] * sign, v[..., 3:], atol=1e-10)
+    g = torch.tensor([0.0, -0.3, 0.0, 0.0, 0.0, 0.0, 1.0], dtype=v.dtype)
+    out = dp_utils.rotate_frame(g, v)
+    assert torch.allclose(out[..., 1], v[..., 1] - 0.3) and torch.allclose(out[..., 0], v[..., 0])
+    qd = torch.tensor(rng.randn(4, 3, 6))
+    assert torch.allclose(dp_utils.rotate_frame_vel(g, qd), qd, atol=1e-12)  # identity rotation leaves twists alone
+
+
+def test_se3_loss_and_reduce_loss():
+    a = torch.tensor([[0.0, 0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
+    ang = 0.4
+    b = torch.tensor([[1.0, 2.0, 0, 0, np.sin(ang / 2), 0, np.cos(ang / 2)]], dtype=torch.float64)
+    assert abs(float(dp_utils.se3_loss(a, b)) - (5.0 + 0.1 * ang)) < 1e-5
+    nan = torch.tensor([[float("nan"), 0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
+    assert float(dp_utils.se3_loss(nan, b)) == 0.0
+    seq = torch.tensor([[1.0, 1.1, 0.9, 50.0, 1.0], [1.0, 1.0, 1.0, 1.0, 1.0]])
+    red = dp_utils.reduce_loss(seq.clone(), clip=True)
+    assert abs(float(red) - np.mean([1.0, 1.1, 0.9] + [1.0] * 5)) < 1e-6  # env 0 truncated where it first exceeds 10x median
+    t = torch.tensor([1.0, float("nan"), 3.0])
+    dp_utils.remove_nan(t)
+    assert t.tolist() == [1.0, 0.0, 3.0]
+
+
+def test_time_mlp_and_schedules():
+    mlp = TimeMLPWrapper(39, out_channels=12, output_scale=0.5)
+    y = mlp(torch.tensor([0.0, 3.5, 38.0]))
+    assert y.shape == (3, 12) and torch.isfinite(y).all() and y.abs().max() < 1.0
+    y.sum().backward()
+    assert all(p.grad is not None for p in mlp.parameters())
+    mlp2 = TimeMLPWrapper(39, out_channels=12, output_scale=0.5)
+    assert torch.equal(mlp2(torch.tensor([1.0])), mlp(torch.tensor([1.0])))  # seeded init
+    assert interp_wt((0, 0.5), (1, 0), 0.25) == 0.5 and interp_wt((0, 0.5), (1, 0), 0.9) == 0
+    assert match_param_name("root_pose_mlp.base_quat", {"root_pose_mlp.base_quat": 1e-3}, "with") == (1, 1e-3)
+    assert match_param_name("vel_mlp.head.weight", {"vel_mlp": 1e-4, "torque_mlp": 2.0}, "startwith") == (1, 1e-4)
