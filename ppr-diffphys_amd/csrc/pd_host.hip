@@ -194,8 +194,8 @@ static int build_device(pd_model *m, int segw) {
   d.small_tiles = (const int *)(base + o_st); d.big_bodies = big_bodies; d.n_small = n_small;
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
-  // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list
-  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles + 8 * segw + 3) / 4) * 4 + 4;
+  // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
+  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
   const int envs_per_block = PD_BWAVES * (64 / segw);
   m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 16 + (size_t)std::max(m->nmat, 1) * 16 +
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +

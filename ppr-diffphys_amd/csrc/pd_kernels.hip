@@ -82,23 +82,59 @@ PD_DEV bool cull_above(float4 cv, float4 sp) {  // true when the whole sphere is
   return ylow > 1e-4f * (1.0f + sp.w);
 }
 
-template <int SEGW, typename F>
-PD_DEV void sweep_flush(const SweepTables &T, const float *rec, const int *hits, int &nh, int l, F &&on_hit) {
-  for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW) {
-    int j = j0 + l;
-    if (j < nh) {
-      int e = hits[j];
-      int pt = e & 0xffff, pb = (e >> 24) & 0x3f;
-      on_hit(pb, rec + pb * PD_REC, T.pts[pt], T.mats[T.pmat[pt]]);
+// Hit pass for one batch [j0, j0 + SEGW) of the env's compacted hit list.  Lane j computes hit j0 + j (compute() does
+// the reference's arithmetic and returns NV floats, zeros when the exact test says "above ground") and parks the
+// result in slot[j]; then lane b (= body b) sums the contiguous run of hits that belong to body b -- hits are appended
+// tile by tile and tiles are grouped by body -- and adds it to dst[b].  No LDS float atomics: 13 ds_add_f32 per hit
+// cost ~2400 cycles per step and stalled the partner wave's LDS traffic; this is plain stores plus a short
+// lane-per-body loop, and the summation order is fixed.
+//
+// ATOMIC = true keeps ds_add_f32 (measured faster for the 6-float forward wrench: 0.358 vs 0.415 ms per rollout;
+// slower for the 13-float adjoint: 0.646 vs 0.617 ms).  Both orders are fixed, so results are reproducible either way.
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
+PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int *hits, float *slot, float *dst, int j0, int nh,
+                              int run_start, int run_cnt, int l, int nb, F &&compute) {
+  const int j = j0 + l;
+  if (j < nh) {
+    int e = hits[j];
+    int pt = e & 0xffff, pb = (e >> 24) & 0x3f;
+    float out[NV];
+    compute(rec + pb * PD_REC, T.pts[pt], T.mats[T.pmat[pt]], out);
+    if (ATOMIC) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) atomicAdd(dst + pb * DSTRIDE + i, out[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) slot[l * NV + i] = out[i];
     }
   }
-  nh = 0;
+  if (ATOMIC) return;
+  WAVE_SYNC();
+  const int hi_all = nh < j0 + SEGW ? nh : j0 + SEGW;
+  const int t_lo = (run_start > j0 ? run_start : j0) - j0;
+  const int t_hi = (run_cnt > 0 ? (run_start + run_cnt < hi_all ? run_start + run_cnt : hi_all) : j0) - j0;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  for (int t = t_lo; __ballot(t < t_hi) != 0ull; ++t) {
+    if (t < t_hi) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) acc[i] += slot[t * NV + i];
+    }
+  }
+  if (l < nb && t_lo < t_hi) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) dst[l * DSTRIDE + i] += acc[i];
+  }
+  WAVE_SYNC();
 }
 
 // cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
-template <int SEGW, typename F>
+// dst: per-body accumulators [nb][DSTRIDE] (zeroed by their owner before the sweep); slot: SEGW*NV floats of scratch.
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
-                           const float4 *cull, int *list, int *hits, bool is_body, int seg, int l, F &&on_hit STAMP_ARGS) {
+                           const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, int seg, int l,
+                           F &&compute STAMP_ARGS) {
   if (m.nc == 0) return;
   const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
   const unsigned long long wave_any = __ballot(surv);
@@ -118,8 +154,8 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
         pk = T.tpack[e & 0xffff];
         pass = !cull_above(cull[e >> 16], T.tsphere[e & 0xffff]);
       }
-      int slot = seg_slot(pass, sm, nlist);
-      if (pass) list[slot] = pk;
+      int s = seg_slot(pass, sm, nlist);
+      if (pass) list[s] = pk;
     }
   }
   // ---- L2, big bodies (rarely survive L1): the segment's lanes share one body's tiles
@@ -141,48 +177,50 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
         pk = T.tpack[t_first + t];
         pass = !cull_above(cb, T.tsphere[t_first + t]);
       }
-      int slot = seg_slot(pass, sm, nlist);
-      if (pass) list[slot] = pk;
+      int s = seg_slot(pass, sm, nlist);
+      if (pass) list[s] = pk;
     }
   }
   STAMP(9);
   WAVE_SYNC();
-  // ---- L3: point cull, PD_UNROLL tiles per iteration; hits are rare, so each lane collects its hits as a bit
-  // mask and the (usually single) compaction round runs once per iteration instead of once per tile
-  int nh = 0;
+  // ---- L3: point cull, PD_UNROLL tiles per iteration (their LDS reads overlap).  Hits are appended tile by tile, so the
+  // hits of one body form one contiguous run [run_start, run_start + run_cnt) of the hit list, tracked by lane == body.
+  int nh = 0, run_start = 0, run_cnt = 0;
+  auto flush_all = [&]() {
+    WAVE_SYNC();
+    for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW)
+      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC>(T, rec, hits, slot, dst, j0, nh, run_start, run_cnt, l, m.nb, compute);
+    nh = 0; run_cnt = 0;
+  };
   for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += PD_UNROLL) {
     int e[PD_UNROLL];
-    unsigned hm = 0u;
+    bool hit[PD_UNROLL];
 #pragma unroll
     for (int u = 0; u < PD_UNROLL; ++u) e[u] = (k0 + u < nlist) ? list[k0 + u] : 0;  // count field 0 => no lane is valid
 #pragma unroll
     for (int u = 0; u < PD_UNROLL; ++u) {
       int pt0 = e[u] & 0xffff, n = (e[u] >> 16) & 0xff, pb = (e[u] >> 24) & 0x3f;
+      hit[u] = false;
       if (l < n) {
         float4 P = T.pts[pt0 + l];
         float4 cb = cull[pb];
-        if (cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f) hm |= 1u << u;
+        hit[u] = cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f;
       }
     }
-    while (__ballot(hm != 0u) != 0ull) {
-      const bool has = hm != 0u;
-      int u = has ? __ffs(hm) - 1 : 0;
-      int eu = e[0];
 #pragma unroll
-      for (int v = 1; v < PD_UNROLL; ++v) eu = (u == v) ? e[v] : eu;
-      int slot = seg_slot(has, sm, nh);
-      if (has) hits[slot] = ((eu & 0xffff) + l) | (eu & 0x3f000000);
-      hm &= hm - 1u;
+    for (int u = 0; u < PD_UNROLL; ++u) {
+      const int before = nh;
+      int s = seg_slot(hit[u], sm, nh);
+      if (hit[u]) hits[s] = ((e[u] & 0xffff) + l) | (e[u] & 0x3f000000);
+      if (l == ((e[u] >> 24) & 0x3f) && nh > before) {
+        if (run_cnt == 0) run_start = before;
+        run_cnt += nh - before;
+      }
     }
-    if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) {  // rare: keep room for the next iteration
-      WAVE_SYNC();
-      sweep_flush<SEGW>(T, rec, hits, nh, l, on_hit);
-      WAVE_SYNC();
-    }
+    if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) flush_all();  // rare: keep room for the next iteration
   }
   STAMP(10);
-  WAVE_SYNC();
-  sweep_flush<SEGW>(T, rec, hits, nh, l, on_hit);
+  flush_all();
   STAMP(11);
 }
 
@@ -229,17 +267,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
   int *list = (int *)(pcon + nb * PD_W6), *hits = list + m.ntiles;
+  float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
 
   BodyConst c = load_body_const(m, b);
 #pragma unroll
   for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
-  auto contact_hit = [&](int pb, const float *r, float4 P, float4 mat) {
+  auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {  // body_f -= (t, f)   (:179)
     ContactOut o;
-    if (contact_point_fwd(r, P, mat, o)) {
-      float *f = facc + pb * PD_W6;
-      atomicAdd(f + 0, -o.t.x); atomicAdd(f + 1, -o.t.y); atomicAdd(f + 2, -o.t.z);
-      atomicAdd(f + 3, -o.f.x); atomicAdd(f + 4, -o.f.y); atomicAdd(f + 5, -o.f.z);
-    }
+    o.t = V3(0, 0, 0); o.f = V3(0, 0, 0);
+    contact_point_fwd(r, P, mat, o);
+    out[0] = -o.t.x; out[1] = -o.t.y; out[2] = -o.t.z; out[3] = -o.f.x; out[4] = -o.f.y; out[5] = -o.f.z;
   };
   if (SPLIT && contact_wave) {
     // ---- contact wave: eval_body_contacts for the partner body wave's envs, between barriers A and B of each step
@@ -249,7 +286,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       STAMP(7);
       float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
       if (is_body) cv = cull[b];
-      sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, contact_hit STAMP_PASS);
+      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, cv, rec, cull, list, hits, slot, facc, is_body, seg, l, contact_hit STAMP_PASS);
       STAMP(12);
       __syncthreads();  // B: contact wrenches are complete
     }
@@ -323,8 +360,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       __syncthreads();  // A: hand this step's records to the contact wave
     } else {
       WAVE_SYNC();
-      sweep_contacts<SEGW>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, is_body, seg, l,
-                           contact_hit STAMP_PASS);
+      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
+                                     is_body, seg, l, contact_hit STAMP_PASS);
     }
     const int fr = a.frame_of_step[step];
     STAMP(1);
@@ -408,19 +445,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
   int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.ntiles;
+  float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
 
   BodyConst c = load_body_const(m, b);
 #pragma unroll
   for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
-  auto contact_hit = [&](int pb, const float *r, float4 P, float4 mat) {
-    BodyAdj o;
-    if (contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o)) {
-      float *d = cacc + pb * PD_ADJ;
-      atomicAdd(d + 0, o.p.x); atomicAdd(d + 1, o.p.y); atomicAdd(d + 2, o.p.z);
-      atomicAdd(d + 3, o.r.x); atomicAdd(d + 4, o.r.y); atomicAdd(d + 5, o.r.z); atomicAdd(d + 6, o.r.w);
-      atomicAdd(d + 7, o.w.x); atomicAdd(d + 8, o.w.y); atomicAdd(d + 9, o.w.z);
-      atomicAdd(d + 10, o.v.x); atomicAdd(d + 11, o.v.y); atomicAdd(d + 12, o.v.z);
-    }
+  auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {
+    const int pb = (int)(r - rec) / PD_REC;
+    BodyAdj o = adj_zero();
+    contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    adj_store(out, o);
   };
   if (SPLIT && contact_wave) {
     // ---- contact wave: adjoint of eval_body_contacts for the partner body wave's envs, between barriers A and B
@@ -430,7 +464,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       STAMP(7);
       float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
       if (is_body) cv = cull[b];
-      sweep_contacts<SEGW>(m, tabs, c, cv, rec, cull, list, hits, is_body, seg, l, contact_hit STAMP_PASS);
+      sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, seg, l, contact_hit STAMP_PASS);
       STAMP(12);
       __syncthreads();  // B: contact adjoints are complete
     }
@@ -549,8 +583,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (SPLIT) {
       __syncthreads();  // B: contact adjoints are complete
     } else {
-      sweep_contacts<SEGW>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, is_body, seg, l,
-                           contact_hit STAMP_PASS);
+      sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot,
+                                           cacc, is_body, seg, l, contact_hit STAMP_PASS);
       WAVE_SYNC();
     }
     if (is_body) {
