@@ -76,6 +76,7 @@ struct BodyConst {
   float4 sphere;  // bounding sphere of this body's contact candidates
   int tile_first, tile_count;
   int small_e[4];  // this lane's entries of the small-body tile list (chunk u: entry u*SEGW + lane)
+  int child[4];    // first four children (-1 = none); the rest, if any, are walked from `children`
 };
 
 PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
@@ -86,6 +87,11 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
   c.p_pj = ld3(m.X_p + b * 7); c.q_pj = ld4(m.X_p + b * 7 + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
   c.sphere = m.body_sphere[b];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int cid = (int)((c.children >> (8 * k)) & 0xffull);
+    c.child[k] = cid == 0xff ? -1 : cid;
+  }
   c.tile_first = m.body_tiles[b].x; c.tile_count = m.body_tiles[b].y;
   return c;
 }

@@ -342,6 +342,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   if (a.nsteps > 0) load_controls(0);
   STAMP_DECL;
   for (int step = 0; step < a.nsteps; ++step) {
+    // barrier A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
+    // contact wave starts sweeping while this wave still unpacks controls and spills the state
+    if (SPLIT) {
+      __syncthreads();  // A: hand this step's records to the contact wave
+    }
+    STAMP(0);
     float tgt[ND], act[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
@@ -355,13 +361,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       td[0] = s.w.x; td[(size_t)N] = s.w.y; td[(size_t)2 * N] = s.w.z;
       td[(size_t)3 * N] = s.v.x; td[(size_t)4 * N] = s.v.y; td[(size_t)5 * N] = s.v.z;
     }
-    STAMP(0);
-    if (SPLIT) {
-      __syncthreads();  // A: hand this step's records to the contact wave
-    } else {
+    if (!SPLIT) {
       WAVE_SYNC();
       sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
-                                     is_body, seg, l, contact_hit STAMP_PASS);
+                                           is_body, seg, l, contact_hit STAMP_PASS);
     }
     const int fr = a.frame_of_step[step];
     STAMP(1);
@@ -375,7 +378,19 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     STAMP(2);
     WAVE_SYNC();
     v3 jt = -wc_t, jf = -wc_f;  // joint wrench on this body: own joint first, then children in index order
-    for (int k = 0; k < m.max_children; ++k) {
+    {  // first four children: all LDS reads are issued back to back (one exposed latency instead of one per child)
+      float cw[4][6];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float *pc = pcon + (c.child[k] >= 0 ? c.child[k] : 0) * PD_W6;
+        const bool on = is_body && c.child[k] >= 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cw[k][i] = on ? pc[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { jt += V3(cw[k][0], cw[k][1], cw[k][2]); jf += V3(cw[k][3], cw[k][4], cw[k][5]); }
+    }
+    for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
       if (is_body && cid != 0xff) {
         const float *pc = pcon + cid * PD_W6;
@@ -575,7 +590,19 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     }
     STAMP(2);
     WAVE_SYNC();
-    for (int k = 0; k < m.max_children; ++k) {
+    {  // first four children with all LDS reads in flight together, then any further ones
+      float cw[4][PD_ADJ];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float *pc = cslot + (c.child[k] >= 0 ? c.child[k] : 0) * PD_ADJ;
+        const bool on = is_body && c.child[k] >= 0;
+#pragma unroll
+        for (int i = 0; i < PD_ADJ; ++i) cw[k][i] = on ? pc[i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) adj_add_from(ga, cw[k]);
+    }
+    for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
       if (is_body && cid != 0xff) adj_add_from(ga, cslot + cid * PD_ADJ);
     }

@@ -39,7 +39,7 @@ fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints
       (3, "wait at barrier B + facc + traj_f/frame stores"), (4, "integrate"), (5, "stage record")]
 bn = [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"), (2, "wait A + joints adj + stores"),
       (3, "child gather"), (4, "wait B + cacc gather")]
-cn = [(7, "wait at barrier A (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
+cn = [(7, "wait at barrier A/A1 (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
 for lab, arr in (("FWD", f_all), ("BWD", b_all)):
     for who, names, contact in (("body wave", fn if lab == "FWD" else bn, False), ("contact wave", cn, True)):
         r = rows(arr, contact)
