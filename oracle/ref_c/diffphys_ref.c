@@ -109,6 +109,10 @@ static inline qt q_axis_angle(v3 axis, real ang) {
  * contribution is dropped (not inf) where sqrt(1-x^2) is not > 0.  POLICY, see DESIGN.md section 6. */
 static inline real inv_sqrt_1mx2(real x) { real d = R_SQRT((real)1 - x * x); return d > (real)0 ? (real)1 / d : (real)0; }
 static inline real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* Warp's acos/asin builtins clamp their argument to [-1, 1] (recall): a unit-quaternion w that rounds to 1.0000001f
+ * must not turn into NaN.  Same POLICY note as the adjoint guard above. */
+static inline real acos_c(real x) { return R_ACOS(clampr(x, (real)-1, (real)1)); }
+static inline real asin_c(real x) { return R_ASIN(clampr(x, (real)-1, (real)1)); }
 static inline real clamp_pass(real x, real lo, real hi) { return (x < lo || x > hi) ? (real)0 : (real)1; }
 
 /* adjoints (accumulate into adj_* like Warp's generated code) */
@@ -459,7 +463,7 @@ static void joint_force_adj(real q, real qd, real target, real ke, real kd, real
 
 static void quat_decompose(qt q, real *ang) {
   v3 c0 = qrot(q, V(1, 0, 0)), c1 = qrot(q, V(0, 1, 0)), c2 = qrot(q, V(0, 0, 1));
-  ang[0] = -R_ATAN2(c2.y, c2.z); ang[1] = -R_ASIN(-c2.x); ang[2] = -R_ATAN2(c1.x, c0.x);
+  ang[0] = -R_ATAN2(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -R_ATAN2(c1.x, c0.x);
 }
 static void quat_decompose_adj(qt q, const real *g, qt *adj_q) {
   v3 ex = V(1, 0, 0), ey = V(0, 1, 0), ez = V(0, 0, 1);
@@ -510,7 +514,7 @@ static void joints_fwd(const RefTemplate *t, const real *body_q, const real *bod
     int qds = t->qd_start[i];
     v3 t_total = V(0, 0, 0), f_total = V(0, 0, 0);
     if (c.ty == JOINT_FIXED) {
-      v3 ang_err = vscale(vnormalize(qv(c.r_err)), R_ACOS(c.r_err.w) * (real)2);
+      v3 ang_err = vscale(vnormalize(qv(c.r_err)), acos_c(c.r_err.w) * (real)2);
       f_total = vadd(f_total, vadd(vscale(c.x_err, ake), vscale(c.v_err, akd)));
       t_total = vadd(t_total, vadd(vscale(qrot(c.q_p, ang_err), ake), vscale(c.w_err, akd * ads)));
     }
@@ -520,7 +524,7 @@ static void joints_fwd(const RefTemplate *t, const real *body_q, const real *bod
       v3 a = vscale(axis, vdot(qv(c.r_err), axis));
       qt twist = qnormalize(Q(a.x, a.y, a.z, c.r_err.w));
       real sgn = vdot(axis, qv(twist)) < (real)0 ? (real)-1 : (real)1;
-      real q = R_ACOS(twist.w) * (real)2 * sgn;
+      real q = acos_c(twist.w) * (real)2 * sgn;
       real qd = vdot(c.w_err, axis_p);
       real jf = joint_force(q, qd, target[qds], tke[qds], tkd[qds], act[qds], t->limit_lower[qds], t->limit_upper[qds],
                             t->limit_ke[qds], t->limit_kd[qds]);
@@ -586,7 +590,7 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
     v3 adj_x_err = V(0, 0, 0), adj_v_err = V(0, 0, 0), adj_w_err = V(0, 0, 0);
     qt adj_r_err = Q(0, 0, 0, 0), adj_q_p = Q(0, 0, 0, 0), adj_q_c = Q(0, 0, 0, 0);
     if (c.ty == JOINT_FIXED) {
-      v3 rv = qv(c.r_err); real ac = R_ACOS(c.r_err.w) * (real)2;
+      v3 rv = qv(c.r_err); real ac = acos_c(c.r_err.w) * (real)2;
       v3 nrm = vnormalize(rv); v3 ang_err = vscale(nrm, ac);
       vacc(&adj_x_err, vscale(adj_f, ake)); vacc(&adj_v_err, vscale(adj_f, akd));
       vacc(&adj_w_err, vscale(adj_t, akd * ads));
@@ -606,7 +610,7 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
       qt tq = Q(a.x, a.y, a.z, c.r_err.w);
       qt twist = qnormalize(tq);
       real sgn = vdot(axis, qv(twist)) < (real)0 ? (real)-1 : (real)1;
-      real q = R_ACOS(twist.w) * (real)2 * sgn;
+      real q = acos_c(twist.w) * (real)2 * sgn;
       real qd = vdot(c.w_err, axis_p);
       real jf = joint_force(q, qd, target[qds], tke[qds], tkd[qds], act[qds], t->limit_lower[qds], t->limit_upper[qds],
                             t->limit_ke[qds], t->limit_kd[qds]);

@@ -89,14 +89,15 @@ def dot(a, b):
 
 
 class _GuardedArc(torch.autograd.Function):
-    """acos / asin whose adjoint drops the contribution (instead of inf) where sqrt(1-x^2) is not > 0,
-    like Warp's builtin adjoints.  POLICY, see DESIGN.md section 6."""
+    """acos / asin with the argument clamped to [-1, 1] and an adjoint that drops the contribution (instead of
+    inf / NaN) where sqrt(1-x^2) is not > 0, like Warp's builtins.  POLICY, see DESIGN.md section 6."""
 
     @staticmethod
     def forward(ctx, x, is_acos):
         ctx.save_for_backward(x)
         ctx.is_acos = is_acos
-        return torch.acos(x) if is_acos else torch.asin(x)
+        xc = x.clamp(-1.0, 1.0)  # Warp's builtins clamp the argument (recall)
+        return torch.acos(xc) if is_acos else torch.asin(xc)
 
     @staticmethod
     def backward(ctx, g):

@@ -328,7 +328,7 @@ PD_DEV void joint_force_adj(float q, float qd, float target, float ke, float kd,
 
 PD_DEV void quat_decompose(qt q, float *ang) {  // :245-258
   v3 c0 = qrot(q, V3(1, 0, 0)), c1 = qrot(q, V3(0, 1, 0)), c2 = qrot(q, V3(0, 0, 1));
-  ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asinf(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
+  ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
 }
 PD_DEV void quat_decompose_adj(qt q, const float *g, qt &adj_q) {
   v3 ex = V3(1, 0, 0), ey = V3(0, 1, 0), ez = V3(0, 0, 1);
@@ -372,7 +372,7 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
   v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
   const int qds = c.qdstart;
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {  // :385-390
-    v3 ang_err = normalize(qvec(j.r_err)) * (acosf(j.r_err.w) * 2.0f);
+    v3 ang_err = normalize(qvec(j.r_err)) * (acos_c(j.r_err.w) * 2.0f);
     f_total += j.x_err * ake + j.v_err * akd;
     t_total += qrot(j.q_p, ang_err) * ake + j.w_err * (akd * ads);
   }
@@ -381,7 +381,7 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     v3 a = c.axis * dot(qvec(j.r_err), c.axis);
     qt twist = qnormalize(Q4(a.x, a.y, a.z, j.r_err.w));
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
-    float q = acosf(twist.w) * 2.0f * sgn;
+    float q = acos_c(twist.w) * 2.0f * sgn;
     float qd = dot(j.w_err, axis_p);
     float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], m.lim_lo[qds], m.lim_hi[qds], m.lim_ke[qds], m.lim_kd[qds]);
     t_total = axis_p * jf;
@@ -437,7 +437,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
   qt adj_r_err = Q4(0, 0, 0, 0), adj_q_p = Q4(0, 0, 0, 0), adj_q_c = Q4(0, 0, 0, 0);
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {
     v3 rv = qvec(j.r_err);
-    float ac = acosf(j.r_err.w) * 2.0f;
+    float ac = acos_c(j.r_err.w) * 2.0f;
     v3 nrm = normalize(rv), ang_err = nrm * ac;
     adj_x_err += adj_f * ake; adj_v_err += adj_f * akd; adj_w_err += adj_t * (akd * ads);
     v3 adj_ang_err = V3(0, 0, 0);
@@ -454,7 +454,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     qt tq = Q4(a.x, a.y, a.z, j.r_err.w);
     qt twist = qnormalize(tq);
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
-    float q = acosf(twist.w) * 2.0f * sgn;
+    float q = acos_c(twist.w) * 2.0f * sgn;
     float qd = dot(j.w_err, axis_p);
     float lo = m.lim_lo[qds], up = m.lim_hi[qds], lke = m.lim_ke[qds], lkd = m.lim_kd[qds];
     float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], lo, up, lke, lkd);

@@ -54,6 +54,10 @@ PD_DEV qt q_axis_angle(v3 axis, float ang) {
 // as Warp's builtin adjoints do.  POLICY, see DESIGN.md section 6.
 PD_DEV float inv_sqrt_1mx2(float x) { float d = sqrtf(1.0f - x * x); return d > 0.0f ? 1.0f / d : 0.0f; }
 PD_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// Warp's acos/asin builtins clamp their argument to [-1, 1] (recall): a unit-quaternion w that rounds to
+// 1.0000001f must not turn into NaN.  POLICY, see DESIGN.md section 6.
+PD_DEV float acos_c(float x) { return acosf(clampf(x, -1.0f, 1.0f)); }
+PD_DEV float asin_c(float x) { return asinf(clampf(x, -1.0f, 1.0f)); }
 PD_DEV float clamp_pass(float x, float lo, float hi) { return (x < lo || x > hi) ? 0.0f : 1.0f; }
 PD_DEV v3 clamp3(v3 a, float l) { return V3(clampf(a.x, -l, l), clampf(a.y, -l, l), clampf(a.z, -l, l)); }
 PD_DEV v3 clamp3_pass(v3 a, v3 g, float l) {

@@ -327,3 +327,56 @@ def test_phys_model_training_iterations(dev):
     assert q["sim_traj"].shape == (4, 13, 7) and q["grf"].shape == (4, 8 * 13, 6)
     model.save_checkpoint(0)
     assert os.path.exists("/tmp/pprdp_test_log/mi-pace-t/ckpt_phys_latest.pth")
+
+
+def test_generic_joint_kernel_on_toy_robot(dev, oracle_libs, tmp_path):
+    """A URDF mixing free + revolute + compound + fixed joints and box / sphere / mesh / capsule contacts goes through the
+    model compiler and the GENERIC kernel instantiation (all joint types), which none of the three shipped robots uses."""
+    from test_host import OBJ, URDF
+    from diffphys_amd import hip_backend, sim
+    from diffphys_amd.import_urdf import parse_urdf
+    from helpers import build_template
+    from oracle.ref_c import RefC
+
+    (tmp_path / "toy.urdf").write_text(URDF)
+    (tmp_path / "tet.obj").write_text(OBJ)
+    b = sim.ModelBuilder()
+    parse_urdf(str(tmp_path / "toy.urdf"), b, xform=sim.transform((0, 0.5, 0), sim.quat_identity()), floating=True, density=1000.0,
+               armature=0.01, stiffness=220.0, damping=2.0, shape_ke=1e4, shape_kd=10.0, shape_kf=1e2, shape_mu=0.7, limit_ke=50.0, limit_kd=1.0)
+    tpl = build_template(b, attach_ke=8000.0, attach_kd=200.0)
+    nb, nq, nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+    assert sorted(set(int(t) for t in tpl["joint_type"])) == [1, 3, 4, 5]
+    bs, T = 9, 30
+    rng = np.random.RandomState(0)
+    q = np.tile(tpl["joint_q"].astype(np.float64), (bs, 1))
+    q[:, 1] = 0.13 + rng.rand(bs) * 0.02                 # arm sphere and leg mesh are in the ground
+    yaw = rng.uniform(-0.3, 0.3, bs)
+    q[:, 3:7] = np.stack([np.sin(yaw / 2) * 0.1, np.sin(yaw / 2), 0 * yaw, np.cos(yaw / 2)], -1)
+    q[:, 3:7] /= np.linalg.norm(q[:, 3:7], axis=1, keepdims=True)
+    q[:, 7:] = rng.uniform(-0.4, 0.4, (bs, nq - 7))
+    q[:, 8] = 1.6 + rng.rand(bs) * 0.2                   # compound x-angle beyond its +1.5 limit: limit force path
+    mass = np.tile(tpl["body_mass"].astype(np.float64), bs)
+    inertia = np.tile(tpl["body_inertia"].astype(np.float64), (bs, 1, 1))
+    ke = np.tile(np.r_[np.zeros(6), np.full(nqd - 6, 60.0)], bs)
+    inp = dict(q_init=q.reshape(-1), qd_init=rng.randn(bs * nqd) * 0.2, torques=rng.randn(T, bs * nqd) * 0.3,
+               res_f=rng.randn(T, bs * nb, 6) * 0.3, refs=rng.uniform(-0.3, 0.3, (T, bs * nqd)), target_ke=ke, target_kd=ke * 0.02,
+               body_mass=mass, body_inv_mass=1 / mass, body_inertia=inertia, body_inv_inertia=np.linalg.inv(inertia),
+               adj_pos=rng.randn(3, bs * nb, 7) * 1e-3, adj_vel=rng.randn(3, bs * nb, 6) * 1e-3)
+    inp = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inp.items()}
+    inp.update(frame2step=[0, 14, 29], nsteps=T, dt=5e-4)
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert np.abs(st["grf"]).max() > 5.0 and np.abs(st["jaf"]).max() > 1.0
+    # looser bars than the robots': a FIXED joint's angular error is normalize(tiny) * acos(w ~ 1), which is round-off
+    # dominated in fp32 (the fp32 and fp64 C oracles themselves differ by 3e-3 / 1.4e-2 / 1.2e-2 here)
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-4 and relmax(out["wp_vel"], st["wp_vel"]) < 1e-2
+    assert relmax(out["grf"], st["grf"]) < 2e-2 and relmax(out["jaf"], st["jaf"]) < 0.15  # jaf: FIXED-joint round-off, ~8 N m of 122
+    assert all(np.isfinite(v).all() for v in out["grads"].values())
+    # per-env medians: at its operating point (zero rotation error, w = 1 - O(ulp)) the FIXED joint's acos adjoint is
+    # 1/sqrt(1 - w^2) ~ 3e3 times round-off, so single envs can legitimately disagree wildly in fp32
+    for k in ("q_init", "qd_init", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia"):
+        g, r = out["grads"][k].reshape(bs, -1).astype(np.float64), gr[k].reshape(bs, -1).astype(np.float64)
+        per_env = np.abs(g - r).max(1) / (np.abs(r).max(1) + 1e-12)
+        assert np.median(per_env) < 5e-2, (k, per_env)
