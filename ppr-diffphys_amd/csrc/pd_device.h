@@ -36,6 +36,7 @@ struct PdDevModel {
   const int *small_tiles;                                 // [4*64] flat list (tile | body << 16) of the tiles of small bodies, -1 padded
   unsigned long long big_bodies;                          // bodies whose tiles are NOT in small_tiles
   int nmat, n_small;
+  int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
 };
@@ -98,10 +99,12 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
 
 // Returns the cull vector (p_y, Ry): Ry = second row of R(q), so the world height of a body-frame point x is
 // p_y + Ry . x.  It is also stored 16-byte aligned in cull[b] so the sweeps fetch it with one ds_read_b128.
-PD_DEV float4 stage_record(float *rec, float4 *cull, int b, const BodyState &s, v3 com) {
+PD_DEV float4 stage_record(float *rec, float4 *cull, int b, const BodyState &s, v3 rc) {
   float *r = rec + b * PD_REC;
-  v3 rc = qrot(s.r, com);
-  v3 Ry = qrot_inv(s.r, V3(0.f, 1.f, 0.f));
+  // row 1 of the rotation matrix of a unit quaternion (9 flops instead of a full rotation); the cull tests that
+  // consume it carry explicit safety margins, the exact contact test does not use it
+  v3 Ry = V3(2.0f * (s.r.x * s.r.y + s.r.z * s.r.w), 1.0f - 2.0f * (s.r.x * s.r.x + s.r.z * s.r.z),
+             2.0f * (s.r.y * s.r.z - s.r.x * s.r.w));
   r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
   r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
   r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
@@ -309,6 +312,13 @@ PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g
 
 // ---------------------------------------------------------------------------------------------
 // Joint PD + attachment forces for joint i == child body i (integrator_euler.py:289-451).
+struct JointLimit { float lo, up, ke, kd; };
+PD_DEV JointLimit load_limit(const PdDevModel &m, int dof) {  // skipped entirely (uniform branch) when no joint has limit gains
+  JointLimit L;
+  L.lo = -1.0e30f; L.up = 1.0e30f; L.ke = 0.f; L.kd = 0.f;
+  if (m.has_limits) { L.lo = m.lim_lo[dof]; L.up = m.lim_hi[dof]; L.ke = m.lim_ke[dof]; L.kd = m.lim_kd[dof]; }
+  return L;
+}
 PD_DEV float joint_force(float q, float qd, float target, float ke, float kd, float act, float lo, float up, float lke,
                          float lkd) {
   float limit_f = 0.0f;  // :274-281
@@ -346,7 +356,7 @@ struct JointCtx {  // locals shared by the forward and the adjoint
   qt qp, q_p, r_err;
 };
 
-PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, const float *rec, JointCtx &j) {
+PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, JointCtx &j) {
   j.pp = V3(0, 0, 0); j.qp = Q4(0, 0, 0, 1); j.x_p = c.p_pj; j.q_p = c.q_pj;
   j.r_p = V3(0, 0, 0); j.w_p = V3(0, 0, 0); j.v_p = V3(0, 0, 0);
   if (c.parent >= 0) {  // :326-333
@@ -356,7 +366,7 @@ PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, const float *rec, 
     j.q_p = qmul(j.qp, c.q_pj);
     j.r_p = j.x_p - (j.pp + ld3(r + 13));
   }
-  j.r_c = s.p - (s.p + qrot(s.r, c.com));  // :338
+  j.r_c = s.p - (s.p + rc_c);  // :338, rc_c = rot(q_c, com) from the staging
   j.x_err = s.p - j.x_p; j.r_err = qmul(qconj(j.q_p), s.r);  // :369-372
   j.v_err = s.v - j.v_p; j.w_err = s.w - j.w_p;
 }
@@ -364,10 +374,10 @@ PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, const float *rec, 
 // tgt/act/ke/kd: this joint's dofs (1 for revolute, 3 for compound).  Outputs the wrench pair:
 // parent += (t + r_p x f, f), child -= (t + r_c x f, f)   (:448-451)
 template <int JT>
-PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *rec, const float *tgt,
+PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
                       const float *act, const float *ke, const float *kd, v3 &wp_t, v3 &wp_f, v3 &wc_t, v3 &wc_f) {
   JointCtx j;
-  joint_ctx(c, s, rec, j);
+  joint_ctx(c, s, rc_c, rec, j);
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
   const int qds = c.qdstart;
@@ -383,7 +393,8 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
     float q = acos_c(twist.w) * 2.0f * sgn;
     float qd = dot(j.w_err, axis_p);
-    float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], m.lim_lo[qds], m.lim_hi[qds], m.lim_ke[qds], m.lim_kd[qds]);
+    const JointLimit L = load_limit(m, qds);
+    float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], L.lo, L.up, L.ke, L.kd);
     t_total = axis_p * jf;
     v3 swing = cross(axis_p, axis_c);
     f_total += j.x_err * ake + j.v_err * akd;
@@ -404,8 +415,8 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       v3 axw = qrot(q_w, ax[k]);
-      float jf = joint_force(ang[k], dot(axw, j.w_err), tgt[k], ke[k], kd[k], act[k], m.lim_lo[qds + k], m.lim_hi[qds + k],
-                             m.lim_ke[qds + k], m.lim_kd[qds + k]);
+      const JointLimit L = load_limit(m, qds + k);
+      float jf = joint_force(ang[k], dot(axw, j.w_err), tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
       t_total += axw * jf;
     }
     t_total = clamp3(t_total, 1.0e4f);
@@ -418,11 +429,11 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
 // Adjoint.  gc_* = adjoint of the child's wrench accumulator, gp_* = of the parent's (zero if none).
 // own += d/d(child state); par = d/d(parent state); a_* = per-dof gradients (overwritten).
 template <int JT>
-PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *rec, const float *tgt,
+PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
                       const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
                       BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
   JointCtx j;
-  joint_ctx(c, s, rec, j);
+  joint_ctx(c, s, rc_c, rec, j);
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   const int qds = c.qdstart;
   v3 f_raw = j.x_err * ake + j.v_err * akd;
@@ -456,7 +467,8 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
     float q = acos_c(twist.w) * 2.0f * sgn;
     float qd = dot(j.w_err, axis_p);
-    float lo = m.lim_lo[qds], up = m.lim_hi[qds], lke = m.lim_ke[qds], lkd = m.lim_kd[qds];
+    const JointLimit L = load_limit(m, qds);
+    float lo = L.lo, up = L.up, lke = L.ke, lkd = L.kd;
     float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], lo, up, lke, lkd);
     adj_x_err += adj_f * ake; adj_v_err += adj_f * akd;
     float adj_jf = dot(adj_t, axis_p);
@@ -495,8 +507,8 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       axw[k] = qrot(q_w, ax[k]); qdk[k] = dot(axw[k], j.w_err);
-      jf[k] = joint_force(ang[k], qdk[k], tgt[k], ke[k], kd[k], act[k], m.lim_lo[qds + k], m.lim_hi[qds + k],
-                          m.lim_ke[qds + k], m.lim_kd[qds + k]);
+      const JointLimit L = load_limit(m, qds + k);
+      jf[k] = joint_force(ang[k], qdk[k], tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
       t_raw += axw[k] * jf[k];
     }
     v3 adj_f_raw = clamp3_pass(f_raw, adj_f, 1.0e4f);
@@ -511,8 +523,9 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
       v3 adj_axw = adj_t_raw * jf[k];
       float adj_qdk = 0.f;
       a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f;
-      joint_force_adj(ang[k], qdk[k], tgt[k], ke[k], kd[k], m.lim_lo[qds + k], m.lim_hi[qds + k], m.lim_ke[qds + k],
-                      m.lim_kd[qds + k], adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k], a_kd[k], a_act[k]);
+      const JointLimit L = load_limit(m, qds + k);
+      joint_force_adj(ang[k], qdk[k], tgt[k], ke[k], kd[k], L.lo, L.up, L.ke, L.kd, adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k],
+                      a_kd[k], a_act[k]);
       adj_axw += j.w_err * adj_qdk; adj_w_err += axw[k] * adj_qdk;
       adj_qrot(q_w, ax[k], adj_q_w, adj_ax[k], adj_axw);
     }
@@ -536,7 +549,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     adj_qmul(qconj(j.q_p), s.r, adj_cqp, adj_q_c, adj_r_err);
     adj_q_p += qconj(adj_cqp);
   }
-  adj_qrot_q(s.r, c.com, adj_q_c, -adj_r_c);  // r_c = x_c - (x_c + rot(q_c, com))
+  adj_qrot_q(s.r, c.com, adj_q_c, -adj_r_c);  // r_c = x_c - (x_c + rot(q_c, com)); rc_c is a function of q_c
   own.p += adj_x_err; own.r += adj_q_c; own.w += adj_w_err; own.v += adj_v_err;
   par = adj_zero();
   if (c.parent >= 0) {
@@ -551,11 +564,12 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
 
 // ---------------------------------------------------------------------------------------------
 // integrate_bodies (integrator_euler.py:21-91) for one body.
-PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m,
-                               const float *I, const float *invI, float dt) {
+// rc = rot(q, com) of the input state (from the staging); rc_out = the same for the returned state.
+PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc, v3 t0, v3 f0, float inv_m,
+                               const float *I, const float *invI, float dt, v3 &rc_out) {
   v3 g = V3(m.gx, m.gy, m.gz);
   float nz = inv_m != 0.0f ? 1.0f : 0.0f;
-  v3 x_com = s.p + qrot(s.r, c.com);                            // :61
+  v3 x_com = s.p + rc;                                          // :61
   v3 v1 = s.v + (f0 * inv_m + g * nz) * dt;                     // :64
   v3 x1 = x_com + v1 * dt;                                      // :65
   v3 wb = qrot_inv(s.r, s.w);                                   // :68
@@ -565,7 +579,8 @@ PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const Bo
   w1 = w1 * (1.0f - 0.1f * dt);                                 // :75
   BodyState o;
   o.w = clamp3(w1, 10.0f); o.v = clamp3(v1, 10.0f);             // :78-88
-  o.r = r1; o.p = x1 - qrot(r1, c.com);                         // :90
+  rc_out = qrot(r1, c.com);
+  o.r = r1; o.p = x1 - rc_out;                                  // :90
   return o;
 }
 

@@ -192,6 +192,8 @@ static int build_device(pd_model *m, int segw) {
   d.body_sphere = (const float4 *)(base + o_bs); d.tile_sphere = (const float4 *)(base + o_ts);
   d.tile_pack = (const int *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
   d.small_tiles = (const int *)(base + o_st); d.big_bodies = big_bodies; d.n_small = n_small;
+  d.has_limits = 0;
+  for (int i = 0; i < m->nqd; ++i) if (m->lim_ke[i] != 0.f || m->lim_kd[i] != 0.f) d.has_limits = 1;
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
   // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)

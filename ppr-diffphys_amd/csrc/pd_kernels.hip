@@ -314,10 +314,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
+  v3 rc = V3(0, 0, 0);  // rot(q, com) of the current state, shared by staging, joints and integration
   for (int d = 0; d <= m.max_depth; ++d) {
     if (is_body && c.depth == d) {
       s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
-      stage_record(rec, cull, b, s, c.com);
+      rc = qrot(s.r, c.com);
+      stage_record(rec, cull, b, s, rc);
     }
     WAVE_SYNC();
   }
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     STAMP(1);
     // ---- eval_body_joints (runs while the contact wave sweeps)
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
-    if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT>(m, c, s, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
+    if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT>(m, c, s, rc, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
     if (is_body) {
       float *pc = pcon + b * PD_W6;
       pc[0] = wp_t.x; pc[1] = wp_t.y; pc[2] = wp_t.z; pc[3] = wp_f.x; pc[4] = wp_f.y; pc[5] = wp_f.z;
@@ -430,10 +432,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     STAMP(3);
     // ---- integrate_bodies
-    s = integrate_fwd(m, c, s, ft, ff, inv_m, I, invI, a.dt);
+    s = integrate_fwd(m, c, s, rc, ft, ff, inv_m, I, invI, a.dt, rc);
     STAMP(4);
     WAVE_SYNC();
-    if (is_body) stage_record(rec, cull, b, s, c.com);
+    if (is_body) stage_record(rec, cull, b, s, rc);
     if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
     const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
     load_step(step - 1);
-    if (is_body) stage_record(rec, cull, b, s, c.com);
+    const v3 rc = qrot(s.r, c.com);
+    if (is_body) stage_record(rec, cull, b, s, rc);
     STAMP(0);
     // ---- adjoint of integrate_bodies
     BodyAdj ga = adj_zero();
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (is_body && c.type != PD_JOINT_FREE) {
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
       if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-      joint_adj<JT>(m, c, s, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
+      joint_adj<JT>(m, c, s, rc, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
     }
     if (is_body) {
       adj_store(cslot + b * PD_ADJ, par);
