@@ -137,6 +137,10 @@ class DeviceModel:
         if frame_of_step.dtype != torch.int32 or not frame_of_step.is_cuda or frame_of_step.numel() != nsteps + 1:
             raise ValueError("frame_of_step must be an int32 GPU tensor of nsteps+1 entries")
         ws = torch.empty(self.workspace_floats(bs, nsteps), dtype=torch.float32, device=dev)
+        if bs == 0 or nframes == 0:  # empty batch / no output frames: nothing to launch (data_ptr() of an empty tensor is null)
+            z = lambda n: torch.zeros(nframes, bs * nb, n, dtype=torch.float32, device=dev)
+            if bs == 0:
+                return z(7), z(6), (z(6) if want_forces else None), (z(6) if want_forces else None), ws
         wp_pos = torch.empty(nframes, bs * nb, 7, dtype=torch.float32, device=dev)
         wp_vel = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev)
         grf = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev) if want_forces else None
@@ -160,6 +164,8 @@ class DeviceModel:
         g = dict(q_init=e(bs * nq), qd_init=e(bs * nqd), torques=e(nsteps, bs * nqd), res_f=e(nsteps, bs * nb, 6),
                  refs=e(nsteps, bs * nqd), target_ke=e(bs * nqd), target_kd=e(bs * nqd), body_inv_mass=e(bs * nb),
                  body_inertia=e(bs * nb, 3, 3), body_inv_inertia=e(bs * nb, 3, 3))
+        if bs == 0:
+            return g
         _check(lib().pd_rollout_backward(
             self.h, bs, nsteps, float(dt), _dev(q_init, "q_init", bs * nq), _dev(qd_init, "qd_init", bs * nqd),
             _dev(torques, "torques", nsteps * bs * nqd), _dev(refs, "refs", nsteps * bs * nqd),
@@ -179,6 +185,8 @@ class DeviceModel:
         dev = joint_q.device
         body_q = torch.empty(n, self.nb, 7, dtype=torch.float32, device=dev)
         body_qd = torch.empty(n, self.nb, 6, dtype=torch.float32, device=dev)
+        if n == 0:
+            return body_q, body_qd
         _check(lib().pd_fk_forward(self.h, n, _dev(joint_q, "joint_q", n * self.nq), _dev(joint_qd, "joint_qd", n * self.nqd),
                                    _dev(body_q, "body_q"), _dev(body_qd, "body_qd"), _stream()))
         return body_q, body_qd
@@ -188,6 +196,8 @@ class DeviceModel:
         dev = joint_q.device
         gq = torch.empty(n, self.nq, dtype=torch.float32, device=dev)
         gqd = torch.empty(n, self.nqd, dtype=torch.float32, device=dev)
+        if n == 0:
+            return gq, gqd
         _check(lib().pd_fk_backward(self.h, n, _dev(joint_q, "joint_q", n * self.nq), _dev(joint_qd, "joint_qd", n * self.nqd),
                                     _dev(adj_body_q, "adj_body_q", n * self.nb * 7),
                                     _dev(adj_body_qd, "adj_body_qd", n * self.nb * 6), _dev(gq, "g"), _dev(gqd, "g"), _stream()))

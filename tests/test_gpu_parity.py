@@ -319,7 +319,7 @@ def test_phys_model_training_iterations(dev):
         out = model.forward(frame_start=fs)
         model.backward(out["total_loss"])
         gd = model.update()
-        losses.append(float(out["total_loss"]))
+        losses.append(float(out["total_loss"].detach()))
         assert np.isfinite(losses[-1])
     assert len(gd) > 0 and all(torch.isfinite(v) for v in gd.values())
     assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
@@ -380,3 +380,45 @@ def test_generic_joint_kernel_on_toy_robot(dev, oracle_libs, tmp_path):
         g, r = out["grads"][k].reshape(bs, -1).astype(np.float64), gr[k].reshape(bs, -1).astype(np.float64)
         per_env = np.abs(g - r).max(1) / (np.abs(r).max(1) + 1e-12)
         assert np.median(per_env) < 5e-2, (k, per_env)
+
+
+def test_empty_batch_and_graph_capture(dev):
+    """Empty inputs return empty outputs; and the launch path neither allocates through HIP nor synchronises, so a
+    forward + adjoint pair can be captured into a HIP graph (torch.cuda.graphs) and replayed with identical results."""
+    from diffphys_amd import dp_model, hip_backend, robots, synth
+
+    tpl = robots.load_template("laikago")
+    dm = hip_backend.DeviceModel(tpl)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    fos = dp_model.frame_of_step_tensor(5, [0, 4], dev)
+    pos, vel, grf, jaf, ws = dm.rollout_forward(0, 5, 5e-4, z(0), z(0), z(5, 0), z(5, 0, 6), z(5, 0), z(0), z(0), z(0), z(0, 3, 3), z(0, 3, 3),
+                                                frame_of_step=fos, nframes=2)
+    assert pos.shape == (2, 0, 7) and vel.shape == (2, 0, 6) and ws.numel() == 0
+    bq, bqd = dm.fk_forward(z(0, 19), z(0, 18))
+    assert bq.shape == (0, 13, 7)
+
+    bs, T = 64, 34
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=1, penetration=0.002)
+    t = {k: torch.from_numpy(inp[k]).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
+    fos = dp_model.frame_of_step_tensor(T, inp["frame2step"], dev)
+    F = len(inp["frame2step"])
+
+    def run():
+        o = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame_of_step=fos, nframes=F)
+        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, F, o[4], t["adj_pos"], t["adj_vel"])
+        return o[0], g["q_init"]
+
+    ref_pos, ref_g = run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()  # warm-up on the capture stream
+        with torch.cuda.graph(graph, stream=side):
+            cap_pos, cap_g = run()
+    torch.cuda.current_stream().wait_stream(side)
+    cap_pos.zero_(); cap_g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cap_pos, ref_pos) and torch.equal(cap_g, ref_g)
