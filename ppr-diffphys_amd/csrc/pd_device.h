@@ -30,7 +30,7 @@ struct PdDevModel {
   const unsigned char *pt_mat;                            // [nc padded to 16] material index of each point
   const float4 *materials;                                // [nmat] (ke,kd,kf,mu)
   const float4 *body_sphere;                              // [nb] bounding sphere of the body's points (w < 0: none)
-  const float4 *tile_sphere;                              // [ntiles] bounding sphere (centre, radius + max dist)
+  const float4 *tile_lo, *tile_hi;                        // [ntiles] body-frame AABB: (lo.xyz, max dist), (hi.xyz, safety margin)
   const int *tile_pack;                                   // [ntiles] first point | count << 16 | body << 24
   const int2 *body_tiles;                                 // [nb] (first tile, tile count)
   const int *small_tiles;                                 // [4*64] flat list (tile | body << 16) of the tiles of small bodies, -1 padded

@@ -70,6 +70,18 @@ static float4 bound_sphere(const std::vector<int> &ids, const float *pts, const 
   return make_float4(c[0], c[1], c[2], r * 1.0001f + std::max(dmax, 0.0f) + 1e-6f);
 }
 
+// body-frame AABB of a point set: lo = (min xyz, max dist), hi = (max xyz, safety margin of the cull test)
+static void bound_box(const std::vector<int> &ids, const float *pts, const float *dist, float4 &lo, float4 &hi) {
+  float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f}, dmax = 0.f, ext = 0.f;
+  for (int i : ids) {
+    for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], pts[i * 3 + k]); mx[k] = std::max(mx[k], pts[i * 3 + k]); }
+    dmax = std::max(dmax, dist[i]);
+  }
+  for (int k = 0; k < 3; ++k) ext = std::max(ext, std::max(std::fabs(mn[k]), std::fabs(mx[k])));
+  lo = make_float4(mn[0], mn[1], mn[2], dmax);
+  hi = make_float4(mx[0], mx[1], mx[2], 1e-4f * (1.0f + ext + dmax));
+}
+
 static void free_device(pd_model *m) {
   if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
 }
@@ -114,7 +126,7 @@ static int build_device(pd_model *m, int segw) {
   }
   if (jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
   // ---- contact table: grouped by body, kd-ordered inside a body, cut into tiles of <= segw points
-  std::vector<float4> pts, tile_sphere, mats;
+  std::vector<float4> pts, tile_lo, tile_hi, mats;
   std::vector<unsigned char> pt_mat;
   std::vector<int> tile_pack;
   std::vector<int2> body_tiles(nb, make_int2(0, 0));
@@ -128,7 +140,9 @@ static int build_device(pd_model *m, int segw) {
     kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), segw);
     for (size_t t0 = 0; t0 < ids.size(); t0 += segw) {
       std::vector<int> tid(ids.begin() + t0, ids.begin() + std::min(ids.size(), t0 + segw));
-      tile_sphere.push_back(bound_sphere(tid, m->cpoint.data(), m->cdist.data()));
+      float4 blo, bhi;
+      bound_box(tid, m->cpoint.data(), m->cdist.data(), blo, bhi);
+      tile_lo.push_back(blo); tile_hi.push_back(bhi);
       tile_pack.push_back((int)pts.size() | ((int)tid.size() << 16) | (b << 24));
       body_tiles[b].y++;
       for (int k : tid) {
@@ -161,7 +175,7 @@ static int build_device(pd_model *m, int segw) {
   if (mats.empty()) mats.push_back(make_float4(0, 0, 0, 0));
   if (pts.empty()) pts.push_back(make_float4(0, 0, 0, 0));
   pt_mat.resize(((std::max(nc, 1) + 15) / 16) * 16, 0);
-  if (tile_pack.empty()) { tile_pack.push_back(0); tile_sphere.push_back(make_float4(0, 0, 0, -1.0f)); }
+  if (tile_pack.empty()) { tile_pack.push_back(0); tile_lo.push_back(make_float4(0, 0, 0, 0)); tile_hi.push_back(make_float4(0, 0, 0, 0)); }
 
   // ---- upload
   std::vector<unsigned char> buf;
@@ -170,7 +184,7 @@ static int build_device(pd_model *m, int segw) {
   size_t o_Xp = put(buf, m->X_p), o_Xc = put(buf, m->X_c), o_axis = put(buf, m->axis), o_com = put(buf, m->com);
   size_t o_lo = put(buf, m->lim_lo), o_hi = put(buf, m->lim_hi), o_lke = put(buf, m->lim_ke), o_lkd = put(buf, m->lim_kd);
   size_t o_pts = put(buf, pts), o_ptm = put(buf, pt_mat), o_mats = put(buf, mats);
-  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_sphere), o_ti = put(buf, tile_pack), o_bt = put(buf, body_tiles), o_st = put(buf, small_tiles);
+  size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_lo), o_th = put(buf, tile_hi), o_ti = put(buf, tile_pack), o_bt = put(buf, body_tiles), o_st = put(buf, small_tiles);
   free_device(m);
   hipError_t e = hipMalloc(&m->blob, buf.size());
   if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
@@ -189,7 +203,7 @@ static int build_device(pd_model *m, int segw) {
   d.lim_ke = (const float *)(base + o_lke); d.lim_kd = (const float *)(base + o_lkd);
   d.pts = (const float4 *)(base + o_pts); d.pt_mat = base + o_ptm; d.materials = (const float4 *)(base + o_mats);
   d.nmat = m->nmat;
-  d.body_sphere = (const float4 *)(base + o_bs); d.tile_sphere = (const float4 *)(base + o_ts);
+  d.body_sphere = (const float4 *)(base + o_bs); d.tile_lo = (const float4 *)(base + o_ts); d.tile_hi = (const float4 *)(base + o_th);
   d.tile_pack = (const int *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
   d.small_tiles = (const int *)(base + o_st); d.big_bodies = big_bodies; d.n_small = n_small;
   d.has_limits = 0;
@@ -199,7 +213,7 @@ static int build_device(pd_model *m, int segw) {
   // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
   d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
   const int envs_per_block = PD_BWAVES * (64 / segw);
-  m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 16 + (size_t)std::max(m->nmat, 1) * 16 +
+  m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
                    (size_t)envs_per_block * d.env_lds_floats * 4;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;

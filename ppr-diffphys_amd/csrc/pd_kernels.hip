@@ -62,7 +62,8 @@ PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
 // Ground-contact sweep for one segment (= one env).  Conservative three-level cull, then the exact
 // test of the reference inside on_hit.  All tables are in LDS (copied once per workgroup):
 //   L1  per body  : bounding sphere of all its candidate points vs y = 0               (lane = body)
-//   L2  per tile  : tile = <= SEGW spatially compact points of ONE body; sphere test    (lane = tile of a surviving body)
+//   L2  per tile  : tile = <= SEGW spatially compact points of ONE body; body-frame AABB support test (tighter than a
+//                   sphere for the elongated tiles of a limb, fewer tiles reach L3)       (lane = tile of a surviving body)
 //   L3  per point : y-row test  c = p_y + Ry . x - dist, PD_UNROLL tiles per iteration so that their LDS reads overlap;
 //                   survivors are compacted into a per-env hit list                      (lane = point)
 //   hit pass      : lanes = compacted hits (dense), on_hit(record, point, material) does the reference's arithmetic
@@ -71,7 +72,7 @@ PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
 #define PD_HIT_CAP_TILES 8   // hit-list capacity in units of SEGW (two L3 iterations)
 
 struct SweepTables {
-  const float4 *pts, *tsphere, *mats;
+  const float4 *pts, *tlo, *thi, *mats;
   const unsigned char *pmat;
   const int *tpack;
   const int2 *btiles;
@@ -80,6 +81,11 @@ struct SweepTables {
 PD_DEV bool cull_above(float4 cv, float4 sp) {  // true when the whole sphere is provably above y = 0
   float ylow = cv.x + (cv.y * sp.x + cv.z * sp.y + cv.w * sp.z) - sp.w;
   return ylow > 1e-4f * (1.0f + sp.w);
+}
+// Same for a body-frame box [lo, hi]: the lowest world height over the box is p_y + sum_i min(Ry_i lo_i, Ry_i hi_i).
+PD_DEV bool cull_above_box(float4 cv, float4 lo, float4 hi) {
+  float ylow = cv.x + fminf(cv.y * lo.x, cv.y * hi.x) + fminf(cv.z * lo.y, cv.z * hi.y) + fminf(cv.w * lo.z, cv.w * hi.z) - lo.w;
+  return ylow > hi.w;
 }
 
 // Hit pass for one batch [j0, j0 + SEGW) of the env's compacted hit list.  Lane j computes hit j0 + j (compute() does
@@ -152,7 +158,7 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
       int pk = 0;
       if (pass) {
         pk = T.tpack[e & 0xffff];
-        pass = !cull_above(cull[e >> 16], T.tsphere[e & 0xffff]);
+        pass = !cull_above_box(cull[e >> 16], T.tlo[e & 0xffff], T.thi[e & 0xffff]);
       }
       int s = seg_slot(pass, sm, nlist);
       if (pass) list[s] = pk;
@@ -175,7 +181,7 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
       int pk = 0;
       if (pass) {
         pk = T.tpack[t_first + t];
-        pass = !cull_above(cb, T.tsphere[t_first + t]);
+        pass = !cull_above_box(cb, T.tlo[t_first + t], T.thi[t_first + t]);
       }
       int s = seg_slot(pass, sm, nlist);
       if (pass) list[s] = pk;
@@ -230,18 +236,19 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
   const int nc4 = m.nc > 0 ? m.nc : 1, nt4 = m.ntiles > 0 ? m.ntiles : 1, nm4 = m.nmat > 0 ? m.nmat : 1;
   const int nbp = (m.nb + 1) & ~1, ncb = (nc4 + 15) & ~15, ntp = (nt4 + 3) & ~3;
   float4 *pts = (float4 *)smem;
-  float4 *tsp = pts + nc4;
-  float4 *mat = tsp + nt4;
+  float4 *tlo = pts + nc4;
+  float4 *thi = tlo + nt4;
+  float4 *mat = thi + nt4;
   int *tpk = (int *)(mat + nm4);
   int2 *btl = (int2 *)(tpk + ntp);
   unsigned char *pmt = (unsigned char *)(btl + nbp);
   for (int i = threadIdx.x; i < m.nc; i += NT) pts[i] = m.pts[i];
-  for (int i = threadIdx.x; i < m.ntiles; i += NT) { tsp[i] = m.tile_sphere[i]; tpk[i] = m.tile_pack[i]; }
+  for (int i = threadIdx.x; i < m.ntiles; i += NT) { tlo[i] = m.tile_lo[i]; thi[i] = m.tile_hi[i]; tpk[i] = m.tile_pack[i]; }
   for (int i = threadIdx.x; i < m.nmat; i += NT) mat[i] = m.materials[i];
   for (int i = threadIdx.x; i < m.nb; i += NT) btl[i] = m.body_tiles[i];
   for (int i = threadIdx.x; i < ncb / 4; i += NT) ((unsigned int *)pmt)[i] = ((const unsigned int *)m.pt_mat)[i];
   __syncthreads();
-  T.pts = pts; T.tsphere = tsp; T.mats = mat; T.tpack = tpk; T.btiles = btl; T.pmat = pmt;
+  T.pts = pts; T.tlo = tlo; T.thi = thi; T.mats = mat; T.tpack = tpk; T.btiles = btl; T.pmat = pmt;
   return (float *)(pmt + ncb) + (size_t)env_slot * m.env_lds_floats;  // env_lds_floats is a multiple of 4: 16-B aligned
 }
 
