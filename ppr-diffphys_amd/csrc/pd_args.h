@@ -9,6 +9,10 @@
 #define PD_BLOCK (2 * PD_BWAVES * 64)
 #define PD_FK_BLOCK (PD_BWAVES * 64)
 
+// Forward sweeps log their hit list (count + up to PD_HITLOG-1 entries) so that the adjoint replays it instead of
+// repeating the three cull levels; count -1 = did not fit, the adjoint then culls again for that wave.
+#define PD_HITLOG 32
+
 enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
 
 struct RolloutArgs {
@@ -21,6 +25,7 @@ struct RolloutArgs {
   // backward only
   const float *adj_pos, *adj_vel;
   float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
+  int *hitlog;              // workspace tail: per (step, env) the compacted contact hit list of the forward sweep
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
 };
 

@@ -36,6 +36,7 @@ struct PdDevModel {
   const int *small_tiles;                                 // [4*64] flat list (tile | body << 16) of the tiles of small bodies, -1 padded
   unsigned long long big_bodies;                          // bodies whose tiles are NOT in small_tiles
   int nmat, n_small;
+  int list_cap;                                            // ints reserved for the tile list (>= ntiles and >= 2*nb)
   int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch

@@ -206,12 +206,13 @@ static int build_device(pd_model *m, int segw) {
   d.body_sphere = (const float4 *)(base + o_bs); d.tile_lo = (const float4 *)(base + o_ts); d.tile_hi = (const float4 *)(base + o_th);
   d.tile_pack = (const int *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
   d.small_tiles = (const int *)(base + o_st); d.big_bodies = big_bodies; d.n_small = n_small;
+  d.list_cap = std::max(ntiles, 2 * nb);
   d.has_limits = 0;
   for (int i = 0; i < m->nqd; ++i) if (m->lim_ke[i] != 0.f || m->lim_kd[i] != 0.f) d.has_limits = 1;
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
   // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
-  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + ntiles + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
+  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
   const int envs_per_block = PD_BWAVES * (64 / segw);
   m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
@@ -296,7 +297,7 @@ int pd_model_set_segment_width(pd_model *m, int lanes) {
 int pd_model_get_segment_width(const pd_model *m) { return m ? m->segw : 0; }
 
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
-  return m ? (size_t)nsteps * 19 * (size_t)bs * m->nb : 0;
+  return m ? (size_t)nsteps * 19 * (size_t)bs * m->nb + (size_t)nsteps * (size_t)bs * PD_HITLOG : 0;  // + hit log (ints)
 }
 
 int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
@@ -314,6 +315,7 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.res_f = res_f; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = frame_of_step; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
+  a.hitlog = (int *)(ws + (size_t)nsteps * 19 * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, m->lds_rollout, st);
@@ -342,6 +344,7 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.frame_of_step = frame_of_step; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
+  a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * 19 * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout, st);

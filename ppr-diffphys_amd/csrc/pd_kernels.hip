@@ -137,15 +137,45 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
 
 // cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
 // dst: per-body accumulators [nb][DSTRIDE] (zeroed by their owner before the sweep); slot: SEGW*NV floats of scratch.
+// log != nullptr, replay_cnt == PD_NO_REPLAY : forward sweep, the final hit list is written to log (this env, this step)
+// replay_cnt >= 0                            : adjoint sweep, the first replay_cnt entries of log ARE the hit list
+#define PD_NO_REPLAY (-2)
 template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
-                           const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, int seg, int l,
-                           F &&compute STAMP_ARGS) {
-  if (m.nc == 0) return;
+                           const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, bool env_ok, int seg,
+                           int l, int *log, int replay_cnt, F &&compute STAMP_ARGS) {
+  if (replay_cnt >= 0) {  // wave-uniform: every env of this wave has a usable log entry
+    const int nh_r = replay_cnt;
+    for (int j = l; j < nh_r; j += SEGW) hits[j] = log[1 + j];
+    int *rs = list, *re = list + m.nb;  // run bounds per body (the tile list is not used in a replay)
+    if (l < m.nb) { rs[l] = 0; re[l] = 0; }
+    WAVE_SYNC();
+    for (int j = l; j < nh_r; j += SEGW) {
+      const int pb = (hits[j] >> 24) & 0x3f;
+      const int prev = j > 0 ? (hits[j - 1] >> 24) & 0x3f : -1, next = j + 1 < nh_r ? (hits[j + 1] >> 24) & 0x3f : -1;
+      if (prev != pb) rs[pb] = j;
+      if (next != pb) re[pb] = j + 1;
+    }
+    WAVE_SYNC();
+    int rstart = 0, rcnt = 0;
+    if (l < m.nb) { rstart = rs[l]; rcnt = re[l] - rstart; }
+    STAMP(10);
+    for (int j0 = 0; __ballot(j0 < nh_r) != 0ull; j0 += SEGW)
+      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC>(T, rec, hits, slot, dst, j0, nh_r, rstart, rcnt, l, m.nb, compute);
+    STAMP(11);
+    return;
+  }
+  if (m.nc == 0) {
+    if (log && env_ok && l == 0) log[0] = 0;
+    return;
+  }
   const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
   const unsigned long long wave_any = __ballot(surv);
   STAMP(8);
-  if (wave_any == 0ull) return;
+  if (wave_any == 0ull) {
+    if (log && env_ok && l == 0) log[0] = 0;
+    return;
+  }
   const unsigned long long M = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;  // surviving bodies of my env
   const SegMask sm = seg_mask<SEGW>(seg);
   int nlist = 0;
@@ -192,6 +222,7 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
   // ---- L3: point cull, PD_UNROLL tiles per iteration (their LDS reads overlap).  Hits are appended tile by tile, so the
   // hits of one body form one contiguous run [run_start, run_start + run_cnt) of the hit list, tracked by lane == body.
   int nh = 0, run_start = 0, run_cnt = 0;
+  bool flushed = false;
   auto flush_all = [&]() {
     WAVE_SYNC();
     for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW)
@@ -223,9 +254,15 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
         run_cnt += nh - before;
       }
     }
-    if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) flush_all();  // rare: keep room for the next iteration
+    if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) { flush_all(); flushed = true; }  // rare
   }
   STAMP(10);
+  if (log && env_ok) {  // hand the hit list to the adjoint
+    WAVE_SYNC();
+    const bool fits = !flushed && nh < PD_HITLOG;
+    if (l == 0) log[0] = fits ? nh : -1;
+    if (fits) for (int j = l; j < nh; j += SEGW) log[1 + j] = hits[j];
+  }
   flush_all();
   STAMP(11);
 }
@@ -265,6 +302,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
+  const int ec = env_ok ? env : 0;  // clamped env for safe addressing
   const bool is_body = env_ok && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
-  int *list = (int *)(pcon + nb * PD_W6), *hits = list + m.ntiles;
+  int *list = (int *)(pcon + nb * PD_W6), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
 
   BodyConst c = load_body_const(m, b);
@@ -293,14 +331,14 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       STAMP(7);
       float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
       if (is_body) cv = cull[b];
-      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, cv, rec, cull, list, hits, slot, facc, is_body, seg, l, contact_hit STAMP_PASS);
+      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, cv, rec, cull, list, hits, slot, facc, is_body, env_ok, seg, l,
+                                           a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, PD_NO_REPLAY, contact_hit STAMP_PASS);
       STAMP(12);
       __syncthreads();  // B: contact wrenches are complete
     }
     STAMP_FLUSH(a);
     return;
   }
-  const int ec = env_ok ? env : 0;       // clamped env for safe addressing
   const size_t idx = (size_t)ec * nb + b;  // flat body index (env-major)
   const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
 
@@ -373,7 +411,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (!SPLIT) {
       WAVE_SYNC();
       sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
-                                           is_body, seg, l, contact_hit STAMP_PASS);
+                                           is_body, env_ok, seg, l, a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, PD_NO_REPLAY,
+                                           contact_hit STAMP_PASS);
     }
     const int fr = a.frame_of_step[step];
     STAMP(1);
@@ -460,6 +499,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
+  const int ec = env_ok ? env : 0;  // clamped env for safe addressing
   const bool is_body = env_ok && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
@@ -468,7 +508,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
-  int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.ntiles;
+  int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
 
   BodyConst c = load_body_const(m, b);
@@ -484,18 +524,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     // ---- contact wave: adjoint of eval_body_contacts for the partner body wave's envs, between barriers A and B
     STAMP_DECL;
     for (int step = a.nsteps - 1; step >= 0; --step) {
+      // the forward sweep logged this step's hit list: fetch its length before the barrier (latency hidden by the wait)
+      int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
+      const int cnt = env_ok ? lg[0] : 0;
       __syncthreads();  // A: records, cull vectors and wrench adjoints (adjf) of this step are staged; cacc is zero
       STAMP(7);
       float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
       if (is_body) cv = cull[b];
-      sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, seg, l, contact_hit STAMP_PASS);
+      const bool replay = __ballot(cnt < 0) == 0ull;  // -1: the list did not fit the log, cull again (whole wave)
+      sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, env_ok, seg, l,
+                                                   replay ? lg : nullptr, replay ? cnt : PD_NO_REPLAY, contact_hit STAMP_PASS);
       STAMP(12);
       __syncthreads();  // B: contact adjoints are complete
     }
     STAMP_FLUSH(a);
     return;
   }
-  const int ec = env_ok ? env : 0;
   const size_t idx = (size_t)ec * nb + b;
   const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
 
@@ -560,6 +604,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
     const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
     load_step(step - 1);
+    // unsplit kernels replay the forward hit list inline further down: fetch its length now, far ahead of its use
+    int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
+    const int log_cnt = (!SPLIT && env_ok) ? lg[0] : 0;
     const v3 rc = qrot(s.r, c.com);
     if (is_body) stage_record(rec, cull, b, s, rc);
     STAMP(0);
@@ -620,8 +667,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (SPLIT) {
       __syncthreads();  // B: contact adjoints are complete
     } else {
+      const bool replay = __ballot(log_cnt < 0) == 0ull;
+      const int cnt = log_cnt;
       sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot,
-                                           cacc, is_body, seg, l, contact_hit STAMP_PASS);
+                                                   cacc, is_body, env_ok, seg, l, replay ? lg : nullptr, replay ? cnt : PD_NO_REPLAY,
+                                                   contact_hit STAMP_PASS);
       WAVE_SYNC();
     }
     if (is_body) {
