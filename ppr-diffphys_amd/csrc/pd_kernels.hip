@@ -137,13 +137,19 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
 
 // cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
 // dst: per-body accumulators [nb][DSTRIDE] (zeroed by their owner before the sweep); slot: SEGW*NV floats of scratch.
-// log != nullptr, replay_cnt == PD_NO_REPLAY : forward sweep, the final hit list is written to log (this env, this step)
+// replay_cnt == PD_NO_REPLAY : full sweep; log_n returns what to log (write_hit_log, done by the caller off the critical path)
 // replay_cnt >= 0                            : adjoint sweep, the first replay_cnt entries of log ARE the hit list
 #define PD_NO_REPLAY (-2)
+template <int SEGW>
+PD_DEV void write_hit_log(int *log, const int *hits, int log_n, bool env_ok, int l) {
+  if (!env_ok) return;
+  if (l == 0) log[0] = log_n;
+  for (int j = l; j < log_n; j += SEGW) log[1 + j] = hits[j];
+}
 template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
                            const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, bool env_ok, int seg,
-                           int l, int *log, int replay_cnt, F &&compute STAMP_ARGS) {
+                           int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS) {
   if (replay_cnt >= 0) {  // wave-uniform: every env of this wave has a usable log entry
     const int nh_r = replay_cnt;
     for (int j = l; j < nh_r; j += SEGW) hits[j] = log[1 + j];
@@ -165,17 +171,12 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
     STAMP(11);
     return;
   }
-  if (m.nc == 0) {
-    if (log && env_ok && l == 0) log[0] = 0;
-    return;
-  }
+  log_n = 0;  // what the forward caller should log for this env: >= 0 hit count (entries are in hits[]), -1 = did not fit
+  if (m.nc == 0) return;
   const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
   const unsigned long long wave_any = __ballot(surv);
   STAMP(8);
-  if (wave_any == 0ull) {
-    if (log && env_ok && l == 0) log[0] = 0;
-    return;
-  }
+  if (wave_any == 0ull) return;
   const unsigned long long M = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;  // surviving bodies of my env
   const SegMask sm = seg_mask<SEGW>(seg);
   int nlist = 0;
@@ -257,12 +258,7 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
     if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) { flush_all(); flushed = true; }  // rare
   }
   STAMP(10);
-  if (log && env_ok) {  // hand the hit list to the adjoint
-    WAVE_SYNC();
-    const bool fits = !flushed && nh < PD_HITLOG;
-    if (l == 0) log[0] = fits ? nh : -1;
-    if (fits) for (int j = l; j < nh; j += SEGW) log[1 + j] = hits[j];
-  }
+  log_n = (!flushed && nh < PD_HITLOG) ? nh : -1;
   flush_all();
   STAMP(11);
 }
@@ -331,10 +327,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       STAMP(7);
       float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
       if (is_body) cv = cull[b];
-      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, cv, rec, cull, list, hits, slot, facc, is_body, env_ok, seg, l,
-                                           a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, PD_NO_REPLAY, contact_hit STAMP_PASS);
+      int log_n;
+      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, cv, rec, cull, list, hits, slot, facc, is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY,
+                                           log_n, contact_hit STAMP_PASS);
       STAMP(12);
       __syncthreads();  // B: contact wrenches are complete
+      write_hit_log<SEGW>(a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, hits, log_n, env_ok, l);  // for the adjoint; off the critical path
     }
     STAMP_FLUSH(a);
     return;
@@ -410,9 +408,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     if (!SPLIT) {
       WAVE_SYNC();
+      int log_n;
       sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
-                                           is_body, env_ok, seg, l, a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, PD_NO_REPLAY,
-                                           contact_hit STAMP_PASS);
+                                           is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY, log_n, contact_hit STAMP_PASS);
+      write_hit_log<SEGW>(a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, hits, log_n, env_ok, l);
     }
     const int fr = a.frame_of_step[step];
     STAMP(1);
@@ -532,8 +531,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
       if (is_body) cv = cull[b];
       const bool replay = __ballot(cnt < 0) == 0ull;  // -1: the list did not fit the log, cull again (whole wave)
+      int log_n_unused;
       sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, env_ok, seg, l,
-                                                   replay ? lg : nullptr, replay ? cnt : PD_NO_REPLAY, contact_hit STAMP_PASS);
+                                                   replay ? lg : nullptr, replay ? cnt : PD_NO_REPLAY, log_n_unused, contact_hit STAMP_PASS);
       STAMP(12);
       __syncthreads();  // B: contact adjoints are complete
     }
@@ -668,10 +668,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       __syncthreads();  // B: contact adjoints are complete
     } else {
       const bool replay = __ballot(log_cnt < 0) == 0ull;
+      int log_n_unused;
       const int cnt = log_cnt;
       sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot,
                                                    cacc, is_body, env_ok, seg, l, replay ? lg : nullptr, replay ? cnt : PD_NO_REPLAY,
-                                                   contact_hit STAMP_PASS);
+                                                   log_n_unused, contact_hit STAMP_PASS);
       WAVE_SYNC();
     }
     if (is_body) {
