@@ -422,3 +422,39 @@ def test_empty_batch_and_graph_capture(dev):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(cap_pos, ref_pos) and torch.equal(cap_g, ref_g)
+
+
+@pytest.mark.parametrize("segw", [0, 64])
+def test_many_contacts_overflow_paths(segw, dev, oracle_libs):
+    """Robot dropped INTO the ground (chassis and legs hundreds of points deep): exercises the cooperative big-body
+    tile cull, hit-list overflow with mid-sweep flushes, the hit-log 'did not fit' marker and the adjoint's re-cull
+    fallback -- none of which a standing robot reaches.  Short horizon: the 500 N clamps make this regime violent."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template("laikago")
+    bs, T = 7, 6
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=8, steps_per_frame=2)
+    q = inp["q_init"].reshape(bs, -1)
+    q[:, 1] -= np.linspace(0.25, 0.42, bs).astype(np.float32)   # chassis bottom well below y = 0 for the later envs
+    rng = np.random.RandomState(0)
+    inp["qd_init"] = (rng.randn(*inp["qd_init"].shape) * 0.3).astype(np.float32)  # tangential velocity => friction term
+    dm = hip_backend.DeviceModel(tpl)
+    if segw:
+        dm.set_segment_width(segw)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    # how many candidates are active at step 0 in the deepest env (oracle-independent count from the fixture geometry)
+    low = synth.fk_pose_np(tpl, q.astype(np.float64))
+    cb = tpl["contact_body"].astype(np.int64)
+    X = low[:, cb]
+    y = X[..., 1] + synth._qrot(X[..., 3:], np.broadcast_to(tpl["contact_point"].astype(np.float64), X[..., :3].shape))[..., 1]
+    nact = (y <= 0).sum(-1)
+    assert nact.max() > 500 and nact.min() > 31, nact   # beyond the 31-entry hit log and the 128-entry hit list
+    assert relmax(out["grf"], st["grf"]) < 1e-3 and relmax(out["wp_pos"], st["wp_pos"]) < 1e-4
+    assert relmax(out["wp_vel"], st["wp_vel"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 1e-2
+    assert all(np.isfinite(v).all() for v in out["grads"].values())
+    for k in ("q_init", "qd_init", "res_f", "refs", "body_inv_mass", "body_inertia"):
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
