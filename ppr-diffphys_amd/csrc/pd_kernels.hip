@@ -2,7 +2,9 @@
 //
 // One launch covers all T steps of all envs (the reference issues 4 launches + 3 aux ops per step
 // from Python, /root/reference/diffphys/dp_model.py:1209-1234).  Per step the only HBM traffic is
-// the SoA state spill for the adjoint, the step's controls, and frame outputs.  See DESIGN.md.
+// the SoA state + wrench spill for the adjoint, the step's controls, the contact hit log and frame
+// outputs.  Revolute-only robots run wave-specialised (body waves + contact waves, two workgroup
+// barriers per step).  See DESIGN.md section 3.
 #include "pd_device.h"
 #include "pd_args.h"
 
@@ -34,13 +36,6 @@ struct Seg {
   static constexpr int EPW = 64 / SEGW;
   static constexpr unsigned long long MASK = SEGW == 64 ? ~0ull : ((1ull << SEGW) - 1ull);
 };
-
-// Segment-local ballot: bit i = predicate of lane i of my segment.
-template <int SEGW>
-PD_DEV unsigned long long seg_ballot(bool pred, int seg) {
-  unsigned long long b = __ballot(pred);
-  return (b >> (seg * SEGW)) & Seg<SEGW>::MASK;
-}
 
 // Stream compaction inside a segment: returns this lane's slot among the segment's lanes with pred set
 // (v_mbcnt on the ballot masked to the segment: 4 VALU ops) and adds the segment's count to `total`.

@@ -3,8 +3,8 @@
 // built-ins the reference's kernels call: quat_rotate as
 // x(2w^2-1) + 2w(q_v x x) + 2 q_v (q_v . x), Hamilton product, conjugate inverse,
 // normalize(vec3)=0 at zero length, clamp/min adjoints routed to the selected argument.
-// No fast-math: NaN/inf must appear exactly where the reference lets them appear
-// (acos at +-1, asin gimbal); the boundary scrubs them (dp_utils.py:43-57 of the reference).
+// No fast-math (inf/NaN semantics are kept; the boundary scrubs NaN like dp_utils.py:43-57 of the reference).
+// acos/asin clamp their argument and drop the adjoint at |x| = 1 (acos_c / inv_sqrt_1mx2 below).
 #pragma once
 #include <hip/hip_runtime.h>
 
