@@ -76,6 +76,7 @@ struct BodyConst {
   v3 com, axis, p_pj, com_par;
   qt q_pj, q_off;
   float4 sphere;  // bounding sphere of this body's contact candidates
+  float reach;    // >= distance of any contact candidate from the centre of mass (0: no candidates)
   int tile_first, tile_count;
   int small_e[4];  // this lane's entries of the small-body tile list (chunk u: entry u*SEGW + lane)
   int child[4];    // first four children (-1 = none); the rest, if any, are walked from `children`
@@ -89,6 +90,7 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
   c.p_pj = ld3(m.X_p + b * 7); c.q_pj = ld4(m.X_p + b * 7 + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
   c.sphere = m.body_sphere[b];
+  c.reach = c.sphere.w >= 0.0f ? length(V3(c.sphere.x, c.sphere.y, c.sphere.z) - c.com) + c.sphere.w : 0.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int cid = (int)((c.children >> (8 * k)) & 0xffull);
@@ -564,10 +566,120 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
 }
 
 // ---------------------------------------------------------------------------------------------
+// Revolute joint adjoint in two halves (wave-specialised adjoint kernel): rev_forward recomputes everything that depends
+// on the stored state and the controls only -- it runs on the otherwise idle contact wave and is handed over through
+// LDS -- and rev_adjoint, on the body wave, is the part that needs the wrench adjoints.  Together they equal the
+// revolute branch of joint_adj.
+#define PD_JC 25  // floats of the hand-over record (odd stride)
+struct RevCache {
+  qt q_p, r_err, tq;
+  v3 x_p, axis_p, axis_c;
+  float q, qd, jf, dq;  // dq = d q / d twist.w = -2 sgn / sqrt(1 - twist.w^2), guarded
+};
+PD_DEV void rev_cache_store(float *d, const RevCache &R) {
+  d[0] = R.q_p.x; d[1] = R.q_p.y; d[2] = R.q_p.z; d[3] = R.q_p.w; d[4] = R.r_err.x; d[5] = R.r_err.y; d[6] = R.r_err.z; d[7] = R.r_err.w;
+  d[8] = R.tq.x; d[9] = R.tq.y; d[10] = R.tq.z; d[11] = R.tq.w; d[12] = R.x_p.x; d[13] = R.x_p.y; d[14] = R.x_p.z;
+  d[15] = R.axis_p.x; d[16] = R.axis_p.y; d[17] = R.axis_p.z; d[18] = R.axis_c.x; d[19] = R.axis_c.y; d[20] = R.axis_c.z;
+  d[21] = R.q; d[22] = R.qd; d[23] = R.jf; d[24] = R.dq;
+}
+PD_DEV RevCache rev_cache_load(const float *d) {
+  RevCache R;
+  R.q_p = ld4(d); R.r_err = ld4(d + 4); R.tq = ld4(d + 8); R.x_p = ld3(d + 12); R.axis_p = ld3(d + 15); R.axis_c = ld3(d + 18);
+  R.q = d[21]; R.qd = d[22]; R.jf = d[23]; R.dq = d[24];
+  return R;
+}
+
+PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 w_c, const float *rec, float tgt, float act, float ke,
+                            float kd) {
+  RevCache R;
+  R.x_p = c.p_pj; R.q_p = c.q_pj;
+  v3 w_p = V3(0, 0, 0);
+  if (c.parent >= 0) {
+    const float *r = rec + c.parent * PD_REC;
+    const qt qp = ld4(r + 3);
+    w_p = ld3(r + 7);
+    R.x_p = ld3(r) + qrot(qp, c.p_pj);
+    R.q_p = qmul(qp, c.q_pj);
+  }
+  R.r_err = qmul(qconj(R.q_p), q_c);
+  R.axis_p = qrot(R.q_p, c.axis);
+  R.axis_c = qrot(q_c, c.axis);
+  v3 a = c.axis * dot(qvec(R.r_err), c.axis);
+  R.tq = Q4(a.x, a.y, a.z, R.r_err.w);
+  const qt twist = qnormalize(R.tq);
+  const float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
+  R.q = acos_c(twist.w) * 2.0f * sgn;
+  R.dq = -2.0f * sgn * inv_sqrt_1mx2(twist.w);
+  R.qd = dot(w_c - w_p, R.axis_p);
+  const JointLimit L = load_limit(m, c.qdstart);
+  R.jf = joint_force(R.q, R.qd, tgt, ke, kd, act, L.lo, L.up, L.ke, L.kd);
+  return R;
+}
+
+PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const RevCache &R,
+                        float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par, float &a_tgt,
+                        float &a_act, float &a_ke, float &a_kd) {
+  const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
+  v3 pp = V3(0, 0, 0), w_p = pp, v_p = pp, r_p = pp;
+  qt qp = Q4(0, 0, 0, 1);
+  if (c.parent >= 0) {
+    const float *r = rec + c.parent * PD_REC;
+    pp = ld3(r); qp = ld4(r + 3); w_p = ld3(r + 7); v_p = ld3(r + 10);
+    r_p = R.x_p - (pp + ld3(r + 13));
+  }
+  const v3 r_c = s.p - (s.p + rc_c);
+  const v3 x_err = s.p - R.x_p, v_err = s.v - v_p, w_err = s.w - w_p;
+  const v3 f_total = x_err * ake + v_err * akd;
+  v3 adj_t = -gc_t, adj_f = -gc_f, adj_r_c = V3(0, 0, 0), adj_r_p = V3(0, 0, 0);
+  adj_cross(r_c, f_total, adj_r_c, adj_f, -gc_t);
+  if (c.parent >= 0) {
+    adj_t += gp_t; adj_f += gp_f;
+    adj_cross(r_p, f_total, adj_r_p, adj_f, gp_t);
+  }
+  v3 adj_x_err = adj_f * ake, adj_v_err = adj_f * akd, adj_w_err = adj_t * (akd * ads);
+  qt adj_r_err = Q4(0, 0, 0, 0), adj_q_p = Q4(0, 0, 0, 0), adj_q_c = Q4(0, 0, 0, 0);
+  const float adj_jf = dot(adj_t, R.axis_p);
+  v3 adj_axis_p = adj_t * R.jf, adj_axis_c = V3(0, 0, 0);
+  float adj_qd = -adj_jf * (akd * ads);
+  adj_axis_p += adj_t * (-R.qd * (akd * ads));
+  adj_cross(R.axis_p, R.axis_c, adj_axis_p, adj_axis_c, adj_t * ake);
+  float adj_q = 0.f;
+  a_tgt = 0.f; a_act = 0.f; a_ke = 0.f; a_kd = 0.f;
+  const JointLimit L = load_limit(m, c.qdstart);
+  joint_force_adj(R.q, R.qd, tgt, ke, kd, L.lo, L.up, L.ke, L.kd, adj_jf, adj_q, adj_qd, a_tgt, a_ke, a_kd, a_act);
+  adj_w_err += R.axis_p * adj_qd; adj_axis_p += w_err * adj_qd;
+  qt adj_tq = Q4(0, 0, 0, 0);
+  adj_qnormalize(R.tq, adj_tq, Q4(0, 0, 0, adj_q * R.dq));
+  const float adj_da = dot(qvec(adj_tq), c.axis);
+  adj_r_err.x += c.axis.x * adj_da; adj_r_err.y += c.axis.y * adj_da; adj_r_err.z += c.axis.z * adj_da;
+  adj_r_err.w += adj_tq.w;
+  adj_qrot_q(R.q_p, c.axis, adj_q_p, adj_axis_p);
+  adj_qrot_q(s.r, c.axis, adj_q_c, adj_axis_c);
+  {  // r_err = conj(q_p) * q_c
+    qt adj_cqp = Q4(0, 0, 0, 0);
+    adj_qmul(qconj(R.q_p), s.r, adj_cqp, adj_q_c, adj_r_err);
+    adj_q_p += qconj(adj_cqp);
+  }
+  adj_qrot_q(s.r, c.com, adj_q_c, -adj_r_c);
+  own.p += adj_x_err; own.r += adj_q_c; own.w += adj_w_err; own.v += adj_v_err;
+  par = adj_zero();
+  if (c.parent >= 0) {
+    v3 adj_x_p = adj_r_p - adj_x_err;
+    par.p = adj_x_p - adj_r_p;
+    adj_qrot_q(qp, c.com_par, par.r, -adj_r_p);
+    adj_qrot_q(qp, c.p_pj, par.r, adj_x_p);
+    adj_qmul_a(c.q_pj, par.r, adj_q_p);
+    par.w = -adj_w_err; par.v = -adj_v_err;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // integrate_bodies (integrator_euler.py:21-91) for one body.
 // rc = rot(q, com) of the input state (from the staging); rc_out = the same for the returned state.
+// sink_rate: bound on how fast any contact candidate of the body can have lost height over this step,
+// |v1_y| + |w1|_1 * reach (the pose update uses the unclamped v1, w1), for the speculative contact cull.
 PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc, v3 t0, v3 f0, float inv_m,
-                               const float *I, const float *invI, float dt, v3 &rc_out) {
+                               const float *I, const float *invI, float dt, v3 &rc_out, float &sink_rate) {
   v3 g = V3(m.gx, m.gy, m.gz);
   float nz = inv_m != 0.0f ? 1.0f : 0.0f;
   v3 x_com = s.p + rc;                                          // :61
@@ -577,6 +689,7 @@ PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const Bo
   v3 tb = qrot_inv(s.r, t0) - cross(wb, mat_vec(I, wb));        // :69
   v3 w1 = qrot(s.r, wb + mat_vec(invI, tb) * dt);               // :71
   qt r1 = qnormalize(s.r + qmul(Q4(w1.x, w1.y, w1.z, 0.f), s.r) * (0.5f * dt));  // :72
+  sink_rate = fabsf(v1.y) + (fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z)) * c.reach;
   w1 = w1 * (1.0f - 0.1f * dt);                                 // :75
   BodyState o;
   o.w = clamp3(w1, 10.0f); o.v = clamp3(v1, 10.0f);             // :78-88

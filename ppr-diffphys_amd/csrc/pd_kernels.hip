@@ -14,6 +14,7 @@
 #define STAMP_ARGS , unsigned long long *st_acc, unsigned long long &st_t
 #define STAMP_PASS , st_acc, st_t
 #define STAMP(i) do { unsigned long long t2_ = pd_memtime(); st_acc[i] += t2_ - st_t; st_t = t2_; } while (0)
+#define STAMP_COUNT(i, n) do { st_acc[i] += (unsigned long long)(n); } while (0)
 #define STAMP_FLUSH(a) do { if ((a).dbg && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((size_t)blockIdx.x * (PD_BLOCK / 64) + (threadIdx.x >> 6)) * 16 + i_] = st_acc[i_]; } while (0)
 __device__ __forceinline__ unsigned long long pd_memtime() {
   unsigned long long t;
@@ -25,6 +26,7 @@ __device__ __forceinline__ unsigned long long pd_memtime() {
 #else
 #define STAMP_DECL
 #define STAMP(i)
+#define STAMP_COUNT(i, n)
 #define STAMP_FLUSH(a)
 #define STAMP_ARGS
 #define STAMP_PASS
@@ -63,7 +65,9 @@ PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
 //                   survivors are compacted into a per-env hit list                      (lane = point)
 //   hit pass      : lanes = compacted hits (dense), on_hit(record, point, material) does the reference's arithmetic
 // With one wavefront per SIMD nothing else hides LDS latency, so the structure minimises DEPENDENT LDS round trips.
+#ifndef PD_UNROLL
 #define PD_UNROLL 4          // tiles handled per L3 iteration (their LDS reads are issued back to back)
+#endif
 #define PD_HIT_CAP_TILES 8   // hit-list capacity in units of SEGW (two L3 iterations)
 
 struct SweepTables {
@@ -97,10 +101,10 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
                               int run_start, int run_cnt, int l, int nb, F &&compute) {
   const int j = j0 + l;
   if (j < nh) {
-    int e = hits[j];
+    int e = hits[j];  // point | material << 16 | body << 24
     int pt = e & 0xffff, pb = (e >> 24) & 0x3f;
     float out[NV];
-    compute(rec + pb * PD_REC, T.pts[pt], T.mats[T.pmat[pt]], out);
+    compute(rec + pb * PD_REC, T.pts[pt], T.mats[(e >> 16) & 0xff], out);
     if (ATOMIC) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) atomicAdd(dst + pb * DSTRIDE + i, out[i]);
@@ -130,48 +134,17 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
   WAVE_SYNC();
 }
 
-// cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
-// dst: per-body accumulators [nb][DSTRIDE] (zeroed by their owner before the sweep); slot: SEGW*NV floats of scratch.
-// replay_cnt == PD_NO_REPLAY : full sweep; log_n returns what to log (write_hit_log, done by the caller off the critical path)
-// replay_cnt >= 0                            : adjoint sweep, the first replay_cnt entries of log ARE the hit list
-#define PD_NO_REPLAY (-2)
+// L1 + L2 of the sweep: fills list[] with the packed tiles that may hold a hit and returns their count (per env).
+// cv / cull may be the exact cull vectors of the state, or -- speculative pre-cull of the NEXT state, wave-specialised
+// forward kernel -- vectors whose height is lowered by a verified bound on the body's motion (see k_rollout_fwd).
 template <int SEGW>
-PD_DEV void write_hit_log(int *log, const int *hits, int log_n, bool env_ok, int l) {
-  if (!env_ok) return;
-  if (l == 0) log[0] = log_n;
-  for (int j = l; j < log_n; j += SEGW) log[1 + j] = hits[j];
-}
-template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
-PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
-                           const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, bool env_ok, int seg,
-                           int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS) {
-  if (replay_cnt >= 0) {  // wave-uniform: every env of this wave has a usable log entry
-    const int nh_r = replay_cnt;
-    for (int j = l; j < nh_r; j += SEGW) hits[j] = log[1 + j];
-    int *rs = list, *re = list + m.nb;  // run bounds per body (the tile list is not used in a replay)
-    if (l < m.nb) { rs[l] = 0; re[l] = 0; }
-    WAVE_SYNC();
-    for (int j = l; j < nh_r; j += SEGW) {
-      const int pb = (hits[j] >> 24) & 0x3f;
-      const int prev = j > 0 ? (hits[j - 1] >> 24) & 0x3f : -1, next = j + 1 < nh_r ? (hits[j + 1] >> 24) & 0x3f : -1;
-      if (prev != pb) rs[pb] = j;
-      if (next != pb) re[pb] = j + 1;
-    }
-    WAVE_SYNC();
-    int rstart = 0, rcnt = 0;
-    if (l < m.nb) { rstart = rs[l]; rcnt = re[l] - rstart; }
-    STAMP(10);
-    for (int j0 = 0; __ballot(j0 < nh_r) != 0ull; j0 += SEGW)
-      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC>(T, rec, hits, slot, dst, j0, nh_r, rstart, rcnt, l, m.nb, compute);
-    STAMP(11);
-    return;
-  }
-  log_n = 0;  // what the forward caller should log for this env: >= 0 hit count (entries are in hits[]), -1 = did not fit
-  if (m.nc == 0) return;
+PD_DEV int sweep_cull(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float4 *cull, int *list,
+                      bool is_body, int seg, int l STAMP_ARGS) {
+  if (m.nc == 0) return 0;
   const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
   const unsigned long long wave_any = __ballot(surv);
   STAMP(8);
-  if (wave_any == 0ull) return;
+  if (wave_any == 0ull) return 0;
   const unsigned long long M = (wave_any >> (seg * SEGW)) & Seg<SEGW>::MASK;  // surviving bodies of my env
   const SegMask sm = seg_mask<SEGW>(seg);
   int nlist = 0;
@@ -215,6 +188,14 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
   }
   STAMP(9);
   WAVE_SYNC();
+  return nlist;
+}
+
+// L3 + hit pass over list[0, nlist): exact point test, compaction, on_hit arithmetic.  log_n: see sweep_contacts.
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
+PD_DEV void sweep_points(const PdDevModel &m, const SweepTables &T, const float *rec, const float4 *cull, const int *list, int nlist,
+                         int *hits, float *slot, float *dst, int seg, int l, int &log_n, F &&compute STAMP_ARGS) {
+  const SegMask sm = seg_mask<SEGW>(seg);
   // ---- L3: point cull, PD_UNROLL tiles per iteration (their LDS reads overlap).  Hits are appended tile by tile, so the
   // hits of one body form one contiguous run [run_start, run_start + run_cnt) of the hit list, tracked by lane == body.
   int nh = 0, run_start = 0, run_cnt = 0;
@@ -226,17 +207,18 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
     nh = 0; run_cnt = 0;
   };
   for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += PD_UNROLL) {
-    int e[PD_UNROLL];
+    int e[PD_UNROLL], mi[PD_UNROLL];
     bool hit[PD_UNROLL];
 #pragma unroll
     for (int u = 0; u < PD_UNROLL; ++u) e[u] = (k0 + u < nlist) ? list[k0 + u] : 0;  // count field 0 => no lane is valid
 #pragma unroll
     for (int u = 0; u < PD_UNROLL; ++u) {
       int pt0 = e[u] & 0xffff, n = (e[u] >> 16) & 0xff, pb = (e[u] >> 24) & 0x3f;
-      hit[u] = false;
+      hit[u] = false; mi[u] = 0;
       if (l < n) {
         float4 P = T.pts[pt0 + l];
         float4 cb = cull[pb];
+        mi[u] = T.pmat[pt0 + l];  // carried in the hit entry: the hit pass then needs no dependent material lookup
         hit[u] = cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f;
       }
     }
@@ -244,7 +226,7 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
     for (int u = 0; u < PD_UNROLL; ++u) {
       const int before = nh;
       int s = seg_slot(hit[u], sm, nh);
-      if (hit[u]) hits[s] = ((e[u] & 0xffff) + l) | (e[u] & 0x3f000000);
+      if (hit[u]) hits[s] = ((e[u] & 0xffff) + l) | (mi[u] << 16) | (e[u] & 0x3f000000);
       if (l == ((e[u] >> 24) & 0x3f) && nh > before) {
         if (run_cnt == 0) run_start = before;
         run_cnt += nh - before;
@@ -256,6 +238,92 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
   log_n = (!flushed && nh < PD_HITLOG) ? nh : -1;
   flush_all();
   STAMP(11);
+}
+
+// L3 alone, for the speculative sweep of the wave-specialised forward kernel: candidates of list[0, nlist) whose height
+// under the (lowered) vectors `cull` passes the point test are compacted into hits[]; nh = their count.  Nothing is
+// evaluated here -- the state the contacts belong to does not exist yet.  Returns false when some env's candidates do
+// not fit hits[] (the caller then redoes the sweep the exact way).
+template <int SEGW>
+PD_DEV bool sweep_l3_spec(const SweepTables &T, const float4 *cull, const int *list, int nlist, int *hits, int seg, int l, int &nh) {
+  const SegMask sm = seg_mask<SEGW>(seg);
+  nh = 0;
+  for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += PD_UNROLL) {
+    if (__ballot(nh > (PD_HIT_CAP_TILES - PD_UNROLL) * SEGW) != 0ull) return false;
+    int e[PD_UNROLL], mi[PD_UNROLL];
+    bool hit[PD_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PD_UNROLL; ++u) e[u] = (k0 + u < nlist) ? list[k0 + u] : 0;
+#pragma unroll
+    for (int u = 0; u < PD_UNROLL; ++u) {
+      int pt0 = e[u] & 0xffff, n = (e[u] >> 16) & 0xff, pb = (e[u] >> 24) & 0x3f;
+      hit[u] = false; mi[u] = 0;
+      if (l < n) {
+        float4 P = T.pts[pt0 + l];
+        float4 cb = cull[pb];
+        mi[u] = T.pmat[pt0 + l];
+        hit[u] = cb.x + (cb.y * P.x + cb.z * P.y + cb.w * P.z) - P.w <= 1e-4f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PD_UNROLL; ++u) {
+      int s = seg_slot(hit[u], sm, nh);
+      if (hit[u]) hits[s] = ((e[u] & 0xffff) + l) | (mi[u] << 16) | (e[u] & 0x3f000000);
+    }
+  }
+  WAVE_SYNC();
+  return true;
+}
+
+// cv = this lane's own cull vector (registers), cull = the segment's cull vectors in LDS.
+// dst: per-body accumulators [nb][DSTRIDE] (zeroed by their owner before the sweep); slot: SEGW*NV floats of scratch.
+// replay_cnt == PD_NO_REPLAY : full sweep; log_n returns what to log (write_hit_log, done by the caller off the critical path)
+// replay_cnt >= 0                            : adjoint sweep, the first replay_cnt entries of log ARE the hit list
+#define PD_NO_REPLAY (-2)
+template <int SEGW>
+PD_DEV void write_hit_log(int *log, const int *hits, int log_n, bool env_ok, int l) {
+  if (!env_ok) return;
+  if (l == 0) log[0] = log_n;
+  for (int j = l; j < log_n; j += SEGW) log[1 + j] = hits[j];
+}
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
+PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
+                           const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, bool env_ok, int seg,
+                           int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS) {
+  if (replay_cnt >= 0) {  // wave-uniform: every env of this wave has a usable log entry
+    const int nh_r = replay_cnt;
+    for (int j = l; j < nh_r; j += SEGW) hits[j] = log[1 + j];
+    int *rs = list, *re = list + m.nb;  // run bounds per body (the tile list is not used in a replay)
+    if (l < m.nb) { rs[l] = 0; re[l] = 0; }
+    WAVE_SYNC();
+    for (int j = l; j < nh_r; j += SEGW) {
+      const int pb = (hits[j] >> 24) & 0x3f;
+      const int prev = j > 0 ? (hits[j - 1] >> 24) & 0x3f : -1, next = j + 1 < nh_r ? (hits[j + 1] >> 24) & 0x3f : -1;
+      if (prev != pb) rs[pb] = j;
+      if (next != pb) re[pb] = j + 1;
+    }
+    WAVE_SYNC();
+    int rstart = 0, rcnt = 0;
+    if (l < m.nb) { rstart = rs[l]; rcnt = re[l] - rstart; }
+    STAMP(10);
+    for (int j0 = 0; __ballot(j0 < nh_r) != 0ull; j0 += SEGW)
+      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC>(T, rec, hits, slot, dst, j0, nh_r, rstart, rcnt, l, m.nb, compute);
+    STAMP(11);
+    return;
+  }
+  log_n = 0;  // what the forward caller should log for this env: >= 0 hit count (entries are in hits[]), -1 = did not fit
+  const int nlist = sweep_cull<SEGW>(m, T, c, cv, cull, list, is_body, seg, l STAMP_PASS);
+  sweep_points<SEGW, NV, DSTRIDE, ATOMIC>(m, T, rec, cull, list, nlist, hits, slot, dst, seg, l, log_n, compute STAMP_PASS);
+}
+
+// Speculative contact cull (k_rollout_fwd): the height any contact candidate of the body is allowed to lose over the
+// next PD_SPEC_K steps -- per step 1.5 x what its present velocity would give plus 0.2 mm.  The value only steers how
+// often the exact sweep has to be redone, never the result.
+#ifndef PD_SPEC_K
+#define PD_SPEC_K 4  // steps served by one speculative cull
+#endif
+PD_DEV float sink_margin(const BodyConst &c, const BodyState &s, float dt) {
+  return (float)PD_SPEC_K * (1.5f * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + 2e-4f);
 }
 
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.
@@ -302,7 +370,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
-  int *list = (int *)(pcon + nb * PD_W6), *hits = list + m.list_cap;
+  // speculative cull vectors of the two latest states (by step parity) + the env's "speculation failed" flag; they live
+  // in the room the adjoint kernel's wider per-body slots leave in the shared per-env size
+  float4 *spec = (float4 *)(scratch + 36 * nb);  // 36 nb floats: 16-byte aligned like cull
+  int *spec_bad = (int *)(scratch + 44 * nb);
+  int *list = (int *)(scratch + 44 * nb + 4), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
 
   BodyConst c = load_body_const(m, b);
@@ -311,23 +383,71 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {  // body_f -= (t, f)   (:179)
     ContactOut o;
     o.t = V3(0, 0, 0); o.f = V3(0, 0, 0);
-    contact_point_fwd(r, P, mat, o);
+    const bool touching = contact_point_fwd(r, P, mat, o);
     out[0] = -o.t.x; out[1] = -o.t.y; out[2] = -o.t.z; out[3] = -o.f.x; out[4] = -o.f.y; out[5] = -o.f.z;
+    return touching;
   };
   if (SPLIT && contact_wave) {
-    // ---- contact wave: eval_body_contacts for the partner body wave's envs, between barriers A and B of each step
+    // ---- contact wave: eval_body_contacts for the partner body wave's envs, between barriers A and B of each step.
+    // The cull (L1-L3) is SPECULATED, once per epoch of PD_SPEC_K steps, in the wait for the body wave's integration:
+    // after barrier B of an epoch's first step s this wave culls with the vectors of state s lowered by margin_b(s), a
+    // guess of how far body b can sink over the epoch.  The body wave checks the guess against the motion it then
+    // integrates (integrate_fwd: sink_rate, summed over the epoch) and raises the env's flag when a body sank further;
+    // a raised flag makes this wave redo the exact sweep.  The candidates are a superset, in the same order, of what
+    // the exact sweep finds in any state of the epoch; contact_hit applies the reference's exact test to each, so the
+    // wrench sums are bit-identical to the unspeculated sweep.
     STAMP_DECL;
+    const SegMask sm = seg_mask<SEGW>(seg);
+    int nh = 0;         // speculated candidates of my env, hits[0, nh)
+    bool have = false;  // wave-uniform: the candidates are there and nothing overwrote them
     for (int step = 0; step < a.nsteps; ++step) {
+      int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
       __syncthreads();  // A: records + cull vectors of this step are staged, wrench accumulators are zero
       STAMP(7);
-      float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
-      if (is_body) cv = cull[b];
-      int log_n;
-      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, cv, rec, cull, list, hits, slot, facc, is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY,
-                                           log_n, contact_hit STAMP_PASS);
+      const bool redo = !have || __ballot(env_ok && *spec_bad != 0) != 0ull;  // wave-uniform
+      STAMP_COUNT(13, redo ? 1 : 0);
+      STAMP_COUNT(14, __shfl(nh, 0));
+      int log_n = 0;
+      if (redo) {
+        float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (is_body) cv = cull[b];
+        const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, cull, list, is_body, seg, l STAMP_PASS);
+        sweep_points<SEGW, 6, PD_W6, true>(m, tabs, rec, cull, list, nlist, hits, slot, facc, seg, l, log_n, contact_hit STAMP_PASS);
+        have = false;  // hits[] now holds this step's exact hits
+      } else {
+        // evaluate the candidates on the state that now exists: contact_hit applies the reference's exact test; the
+        // ones that touch go to the adjoint's log straight away
+        for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW) {
+          const int j = j0 + l;
+          bool touching = false;
+          int e = 0;
+          if (j < nh) {
+            e = hits[j];
+            float out[6];
+            touching = contact_hit(rec + ((e >> 24) & 0x3f) * PD_REC, tabs.pts[e & 0xffff], tabs.mats[(e >> 16) & 0xff], out);
+            if (touching) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) atomicAdd(facc + ((e >> 24) & 0x3f) * PD_W6 + i, out[i]);
+            }
+          }
+          const int s = seg_slot(touching, sm, log_n);
+          if (touching && env_ok && s < PD_HITLOG - 1) lg[1 + s] = e;
+        }
+        if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
+        STAMP(11);
+      }
       STAMP(12);
       __syncthreads();  // B: contact wrenches are complete
-      write_hit_log<SEGW>(a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, hits, log_n, env_ok, l);  // for the adjoint; off the critical path
+      if (redo) write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);  // for the adjoint; off the critical path
+      if (step % PD_SPEC_K == 0 && step + 1 < a.nsteps) {  // state `step` opened an epoch: cull for the steps it serves
+        WAVE_SYNC();  // the log is read out of hits[] before the candidates overwrite it
+        const float4 *sp = spec + ((step / PD_SPEC_K) & 1) * nb;
+        float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (is_body) cv = sp[b];
+        const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, sp, list, is_body, seg, l STAMP_PASS);
+        have = sweep_l3_spec<SEGW>(tabs, sp, list, nlist, hits, seg, l, nh);
+        STAMP(10);
+      }
     }
     STAMP_FLUSH(a);
     return;
@@ -353,14 +473,19 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
   v3 rc = V3(0, 0, 0);  // rot(q, com) of the current state, shared by staging, joints and integration
+  float margin = 0.f, sunk = 0.f;  // speculative contact cull: allowed / integrated loss of height since the epoch's state
   for (int d = 0; d <= m.max_depth; ++d) {
     if (is_body && c.depth == d) {
       s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
       rc = qrot(s.r, c.com);
-      stage_record(rec, cull, b, s, rc);
+      float4 cv = stage_record(rec, cull, b, s, rc);
+      margin = sink_margin(c, s, a.dt);
+      cv.x -= margin;
+      if (SPLIT) spec[b] = cv;  // epoch 0
     }
     WAVE_SYNC();
   }
+  if (SPLIT && l == 0) *spec_bad = 1;  // nothing is speculated for step 0
 
   float *traj_q = a.ws, *traj_qd = a.ws + (size_t)a.nsteps * 7 * N, *traj_f = a.ws + (size_t)a.nsteps * 13 * N;
   // Controls are software-prefetched one step ahead: with one wavefront per SIMD there is no other
@@ -472,10 +597,24 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     STAMP(3);
     // ---- integrate_bodies
-    s = integrate_fwd(m, c, s, rc, ft, ff, inv_m, I, invI, a.dt, rc);
+    float sink_rate;
+    s = integrate_fwd(m, c, s, rc, ft, ff, inv_m, I, invI, a.dt, rc, sink_rate);
     STAMP(4);
+    if (SPLIT) {  // did every body stay inside the margin the contact wave speculated with?  (NaN counts as "no")
+      sunk += sink_rate * a.dt;
+      const bool bad = is_body && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin);
+      const bool any = ((__ballot(bad) >> (seg * SEGW)) & Seg<SEGW>::MASK) != 0ull;
+      if (l == 0) *spec_bad = any ? 1 : 0;
+    }
     WAVE_SYNC();
-    if (is_body) stage_record(rec, cull, b, s, rc);
+    if (is_body) {
+      float4 cv = stage_record(rec, cull, b, s, rc);
+      if (SPLIT && (step + 1) % PD_SPEC_K == 0) {  // state step+1 opens a speculation epoch
+        margin = sink_margin(c, s, a.dt); sunk = 0.f;
+        cv.x -= margin;
+        spec[(((step + 1) / PD_SPEC_K) & 1) * nb + b] = cv;
+      }
+    }
     if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }

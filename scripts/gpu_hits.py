@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Diagnostic: distribution of ground-contact hits per env-step (read from the forward sweep's hit log)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ppr-diffphys_amd"))
+import numpy as np, torch
+from diffphys_amd import robots, synth, hip_backend, dp_model
+
+name, bs, segw = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("laikago", 4096, 16)
+dev = torch.device("cuda:0")
+tpl = robots.load_template(name); T = 100
+seqs = ("mi-trot", "mi-spin") if name == "laikago" else ("mi-pace",)
+inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=1000, seqs=seqs)
+dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw)
+t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
+f2s = inp["frame2step"]; fos = dp_model.frame_of_step_tensor(T, f2s, dev)
+fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
+out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame_of_step=fos, nframes=len(f2s))
+torch.cuda.synchronize()
+nb = int(tpl["nb"])
+ws = out[4]
+log = ws[T * 19 * bs * nb:].view(torch.int32).view(T, bs, -1).cpu().numpy()
+cnt = log[:, :, 0]
+epw = 64 // segw
+print("hits per env-step: mean %.2f  median %d  p90 %d  max %d  overflow(-1) %.3f%%" % (
+    cnt[cnt >= 0].mean(), np.median(cnt), np.percentile(cnt, 90), cnt.max(), 100.0 * (cnt < 0).mean()))
+w = np.clip(cnt, 0, None).reshape(T, bs // epw, epw)
+print("per wave (%d envs): mean sum %.1f  mean max-env %.1f  p90 sum %d" % (epw, w.sum(2).mean(), w.max(2).mean(), np.percentile(w.sum(2), 90)))
+print("batches of %d per env-step now (max over the wave's envs): mean %.2f" % (segw, np.ceil(w.max(2) / segw).mean()))
+print("batches of 64 if compacted wave-wide: mean %.2f" % np.ceil(w.sum(2) / 64.0).mean())
+print("histogram of counts:", np.bincount(np.clip(cnt, 0, None).ravel(), minlength=33)[:33].tolist())
+bodies = (log[:, :, 1:] >> 24) & 0x3f
+valid = np.arange(log.shape[2] - 1)[None, None, :] < np.clip(cnt, 0, None)[:, :, None]
+print("hits by body:", np.bincount(bodies[valid].ravel(), minlength=nb).tolist())
+nbod = np.array([[len(set(bodies[s, e][valid[s, e]])) for e in range(0, bs, 37)] for s in range(0, T, 9)])
+print("distinct bodies in contact per env-step: mean %.2f" % nbod.mean())

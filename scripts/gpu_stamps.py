@@ -33,7 +33,7 @@ b_all = dbg.view(-1, 16).cpu().numpy().astype(np.float64)[: (nw // 8) * 8]
 def rows(arr, contact):
     r = arr.reshape(-1, 8, 16)[:, 4:] if contact else arr.reshape(-1, 8, 16)[:, :4]
     r = r.reshape(-1, 16)
-    return r[r.sum(1) > 0]
+    return r[r[:, :13].sum(1) > 0]
 
 fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints fwd + pcon write"), (6, "child gather"),
       (3, "wait at barrier B + facc + traj_f/frame stores"), (4, "integrate"), (5, "stage record")]
@@ -43,7 +43,11 @@ cn = [(7, "wait at barrier A/A1 (idle)"), (8, "L1 body cull"), (9, "L2 tile cull
 for lab, arr in (("FWD", f_all), ("BWD", b_all)):
     for who, names, contact in (("body wave", fn if lab == "FWD" else bn, False), ("contact wave", cn, True)):
         r = rows(arr, contact)
-        tot = r.sum(1).mean()
+        tot = r[:, :13].sum(1).mean()
         print("%s %-12s waves=%d  cycles per step = %.0f" % (lab, who, len(r), tot / T))
         for i, n in names:
             print("      %-48s %6.1f%%   %8.0f cycles/step" % (n, 100 * r[:, i].mean() / tot, r[:, i].mean() / T))
+
+r = rows(f_all, True)
+print("FWD contact wave: exact cull redone in %.2f%% of wave-steps; speculated candidates (env 0 of the wave) %.2f per step" % (
+    100 * r[:, 13].mean() / T, r[:, 14].mean() / T))
