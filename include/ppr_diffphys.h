@@ -77,8 +77,9 @@ int pd_model_set_segment_width(pd_model *m, int lanes);
 int pd_model_get_segment_width(const pd_model *m);
 
 /* Floats of caller-provided workspace that pd_rollout_forward fills and pd_rollout_backward reads:
- * per step the 13-float body state and the 6-float body wrench, SoA planes [step][component][bs*nb], followed by
- * the forward sweep's contact hit log (32 ints per env-step) that the adjoint replays. */
+ * per step the 13-float body state and the 6-float body wrench as five float4 planes [step][plane][bs*nb], followed
+ * by the forward sweep's contact hit log (32 ints per env-step) that the adjoint replays.  The base must be 16-byte
+ * aligned. */
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps);
 
 /* frame_of_step_dev: [nsteps+1] ints, frame index whose output is state `step`, or -1. */

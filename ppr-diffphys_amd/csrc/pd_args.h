@@ -15,12 +15,14 @@
 
 enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
 
+#define PD_TRAJ_FLOATS 20  // floats of saved trajectory per body-step: 5 float4 planes (pd_kernels.hip: PD_TRAJ_G)
+
 struct RolloutArgs {
   int bs, nsteps, nframes;
   float dt;
   const float *q_init, *qd_init, *torques, *res_f, *refs, *target_ke, *target_kd, *inv_mass, *inertia, *inv_inertia;
   const int *frame_of_step;
-  float *ws;                           // workspace: traj_q [T][7][N], traj_qd [T][6][N], traj_f [T][6][N], N = bs*nb
+  float *ws;                           // workspace: saved trajectory [T][5 planes][N] float4, N = bs*nb, then the hit log
   float *wp_pos, *wp_vel, *grf, *jaf;  // forward outputs (grf/jaf may be null)
   // backward only
   const float *adj_pos, *adj_vel;

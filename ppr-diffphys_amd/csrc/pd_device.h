@@ -40,6 +40,7 @@ struct PdDevModel {
   int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
+  int env_lds_jc;                                         // + joint hand-over records (wave-specialised adjoint only)
 };
 
 #define WAVE_SYNC()                                        \
@@ -70,6 +71,7 @@ PD_DEV v3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
 PD_DEV qt ld4(const float *p) { return Q4(p[0], p[1], p[2], p[3]); }
 
 // Per-lane constants of body l (registers for the whole rollout).
+struct JointLimit { float lo, up, ke, kd; };
 struct BodyConst {
   int type, parent, qstart, qdstart, depth;
   unsigned long long children;
@@ -77,6 +79,7 @@ struct BodyConst {
   qt q_pj, q_off;
   float4 sphere;  // bounding sphere of this body's contact candidates
   float reach;    // >= distance of any contact candidate from the centre of mass (0: no candidates)
+  JointLimit lim[3];  // joint limits of this body's (up to three) joint dofs: loop-invariant, loaded once
   int tile_first, tile_count;
   int small_e[4];  // this lane's entries of the small-body tile list (chunk u: entry u*SEGW + lane)
   int child[4];    // first four children (-1 = none); the rest, if any, are walked from `children`
@@ -97,6 +100,16 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
     c.child[k] = cid == 0xff ? -1 : cid;
   }
   c.tile_first = m.body_tiles[b].x; c.tile_count = m.body_tiles[b].y;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // identically-zero limit forces (no joint has limit gains) cost no loads at all
+    JointLimit L;
+    L.lo = -1.0e30f; L.up = 1.0e30f; L.ke = 0.f; L.kd = 0.f;
+    if (m.has_limits) {
+      const int dof = c.qdstart + k < m.nqd ? c.qdstart + k : m.nqd - 1;
+      L.lo = m.lim_lo[dof]; L.up = m.lim_hi[dof]; L.ke = m.lim_ke[dof]; L.kd = m.lim_kd[dof];
+    }
+    c.lim[k] = L;
+  }
   return c;
 }
 
@@ -315,13 +328,6 @@ PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g
 
 // ---------------------------------------------------------------------------------------------
 // Joint PD + attachment forces for joint i == child body i (integrator_euler.py:289-451).
-struct JointLimit { float lo, up, ke, kd; };
-PD_DEV JointLimit load_limit(const PdDevModel &m, int dof) {  // skipped entirely (uniform branch) when no joint has limit gains
-  JointLimit L;
-  L.lo = -1.0e30f; L.up = 1.0e30f; L.ke = 0.f; L.kd = 0.f;
-  if (m.has_limits) { L.lo = m.lim_lo[dof]; L.up = m.lim_hi[dof]; L.ke = m.lim_ke[dof]; L.kd = m.lim_kd[dof]; }
-  return L;
-}
 PD_DEV float joint_force(float q, float qd, float target, float ke, float kd, float act, float lo, float up, float lke,
                          float lkd) {
   float limit_f = 0.0f;  // :274-281
@@ -383,7 +389,6 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
   joint_ctx(c, s, rc_c, rec, j);
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
-  const int qds = c.qdstart;
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {  // :385-390
     v3 ang_err = normalize(qvec(j.r_err)) * (acos_c(j.r_err.w) * 2.0f);
     f_total += j.x_err * ake + j.v_err * akd;
@@ -396,7 +401,7 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
     float q = acos_c(twist.w) * 2.0f * sgn;
     float qd = dot(j.w_err, axis_p);
-    const JointLimit L = load_limit(m, qds);
+    const JointLimit L = c.lim[0];
     float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], L.lo, L.up, L.ke, L.kd);
     t_total = axis_p * jf;
     v3 swing = cross(axis_p, axis_c);
@@ -418,7 +423,7 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       v3 axw = qrot(q_w, ax[k]);
-      const JointLimit L = load_limit(m, qds + k);
+      const JointLimit L = c.lim[k];
       float jf = joint_force(ang[k], dot(axw, j.w_err), tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
       t_total += axw * jf;
     }
@@ -438,7 +443,6 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
   JointCtx j;
   joint_ctx(c, s, rc_c, rec, j);
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
-  const int qds = c.qdstart;
   v3 f_raw = j.x_err * ake + j.v_err * akd;
   v3 f_total = ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) ? clamp3(f_raw, 1.0e4f) : f_raw;
   v3 adj_t = -gc_t, adj_f = -gc_f, adj_r_c = V3(0, 0, 0), adj_r_p = V3(0, 0, 0);
@@ -470,7 +474,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
     float q = acos_c(twist.w) * 2.0f * sgn;
     float qd = dot(j.w_err, axis_p);
-    const JointLimit L = load_limit(m, qds);
+    const JointLimit L = c.lim[0];
     float lo = L.lo, up = L.up, lke = L.ke, lkd = L.kd;
     float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], lo, up, lke, lkd);
     adj_x_err += adj_f * ake; adj_v_err += adj_f * akd;
@@ -510,7 +514,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       axw[k] = qrot(q_w, ax[k]); qdk[k] = dot(axw[k], j.w_err);
-      const JointLimit L = load_limit(m, qds + k);
+      const JointLimit L = c.lim[k];
       jf[k] = joint_force(ang[k], qdk[k], tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
       t_raw += axw[k] * jf[k];
     }
@@ -526,7 +530,7 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
       v3 adj_axw = adj_t_raw * jf[k];
       float adj_qdk = 0.f;
       a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f;
-      const JointLimit L = load_limit(m, qds + k);
+      const JointLimit L = c.lim[k];
       joint_force_adj(ang[k], qdk[k], tgt[k], ke[k], kd[k], L.lo, L.up, L.ke, L.kd, adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k],
                       a_kd[k], a_act[k]);
       adj_axw += j.w_err * adj_qdk; adj_w_err += axw[k] * adj_qdk;
@@ -589,17 +593,16 @@ PD_DEV RevCache rev_cache_load(const float *d) {
   return R;
 }
 
-PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 w_c, const float *rec, float tgt, float act, float ke,
+// pp, qp, w_p: pose and angular velocity of the parent body (ignored for a joint to the world)
+PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 w_c, v3 pp, qt qp, v3 w_p, float tgt, float act, float ke,
                             float kd) {
   RevCache R;
   R.x_p = c.p_pj; R.q_p = c.q_pj;
-  v3 w_p = V3(0, 0, 0);
   if (c.parent >= 0) {
-    const float *r = rec + c.parent * PD_REC;
-    const qt qp = ld4(r + 3);
-    w_p = ld3(r + 7);
-    R.x_p = ld3(r) + qrot(qp, c.p_pj);
+    R.x_p = pp + qrot(qp, c.p_pj);
     R.q_p = qmul(qp, c.q_pj);
+  } else {
+    w_p = V3(0, 0, 0);
   }
   R.r_err = qmul(qconj(R.q_p), q_c);
   R.axis_p = qrot(R.q_p, c.axis);
@@ -611,7 +614,7 @@ PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 
   R.q = acos_c(twist.w) * 2.0f * sgn;
   R.dq = -2.0f * sgn * inv_sqrt_1mx2(twist.w);
   R.qd = dot(w_c - w_p, R.axis_p);
-  const JointLimit L = load_limit(m, c.qdstart);
+  const JointLimit L = c.lim[0];
   R.jf = joint_force(R.q, R.qd, tgt, ke, kd, act, L.lo, L.up, L.ke, L.kd);
   return R;
 }
@@ -645,7 +648,7 @@ PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState
   adj_cross(R.axis_p, R.axis_c, adj_axis_p, adj_axis_c, adj_t * ake);
   float adj_q = 0.f;
   a_tgt = 0.f; a_act = 0.f; a_ke = 0.f; a_kd = 0.f;
-  const JointLimit L = load_limit(m, c.qdstart);
+  const JointLimit L = c.lim[0];
   joint_force_adj(R.q, R.qd, tgt, ke, kd, L.lo, L.up, L.ke, L.kd, adj_jf, adj_q, adj_qd, a_tgt, a_ke, a_kd, a_act);
   adj_w_err += R.axis_p * adj_qd; adj_axis_p += w_err * adj_qd;
   qt adj_tq = Q4(0, 0, 0, 0);

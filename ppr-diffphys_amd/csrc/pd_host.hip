@@ -24,7 +24,7 @@ struct pd_model {
   int segw = 0, jt = 0;
   void *blob = nullptr;
   PdDevModel dev{};
-  size_t lds_rollout = 0, lds_fk = 0;
+  size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;
   // timing
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   bool ev_valid[2] = {false, false};
@@ -217,10 +217,14 @@ static int build_device(pd_model *m, int segw) {
   m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
                    (size_t)envs_per_block * d.env_lds_floats * 4;
+  // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
+  d.env_lds_jc = ((nb * PD_JC + 3) / 4) * 4;
+  m->lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + d.env_lds_jc) * 4 : m->lds_rollout;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
+  if (m->lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   if (m->lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   m->segw = segw; m->jt = jt;
-  int lds_max = (int)std::max(m->lds_rollout, m->lds_fk);
+  int lds_max = (int)std::max(std::max(m->lds_rollout, m->lds_rollout_bwd), m->lds_fk);
   e = segw == 16 ? pd_set_lds_seg16(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32(jt, lds_max) : pd_set_lds_seg64(jt, lds_max));
   if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(LDS)");
   return 0;
@@ -297,7 +301,7 @@ int pd_model_set_segment_width(pd_model *m, int lanes) {
 int pd_model_get_segment_width(const pd_model *m) { return m ? m->segw : 0; }
 
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
-  return m ? (size_t)nsteps * 19 * (size_t)bs * m->nb + (size_t)nsteps * (size_t)bs * PD_HITLOG : 0;  // + hit log (ints)
+  return m ? (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb + (size_t)nsteps * (size_t)bs * PD_HITLOG : 0;  // + hit log (ints)
 }
 
 int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
@@ -315,7 +319,7 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.res_f = res_f; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = frame_of_step; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
-  a.hitlog = (int *)(ws + (size_t)nsteps * 19 * (size_t)bs * m->nb);
+  a.hitlog = (int *)(ws + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, m->lds_rollout, st);
@@ -344,10 +348,10 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.frame_of_step = frame_of_step; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
-  a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * 19 * (size_t)bs * m->nb);
+  a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
-  hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout, st);
+  hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout_bwd, st);
   timing_end(m, 1, st);
   g_last_model = m;
   return e == hipSuccess ? 0 : hip_fail(e, "rollout_backward launch");

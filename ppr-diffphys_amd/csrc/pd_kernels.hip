@@ -33,6 +33,28 @@ __device__ __forceinline__ unsigned long long pd_memtime() {
 #endif
 
 
+// The hardware returns vector-memory results in issue order, so waiting for ANY load issued after a batch of prefetches
+// waits for the whole batch.  The rollout loops therefore consume nothing they load in the same iteration: every
+// global load is a prefetch for the next iteration, and the iteration opens with one explicit "everything older has
+// landed" wait (free: those loads are an iteration old), which also tells the compiler that no later wait is needed.
+#define PD_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0), expcnt / lgkmcnt untouched
+
+// Global accesses of the rollout loops: wave-uniform base (step, plane: scalar registers and scalar arithmetic) plus a
+// per-lane 32-bit BYTE offset computed once, i.e. the saddr + voffset addressing mode -- no per-lane 64-bit multiplies
+// in the loops.  Offsets stay below 4 GB for any batch that fits the workspace.
+PD_DEV float ldg(const float *ubase, unsigned boff) { return *(const float *)((const char *)ubase + boff); }
+PD_DEV void stg(float *ubase, unsigned boff, float v) { *(float *)((char *)ubase + boff) = v; }
+PD_DEV float4 ldg4(const float *ubase, unsigned boff) { return *(const float4 *)((const char *)ubase + boff); }
+PD_DEV void stg4(float *ubase, unsigned boff, float4 v) { *(float4 *)((char *)ubase + boff) = v; }
+PD_DEV float2 ldg2(const float *ubase, unsigned boff) { return *(const float2 *)((const char *)ubase + boff); }
+PD_DEV void stg2(float *ubase, unsigned boff, float2 v) { *(float2 *)((char *)ubase + boff) = v; }
+
+// Saved trajectory (workspace): per step PD_TRAJ_G planes of float4, [step][plane][bs*nb]; consecutive lanes touch consecutive
+// 16-byte words, and a step costs 5 vector-memory instructions per lane instead of 19 (their issue rate, not the bytes,
+// is what the rollout loops feel).  Planes:  0: q   1: (w, v.x)   2: (p, v.y)   3: (v.z, t)   4: (f, 0)
+// where (t, f) is the total body wrench of the step.  The adjoint's contact wave needs planes 0-1 of a body and 0-2 of its parent.
+#define PD_TRAJ_G 5
+
 template <int SEGW>
 struct Seg {
   static constexpr int EPW = 64 / SEGW;
@@ -326,9 +348,15 @@ PD_DEV float sink_margin(const BodyConst &c, const BodyState &s, float dt) {
   return (float)PD_SPEC_K * (1.5f * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + 2e-4f);
 }
 
-// Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.
-template <int NT>
-PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot) {  // all NT threads of the workgroup
+// Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.  COPY = false leaves
+// the tables in global memory (wave-specialised adjoint: it replays the forward's hit log and fetches the few points it
+// needs a step ahead, so the ~75 KB of LDS go to the joint hand-over records instead).
+template <int NT, bool COPY>
+PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot, int env_floats) {  // all NT threads of the workgroup
+  if (!COPY) {
+    T.pts = m.pts; T.tlo = m.tile_lo; T.thi = m.tile_hi; T.mats = m.materials; T.tpack = m.tile_pack; T.btiles = m.body_tiles; T.pmat = m.pt_mat;
+    return (float *)smem + (size_t)env_slot * env_floats;
+  }
   const int nc4 = m.nc > 0 ? m.nc : 1, nt4 = m.ntiles > 0 ? m.ntiles : 1, nm4 = m.nmat > 0 ? m.nmat : 1;
   const int nbp = (m.nb + 1) & ~1, ncb = (nc4 + 15) & ~15, ntp = (nt4 + 3) & ~3;
   float4 *pts = (float4 *)smem;
@@ -345,7 +373,7 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
   for (int i = threadIdx.x; i < ncb / 4; i += NT) ((unsigned int *)pmt)[i] = ((const unsigned int *)m.pt_mat)[i];
   __syncthreads();
   T.pts = pts; T.tlo = tlo; T.thi = thi; T.mats = mat; T.tpack = tpk; T.btiles = btl; T.pmat = pmt;
-  return (float *)(pmt + ncb) + (size_t)env_slot * m.env_lds_floats;  // env_lds_floats is a multiple of 4: 16-B aligned
+  return (float *)(pmt + ncb) + (size_t)env_slot * env_floats;  // env_floats is a multiple of 4: 16-B aligned
 }
 
 // =============================================================================================
@@ -367,7 +395,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
+  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), true>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats);
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
   // speculative cull vectors of the two latest states (by step parity) + the env's "speculation failed" flag; they live
@@ -487,22 +515,27 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   }
   if (SPLIT && l == 0) *spec_bad = 1;  // nothing is speculated for step 0
 
-  float *traj_q = a.ws, *traj_qd = a.ws + (size_t)a.nsteps * 7 * N, *traj_f = a.ws + (size_t)a.nsteps * 13 * N;
   // Controls are software-prefetched one step ahead: with one wavefront per SIMD there is no other
   // wave to hide the HBM latency of a load issued at its point of use.
+  const unsigned boff = (unsigned)idx * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;  // per-lane byte offsets
   float n_tgt[ND], n_act[ND], n_rf[6];
+  int n_fr = -1;  // frame that state `step` is gathered into (or -1), fetched with the controls
   auto load_controls = [&](int step) {
-    const int sc = step < a.nsteps ? step : a.nsteps - 1;
-    const size_t o = (size_t)sc * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
+    const int sc = __builtin_amdgcn_readfirstlane(step < a.nsteps ? step : a.nsteps - 1);  // keeps the address arithmetic scalar
+    n_fr = a.frame_of_step[sc];
+    const size_t o = (size_t)sc * a.bs * m.nqd;
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
       bool on = k < ndof;
-      n_tgt[k] = on ? a.refs[o + k] : 0.f;
-      n_act[k] = on ? a.torques[o + k] : 0.f;
+      n_tgt[k] = on ? ldg(a.refs + o + k, boff_qd) : 0.f;
+      n_act[k] = on ? ldg(a.torques + o + k, boff_qd) : 0.f;
     }
-    const float *rf = a.res_f + ((size_t)sc * N + idx) * 6;
+    const float *rf = a.res_f + (size_t)sc * N * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) n_rf[k] = rf[k];
+    for (int k = 0; k < 3; ++k) {
+      const float2 v = ldg2(rf + 2 * k, boff * 6u);
+      n_rf[2 * k] = v.x; n_rf[2 * k + 1] = v.y;
+    }
   };
   if (a.nsteps > 0) load_controls(0);
   STAMP_DECL;
@@ -513,19 +546,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       __syncthreads();  // A: hand this step's records to the contact wave
     }
     STAMP(0);
+    PD_WAIT_VMEM();
     float tgt[ND], act[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
     v3 ft = V3(n_rf[0], n_rf[1], n_rf[2]), ff = V3(n_rf[3], n_rf[4], n_rf[5]);  // clear_forces + wp_add
+    const int fr = n_fr;
     load_controls(step + 1);
-    // spill the state for the adjoint (SoA planes: lanes of a wave write consecutive floats)
-    if (is_body) {
-      float *tq = traj_q + (size_t)step * 7 * N + idx, *td = traj_qd + (size_t)step * 6 * N + idx;
-      tq[0] = s.p.x; tq[(size_t)N] = s.p.y; tq[(size_t)2 * N] = s.p.z;
-      tq[(size_t)3 * N] = s.r.x; tq[(size_t)4 * N] = s.r.y; tq[(size_t)5 * N] = s.r.z; tq[(size_t)6 * N] = s.r.w;
-      td[0] = s.w.x; td[(size_t)N] = s.w.y; td[(size_t)2 * N] = s.w.z;
-      td[(size_t)3 * N] = s.v.x; td[(size_t)4 * N] = s.v.y; td[(size_t)5 * N] = s.v.z;
-    }
     if (!SPLIT) {
       WAVE_SYNC();
       int log_n;
@@ -533,7 +560,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
                                            is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY, log_n, contact_hit STAMP_PASS);
       write_hit_log<SEGW>(a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, hits, log_n, env_ok, l);
     }
-    const int fr = a.frame_of_step[step];
     STAMP(1);
     // ---- eval_body_joints (runs while the contact wave sweeps)
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
@@ -576,9 +602,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     const v3 grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
     ft += jt; ff += jf;
     if (is_body) {
-      float *tf = traj_f + (size_t)step * 6 * N + idx;
-      tf[0] = ft.x; tf[(size_t)N] = ft.y; tf[(size_t)2 * N] = ft.z;
-      tf[(size_t)3 * N] = ff.x; tf[(size_t)4 * N] = ff.y; tf[(size_t)5 * N] = ff.z;
+      // spill the state and the total wrench of this step for the adjoint
+      float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
+      stg4(tj, boff * 4u, make_float4(s.r.x, s.r.y, s.r.z, s.r.w));
+      stg4(tj + (size_t)4 * N, boff * 4u, make_float4(s.w.x, s.w.y, s.w.z, s.v.x));
+      stg4(tj + (size_t)8 * N, boff * 4u, make_float4(s.p.x, s.p.y, s.p.z, s.v.y));
+      stg4(tj + (size_t)12 * N, boff * 4u, make_float4(s.v.z, ft.x, ft.y, ft.z));
+      stg4(tj + (size_t)16 * N, boff * 4u, make_float4(ff.x, ff.y, ff.z, 0.f));
       if (fr >= 0) {  // frame gather (dp_model.py:1231-1248)
         float *o = a.wp_pos + ((size_t)fr * N + idx) * 7;
         o[0] = s.p.x; o[1] = s.p.y; o[2] = s.p.z; o[3] = s.r.x; o[4] = s.r.y; o[5] = s.r.z; o[6] = s.r.w;
@@ -638,11 +668,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK)>(m, smem, tabs, wave * EPW + seg);
+  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), !SPLIT>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats + (SPLIT ? m.env_lds_jc : 0));
   float4 *cull = (float4 *)scratch;
   float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
   int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
+  float *jc = scratch + m.env_lds_floats;  // SPLIT: revolute joint hand-over records, PD_JC floats per body
 
   BodyConst c = load_body_const(m, b);
 #pragma unroll
@@ -654,22 +685,122 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     adj_store(out, o);
   };
   if (SPLIT && contact_wave) {
-    // ---- contact wave: adjoint of eval_body_contacts for the partner body wave's envs, between barriers A and B
+    // ---- contact wave.  Per step:
+    //   .. A  : (idle time of the old design) nothing here waits for the body wave: fetch the hit list the forward
+    //           sweep logged for the NEXT iteration, the points / materials of this iteration's hits, and the stored
+    //           pose of this lane's body and its parent; recompute the state-only half of the revolute joint's
+    //           adjoint (rev_forward) and hand it to the body wave through LDS
+    //   A..B  : wrench adjoints are staged: adjoint of eval_body_contacts for the logged hits, one lane per hit,
+    //           summed per body in hit order by a lane-per-component pass
+    // A log that did not fit (count -1) or holds more hits than the segment has lanes takes the generic sweep.
     STAMP_DECL;
+    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE;
+    const size_t qd_off = (size_t)ec * m.nqd + c.qdstart;
+    const float ke1 = rev ? a.target_ke[qd_off] : 0.f, kd1 = rev ? a.target_kd[qd_off] : 0.f;
+    const int lq = l < PD_HITLOG - 1 ? l : PD_HITLOG - 2;
+    const unsigned boff_c = (unsigned)((size_t)ec * nb + b) * 4u, boff_p = (unsigned)((size_t)ec * nb + (c.parent >= 0 ? c.parent : b)) * 4u;
+    const unsigned boff_qd = (unsigned)qd_off * 4u, boff_lg = (unsigned)ec * (PD_HITLOG * 4u);
+    auto load_log = [&](int step, int &cnt, int &e) {
+      const int *lg = a.hitlog + (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * a.bs * PD_HITLOG;
+      cnt = __float_as_int(ldg((const float *)lg, boff_lg)); e = __float_as_int(ldg((const float *)lg + 1, boff_lg + (unsigned)lq * 4u));
+    };
+    auto load_ctrl = [&](int step, float &tgt, float &act) {
+      const size_t o = (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * a.bs * m.nqd;
+      tgt = rev ? ldg(a.refs + o, boff_qd) : 0.f; act = rev ? ldg(a.torques + o, boff_qd) : 0.f;
+    };
+    auto fetch_point = [&](int cnt, int &e, float4 &P, float4 &M) {  // entries past the count are uninitialised memory
+      if (!(env_ok && l < cnt && l < PD_HITLOG - 1)) e = 0;
+      P = m.pts[e & 0xffff]; M = m.materials[(e >> 16) & 0xff];
+    };
+    // stored pose of this lane's body (q, w) and of its parent (p, q, w), one iteration ahead like everything else here
+    auto load_pose = [&](int step, float4 *o) {
+      const float *tj = a.ws + (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * (PD_TRAJ_G * 4) * N;
+      if (rev) {
+        o[0] = ldg4(tj, boff_c * 4u); o[1] = ldg4(tj + (size_t)4 * N, boff_c * 4u);
+        o[2] = ldg4(tj, boff_p * 4u); o[3] = ldg4(tj + (size_t)4 * N, boff_p * 4u); o[4] = ldg4(tj + (size_t)8 * N, boff_p * 4u);
+      }
+    };
+    int cnt_c = 0, e_c = 0, cnt_n = 0, e_n = 0;
+    float4 P_c, M_c;
+    float tgt_c = 0.f, act_c = 0.f;
+    float4 pose[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) pose[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.nsteps > 0) {
+      load_log(a.nsteps - 1, cnt_c, e_c); load_ctrl(a.nsteps - 1, tgt_c, act_c); load_pose(a.nsteps - 1, pose);
+      load_log(a.nsteps - 2, cnt_n, e_n);
+      fetch_point(cnt_c, e_c, P_c, M_c);
+    }
     for (int step = a.nsteps - 1; step >= 0; --step) {
-      // the forward sweep logged this step's hit list: fetch its length before the barrier (latency hidden by the wait)
-      int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
-      const int cnt = env_ok ? lg[0] : 0;
-      __syncthreads();  // A: records, cull vectors and wrench adjoints (adjf) of this step are staged; cacc is zero
+      PD_WAIT_VMEM();
+      // the body wave finished reading the previous hand-over records at barrier B
+      if (rev)
+        rev_cache_store(jc + b * PD_JC, rev_forward(m, c, Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), V3(pose[1].x, pose[1].y, pose[1].z),
+                                                    V3(pose[4].x, pose[4].y, pose[4].z), Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w),
+                                                    V3(pose[3].x, pose[3].y, pose[3].z), tgt_c, act_c, ke1, kd1));
+      STAMP(8);
+      // request everything the next iteration needs; nothing loaded here is touched before the next PD_WAIT_VMEM
+      float tgt_n, act_n;
+      float4 P_n, M_n;
+      int cnt_n2, e_n2;
+      fetch_point(cnt_n, e_n, P_n, M_n);
+      load_ctrl(step - 1, tgt_n, act_n);
+      load_pose(step - 1, pose);
+      load_log(step - 2, cnt_n2, e_n2);
+      const bool fast = __ballot(env_ok && (cnt_c < 0 || cnt_c > SEGW)) == 0ull;  // wave-uniform
+      const int nh = fast && env_ok ? cnt_c : 0;
+      if (fast) hits[l] = e_c;  // body ids for the summation pass
       STAMP(7);
-      float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
-      if (is_body) cv = cull[b];
-      const bool replay = __ballot(cnt < 0) == 0ull;  // -1: the list did not fit the log, cull again (whole wave)
-      int log_n_unused;
-      sweep_contacts<SEGW, PD_ADJ, PD_ADJ, !SPLIT>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, env_ok, seg, l,
-                                                   replay ? lg : nullptr, replay ? cnt : PD_NO_REPLAY, log_n_unused, contact_hit STAMP_PASS);
+      __syncthreads();  // A: records, cull vectors and wrench adjoints (adjf) of this step are staged; cacc is zero
+      STAMP(9);
+      if (fast) {
+        if (l < nh) {
+          float out[PD_ADJ];
+          contact_hit(rec + ((e_c >> 24) & 0x3f) * PD_REC, P_c, M_c, out);
+#pragma unroll
+          for (int i = 0; i < PD_ADJ; ++i) slot[l * PD_ADJ + i] = out[i];
+        }
+        STAMP(10);
+        WAVE_SYNC();
+        // lane i sums component i over the hits of each body, in hit order (the hits of a body are contiguous)
+        float acc = 0.f;
+        int cur = -1;
+        for (int t0 = 0; __ballot(t0 < nh) != 0ull; t0 += 4) {
+          int pb[4];
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool on = t0 + u < nh && l < PD_ADJ;
+            pb[u] = on ? (hits[t0 + u] >> 24) & 0x3f : -1;
+            v[u] = on ? slot[(t0 + u) * PD_ADJ + l] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (pb[u] >= 0) {
+              if (pb[u] != cur) {
+                if (cur >= 0) cacc[cur * PD_ADJ + l] = acc;
+                acc = 0.f; cur = pb[u];
+              }
+              acc += v[u];
+            }
+          }
+        }
+        if (cur >= 0) cacc[cur * PD_ADJ + l] = acc;
+        STAMP(11);
+      } else {
+        float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (is_body) cv = cull[b];
+        int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
+        const bool replay = __ballot(env_ok && cnt_c < 0) == 0ull;  // -1: the list did not fit the log, cull again (whole wave)
+        int log_n_unused;
+        sweep_contacts<SEGW, PD_ADJ, PD_ADJ, false>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, env_ok, seg, l,
+                                                    replay ? lg : nullptr, replay ? (env_ok ? cnt_c : 0) : PD_NO_REPLAY, log_n_unused,
+                                                    contact_hit STAMP_PASS);
+      }
       STAMP(12);
       __syncthreads();  // B: contact adjoints are complete
+      cnt_c = cnt_n; e_c = e_n; P_c = P_n; M_c = M_n; tgt_c = tgt_n; act_c = act_n;
+      cnt_n = cnt_n2; e_n = e_n2;
     }
     STAMP_FLUSH(a);
     return;
@@ -696,47 +827,48 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     for (int k = 0; k < PD_ADJ; ++k) cacc[b * PD_ADJ + k] = 0.f;
   }
 
-  const float *traj_q = a.ws, *traj_qd = a.ws + (size_t)a.nsteps * 7 * N, *traj_f = a.ws + (size_t)a.nsteps * 13 * N;
   BodyAdj gn = adj_zero();  // adjoint of state step+1
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
 
   // The stored state, wrench and controls of the NEXT iteration (step - 1) are software-prefetched.
-  float n_s[19], n_tgt[ND], n_act[ND];
+  const unsigned boff = (unsigned)idx * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;  // per-lane byte offsets
+  float4 n_s[PD_TRAJ_G];
+  float n_tgt[ND], n_act[ND];
+  int n_fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
   auto load_step = [&](int step) {
-    const int sc = step >= 0 ? step : 0;
-    const float *tq = traj_q + (size_t)sc * 7 * N + idx, *td = traj_qd + (size_t)sc * 6 * N + idx;
-    const float *tf = traj_f + (size_t)sc * 6 * N + idx;
+    const int sc = __builtin_amdgcn_readfirstlane(step >= 0 ? step : 0);  // keeps the address arithmetic scalar
+    n_fr = a.frame_of_step[sc + 1];
+    const float *tj = a.ws + (size_t)sc * (PD_TRAJ_G * 4) * N;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) n_s[k] = tq[(size_t)k * N];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { n_s[7 + k] = td[(size_t)k * N]; n_s[13 + k] = tf[(size_t)k * N]; }
-    const size_t o = (size_t)sc * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
+    for (int g = 0; g < PD_TRAJ_G; ++g) n_s[g] = ldg4(tj + (size_t)(4 * g) * N, boff * 4u);
+    const size_t o = (size_t)sc * a.bs * m.nqd;
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
       bool on = k < ndof;
-      n_tgt[k] = on ? a.refs[o + k] : 0.f;
-      n_act[k] = on ? a.torques[o + k] : 0.f;
+      n_tgt[k] = on ? ldg(a.refs + o + k, boff_qd) : 0.f;
+      n_act[k] = on ? ldg(a.torques + o + k, boff_qd) : 0.f;
     }
   };
   if (a.nsteps > 0) load_step(a.nsteps - 1);
   STAMP_DECL;
   for (int step = a.nsteps - 1; step >= 0; --step) {
+    PD_WAIT_VMEM();
     {  // seeds of state step+1 (dp_model.py:1264-1271)
-      int fr = a.frame_of_step[step + 1];
+      const int fr = n_fr;
       if (fr >= 0) {
         const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
         gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
         gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
       }
     }
-    s.p = V3(n_s[0], n_s[1], n_s[2]); s.r = Q4(n_s[3], n_s[4], n_s[5], n_s[6]);
-    s.w = V3(n_s[7], n_s[8], n_s[9]); s.v = V3(n_s[10], n_s[11], n_s[12]);
-    v3 t0 = V3(n_s[13], n_s[14], n_s[15]), f0 = V3(n_s[16], n_s[17], n_s[18]);
+    s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
+    s.p = V3(n_s[2].x, n_s[2].y, n_s[2].z); s.v = V3(n_s[1].w, n_s[2].w, n_s[3].x);
+    v3 t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w), f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
     float tgt[ND], act[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
-    const size_t oc = (size_t)step * a.bs * m.nqd + (size_t)ec * m.nqd + c.qdstart;
+    const size_t oc = (size_t)step * a.bs * m.nqd;  // uniform part; the lane part is boff_qd
     load_step(step - 1);
     // unsplit kernels replay the forward hit list inline further down: fetch its length now, far ahead of its use
     int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
@@ -749,8 +881,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     v3 adj_t0, adj_f0;
     integrate_adj(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
     if (is_body) {
-      float *o = a.g_res_f + ((size_t)step * N + idx) * 6;  // adjoint of wp_add
-      o[0] = adj_t0.x; o[1] = adj_t0.y; o[2] = adj_t0.z; o[3] = adj_f0.x; o[4] = adj_f0.y; o[5] = adj_f0.z;
+      float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
+      stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
+      stg2(o + 4, boff * 6u, make_float2(adj_f0.y, adj_f0.z));
       float *f = adjf + b * PD_W6;
       f[0] = adj_t0.x; f[1] = adj_t0.y; f[2] = adj_t0.z; f[3] = adj_f0.x; f[4] = adj_f0.y; f[5] = adj_f0.z;
     }
@@ -765,18 +898,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (is_body && c.type != PD_JOINT_FREE) {
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
       if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-      joint_adj<JT>(m, c, s, rc, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
+      if (SPLIT)  // revolute only: the state-only half was computed by the contact wave
+        rev_adjoint(m, c, s, rc, rec, rev_cache_load(jc + b * PD_JC), tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt[0],
+                    a_act[0], a_ke[0], a_kd[0]);
+      else
+        joint_adj<JT>(m, c, s, rc, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
     }
     if (is_body) {
       adj_store(cslot + b * PD_ADJ, par);
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
-        if (k < ndof) { a.g_refs[oc + k] = a_tgt[k]; a.g_torques[oc + k] = a_act[k]; }
+        if (k < ndof) { stg(a.g_refs + oc + k, boff_qd, a_tgt[k]); stg(a.g_torques + oc + k, boff_qd, a_act[k]); }
         g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k];
       }
       if (c.type == PD_JOINT_FREE) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { a.g_refs[oc + k] = 0.f; a.g_torques[oc + k] = 0.f; }
+        for (int k = 0; k < 6; ++k) { stg(a.g_refs + oc + k, boff_qd, 0.f); stg(a.g_torques + oc + k, boff_qd, 0.f); }
       }
     }
     STAMP(2);

@@ -19,7 +19,7 @@ out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame_of_step=fos, nframes=len(f
 torch.cuda.synchronize()
 nb = int(tpl["nb"])
 ws = out[4]
-log = ws[T * 19 * bs * nb:].view(torch.int32).view(T, bs, -1).cpu().numpy()
+log = ws[T * 20 * bs * nb:].view(torch.int32).view(T, bs, -1).cpu().numpy()
 cnt = log[:, :, 0]
 epw = 64 // segw
 print("hits per env-step: mean %.2f  median %d  p90 %d  max %d  overflow(-1) %.3f%%" % (

@@ -40,8 +40,10 @@ fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints
 bn = [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"), (2, "wait A + joints adj + stores"),
       (3, "child gather"), (4, "wait B + cacc gather")]
 cn = [(7, "wait at barrier A/A1 (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
+cb = [(8, "joint state-only half -> LDS"), (7, "prefetch issue"), (9, "wait at barrier A"), (10, "contact adjoint per hit"),
+      (11, "per-body sums"), (12, "tail / generic sweep")]
 for lab, arr in (("FWD", f_all), ("BWD", b_all)):
-    for who, names, contact in (("body wave", fn if lab == "FWD" else bn, False), ("contact wave", cn, True)):
+    for who, names, contact in (("body wave", fn if lab == "FWD" else bn, False), ("contact wave", cn if lab == "FWD" else cb, True)):
         r = rows(arr, contact)
         tot = r[:, :13].sum(1).mean()
         print("%s %-12s waves=%d  cycles per step = %.0f" % (lab, who, len(r), tot / T))
