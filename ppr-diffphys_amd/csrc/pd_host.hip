@@ -212,13 +212,16 @@ static int build_device(pd_model *m, int segw) {
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
   // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
-  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
+  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;  // + PD_ADJ: the zero record
+  // lanes (env e, body b) of one wave address base_e + f(b): an env stride of 16 mod 32 floats lets the envs of a wave
+  // alternate between the two halves of the 32 LDS banks (2-way, the minimum for 64 lanes) instead of piling onto one
+  d.env_lds_floats += (16 - d.env_lds_floats % 32 + 32) % 32;
   const int envs_per_block = PD_BWAVES * (64 / segw);
   m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
                    (size_t)envs_per_block * d.env_lds_floats * 4;
   // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
-  d.env_lds_jc = ((nb * PD_JC + 3) / 4) * 4;
+  d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;  // keeps the env stride at 16 mod 32
   m->lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + d.env_lds_jc) * 4 : m->lds_rollout;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (m->lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");

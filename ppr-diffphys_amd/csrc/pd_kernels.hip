@@ -397,12 +397,14 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   SweepTables tabs;
   float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), true>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats);
   float4 *cull = (float4 *)scratch;
+  // pcon: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
   // speculative cull vectors of the two latest states (by step parity) + the env's "speculation failed" flag; they live
   // in the room the adjoint kernel's wider per-body slots leave in the shared per-env size
-  float4 *spec = (float4 *)(scratch + 36 * nb);  // 36 nb floats: 16-byte aligned like cull
-  int *spec_bad = (int *)(scratch + 44 * nb);
-  int *list = (int *)(scratch + 44 * nb + 4), *hits = list + m.list_cap;
+  const int spec_off = ((4 + PD_REC + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;  // 16-byte aligned like cull
+  float4 *spec = (float4 *)(scratch + spec_off);
+  int *spec_bad = (int *)(scratch + spec_off + 8 * nb);
+  int *list = spec_bad + 4, *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
 
   BodyConst c = load_body_const(m, b);
@@ -496,6 +498,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
 #pragma unroll
     for (int k = 0; k < 6; ++k) facc[b * PD_W6 + k] = 0.f;
   }
+  if (l == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) pcon[nb * PD_W6 + k] = 0.f;
+  }
+  int cz[4];  // first four children, the zero record for a missing one
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cz[k] = is_body && c.child[k] >= 0 ? c.child[k] : nb;
 
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
   BodyState s;
@@ -575,10 +584,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       float cw[4][6];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float *pc = pcon + (c.child[k] >= 0 ? c.child[k] : 0) * PD_W6;
-        const bool on = is_body && c.child[k] >= 0;
+        const float *pc = pcon + cz[k] * PD_W6;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) cw[k][i] = on ? pc[i] : 0.f;
+        for (int i = 0; i < 6; ++i) cw[k][i] = pc[i];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) { jt += V3(cw[k][0], cw[k][1], cw[k][2]); jf += V3(cw[k][3], cw[k][4], cw[k][5]); }
@@ -670,7 +678,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   SweepTables tabs;
   float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), !SPLIT>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats + (SPLIT ? m.env_lds_jc : 0));
   float4 *cull = (float4 *)scratch;
-  float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + nb * PD_ADJ;
+  // cslot: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
+  float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + (nb + 1) * PD_ADJ;
   int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
   float *jc = scratch + m.env_lds_floats;  // SPLIT: revolute joint hand-over records, PD_JC floats per body
@@ -678,6 +687,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   BodyConst c = load_body_const(m, b);
 #pragma unroll
   for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
+  if (l == 0) {
+#pragma unroll
+    for (int k = 0; k < PD_ADJ; ++k) cslot[nb * PD_ADJ + k] = 0.f;
+  }
+  int cz[4];  // first four children, the zero record for a missing one
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cz[k] = is_body && c.child[k] >= 0 ? c.child[k] : nb;
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {
     const int pb = (int)(r - rec) / PD_REC;
     BodyAdj o = adj_zero();
@@ -922,10 +938,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       float cw[4][PD_ADJ];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float *pc = cslot + (c.child[k] >= 0 ? c.child[k] : 0) * PD_ADJ;
-        const bool on = is_body && c.child[k] >= 0;
+        const float *pc = cslot + cz[k] * PD_ADJ;
 #pragma unroll
-        for (int i = 0; i < PD_ADJ; ++i) cw[k][i] = on ? pc[i] : 0.f;
+        for (int i = 0; i < PD_ADJ; ++i) cw[k][i] = pc[i];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) adj_add_from(ga, cw[k]);
