@@ -140,18 +140,21 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
   const int hi_all = nh < j0 + SEGW ? nh : j0 + SEGW;
   const int t_lo = (run_start > j0 ? run_start : j0) - j0;
   const int t_hi = (run_cnt > 0 ? (run_start + run_cnt < hi_all ? run_start + run_cnt : hi_all) : j0) - j0;
+  // the running sum continues from dst: the result is the plain left-to-right sum over the body's hits whatever the
+  // batch boundaries are (they move with entries that contribute exactly 0, and those depend on which path logged them)
   float acc[NV];
+  const bool mine = l < nb && t_lo < t_hi;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  for (int i = 0; i < NV; ++i) acc[i] = mine ? dst[l * DSTRIDE + i] : 0.f;
   for (int t = t_lo; __ballot(t < t_hi) != 0ull; ++t) {
     if (t < t_hi) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) acc[i] += slot[t * NV + i];
     }
   }
-  if (l < nb && t_lo < t_hi) {
+  if (mine) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) dst[l * DSTRIDE + i] += acc[i];
+    for (int i = 0; i < NV; ++i) dst[l * DSTRIDE + i] = acc[i];
   }
   WAVE_SYNC();
 }

@@ -458,3 +458,46 @@ def test_many_contacts_overflow_paths(segw, dev, oracle_libs):
     assert all(np.isfinite(v).all() for v in out["grads"].values())
     for k in ("q_init", "qd_init", "res_f", "refs", "body_inv_mass", "body_inertia"):
         assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+
+
+@pytest.mark.gpu
+def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle_libs):
+    """The wave-specialised forward culls ground contacts one epoch ahead with a per-body sink margin and must fall back
+    to the exact sweep when a body moves further than that.  Downward kicks of 3000 m/s^2 on every body from step 3 on
+    (|dv_y| = 1.5 m/s per step: the margin of the epoch's first state is outrun within two steps) force that path;
+    results must still match the oracle, and must not depend on how envs share a wave."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template("laikago")
+    bs, T = 24, 26
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=21, steps_per_frame=5, penetration=0.003)
+    nb = int(tpl["nb"])
+    rf = inp["res_f"].reshape(T, bs, nb, 6)
+    mass = inp["body_mass"].reshape(bs, nb)
+    kick = np.zeros((T, bs), np.float32)
+    kick[3:16, ::2] = 3000.0      # every other env: its wave-mates stay calm, the wave must still redo the sweep
+    kick[8:20, 1::4] = 1500.0
+    rf[..., 4] -= kick[:, :, None] * mass[None]
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert np.abs(st["grf"]).max() > 100.0, "the kicked robots must hit the ground hard"
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-4 and relmax(out["wp_vel"], st["wp_vel"]) < 5e-3
+    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 1e-2
+    for k in ("q_init", "qd_init", "res_f", "refs", "body_inv_mass"):
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+    # batch-composition invariance: the same envs alone (different wave-mates, different redo pattern) give the same bits
+    sub = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    pick = np.arange(1, bs, 3)
+    for k in ("q_init", "qd_init", "target_ke", "target_kd", "body_mass", "body_inv_mass", "body_inertia", "body_inv_inertia"):
+        sub[k] = inp[k].reshape(bs, -1)[pick].reshape(-1)
+    for k in ("torques", "refs", "res_f"):
+        sub[k] = inp[k].reshape(T, bs, -1)[:, pick].reshape(T, -1)
+    F = len(inp["frame2step"])
+    for k in ("adj_pos", "adj_vel"):
+        sub[k] = inp[k].reshape(F, bs, -1)[:, pick].reshape(F, -1)
+    out2 = gpu_rollout(hip_backend.DeviceModel(tpl), sub, dev)
+    assert np.array_equal(out2["wp_pos"].reshape(F, len(pick), -1), out["wp_pos"].reshape(F, bs, -1)[:, pick])
+    assert np.array_equal(out2["grads"]["q_init"].reshape(len(pick), -1), out["grads"]["q_init"].reshape(bs, -1)[pick])
