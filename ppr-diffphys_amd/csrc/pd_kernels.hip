@@ -42,6 +42,8 @@ __device__ __forceinline__ unsigned long long pd_memtime() {
 // Global accesses of the rollout loops: wave-uniform base (step, plane: scalar registers and scalar arithmetic) plus a
 // per-lane 32-bit BYTE offset computed once, i.e. the saddr + voffset addressing mode -- no per-lane 64-bit multiplies
 // in the loops.  Offsets stay below 4 GB for any batch that fits the workspace.
+typedef const __attribute__((address_space(4))) int *pd_const_int_p;  // constant address space => scalar (s_load) access
+PD_DEV int ld_uniform(const int *p, int i) { return ((pd_const_int_p)(unsigned long long)p)[i]; }  // read-only input, wave-uniform index
 PD_DEV float ldg(const float *ubase, unsigned boff) { return *(const float *)((const char *)ubase + boff); }
 PD_DEV void stg(float *ubase, unsigned boff, float v) { *(float *)((char *)ubase + boff) = v; }
 PD_DEV float4 ldg4(const float *ubase, unsigned boff) { return *(const float4 *)((const char *)ubase + boff); }
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   int n_fr = -1;  // frame that state `step` is gathered into (or -1), fetched with the controls
   auto load_controls = [&](int step) {
     const int sc = __builtin_amdgcn_readfirstlane(step < a.nsteps ? step : a.nsteps - 1);  // keeps the address arithmetic scalar
-    n_fr = a.frame_of_step[sc];
+    n_fr = ld_uniform(a.frame_of_step, sc);  // scalar load: no vector-memory instruction for a wave-uniform value
     const size_t o = (size_t)sc * a.bs * m.nqd;
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   int n_fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
   auto load_step = [&](int step) {
     const int sc = __builtin_amdgcn_readfirstlane(step >= 0 ? step : 0);  // keeps the address arithmetic scalar
-    n_fr = a.frame_of_step[sc + 1];
+    n_fr = a.frame_of_step[sc + 1];  // (a scalar load here couples the LDS waits to it through lgkmcnt: +2 %)
     const float *tj = a.ws + (size_t)sc * (PD_TRAJ_G * 4) * N;
 #pragma unroll
     for (int g = 0; g < PD_TRAJ_G; ++g) n_s[g] = ldg4(tj + (size_t)(4 * g) * N, boff * 4u);
