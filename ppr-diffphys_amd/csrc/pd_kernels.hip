@@ -80,6 +80,27 @@ PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
   return slot;
 }
 
+// Per-body sums of per-hit results held one hit per lane (lanes 0 .. nh-1 of the segment, hits of a body contiguous):
+// a serial chain of DPP lane shifts, step s folding lane s-1's finished prefix into lane s.  It reproduces the plain
+// left-to-right sum -- the order of the ds_add_f32 path and of every other path, so results do not depend on which path
+// ran, and entries that contribute exactly 0 may sit anywhere -- without touching LDS.  On return the LAST lane of each
+// body's run holds that body's totals.  2 NV VALU instructions per step (v_add_f32_dpp wave_shr:1 + v_cndmask).
+template <int NV>
+PD_DEV void seg_run_sum(float *acc, int pb, int l, int nh, bool &last) {
+  const int pbp = __builtin_amdgcn_update_dpp(-1, pb, 0x138, 0xf, 0xf, false);  // body of the hit one lane down (wave_shr:1)
+  const int pbn = __builtin_amdgcn_update_dpp(-1, pb, 0x130, 0xf, 0xf, false);  // ... one lane up (wave_shl:1)
+  const bool in = l < nh, cont = in && l > 0 && pbp == pb;
+  last = in && (l == nh - 1 || pbn != pb);
+  for (int s = 1; __ballot(s < nh) != 0ull; ++s) {
+    const bool upd = cont && l == s;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[i]), 0x138, 0xf, 0xf, true));
+      acc[i] = upd ? prev + acc[i] : acc[i];
+    }
+  }
+}
+
 // Ground-contact sweep for one segment (= one env).  Conservative three-level cull, then the exact
 // test of the reference inside on_hit.  All tables are in LDS (copied once per workgroup):
 //   L1  per body  : bounding sphere of all its candidate points vs y = 0               (lane = body)
@@ -452,6 +473,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       } else {
         // evaluate the candidates on the state that now exists: contact_hit applies the reference's exact test; the
         // ones that touch go to the adjoint's log straight away
+        // (per-body sums in registers, seg_run_sum, were measured here too: slower than the 6 ds_add_f32 of the few
+        // candidates that touch -- the chain runs over ALL candidates)
         for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW) {
           const int j = j0 + l;
           bool touching = false;
@@ -770,43 +793,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       load_log(step - 2, cnt_n2, e_n2);
       const bool fast = __ballot(env_ok && (cnt_c < 0 || cnt_c > SEGW)) == 0ull;  // wave-uniform
       const int nh = fast && env_ok ? cnt_c : 0;
-      if (fast) hits[l] = e_c;  // body ids for the summation pass
       STAMP(7);
       __syncthreads();  // A: records, cull vectors and wrench adjoints (adjf) of this step are staged; cacc is zero
       STAMP(9);
       if (fast) {
-        if (l < nh) {
-          float out[PD_ADJ];
-          contact_hit(rec + ((e_c >> 24) & 0x3f) * PD_REC, P_c, M_c, out);
+        float out[PD_ADJ];
 #pragma unroll
-          for (int i = 0; i < PD_ADJ; ++i) slot[l * PD_ADJ + i] = out[i];
-        }
+        for (int i = 0; i < PD_ADJ; ++i) out[i] = 0.f;
+        const int pb = l < nh ? (e_c >> 24) & 0x3f : -2;
+        if (l < nh) contact_hit(rec + pb * PD_REC, P_c, M_c, out);
         STAMP(10);
-        WAVE_SYNC();
-        // lane i sums component i over the hits of each body, in hit order (the hits of a body are contiguous)
-        float acc = 0.f;
-        int cur = -1;
-        for (int t0 = 0; __ballot(t0 < nh) != 0ull; t0 += 4) {
-          int pb[4];
-          float v[4];
+        bool last;
+        seg_run_sum<PD_ADJ>(out, pb, l, nh, last);
+        if (last) {  // cacc is zero (its owner clears it after reading) and a body has one run
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool on = t0 + u < nh && l < PD_ADJ;
-            pb[u] = on ? (hits[t0 + u] >> 24) & 0x3f : -1;
-            v[u] = on ? slot[(t0 + u) * PD_ADJ + l] : 0.f;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (pb[u] >= 0) {
-              if (pb[u] != cur) {
-                if (cur >= 0) cacc[cur * PD_ADJ + l] = acc;
-                acc = 0.f; cur = pb[u];
-              }
-              acc += v[u];
-            }
-          }
+          for (int i = 0; i < PD_ADJ; ++i) cacc[pb * PD_ADJ + i] = out[i];
         }
-        if (cur >= 0) cacc[cur * PD_ADJ + l] = acc;
         STAMP(11);
       } else {
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
