@@ -456,6 +456,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     const SegMask sm = seg_mask<SEGW>(seg);
     int nh = 0;         // speculated candidates of my env, hits[0, nh)
     bool have = false;  // wave-uniform: the candidates are there and nothing overwrote them
+    // When no env of the wave has more candidates than the segment has lanes (the usual case) lane j keeps candidate j --
+    // entry, point, material -- in registers for the whole epoch: the per-step hit pass then starts with the record read.
+    bool lane_owns = false;  // wave-uniform
+    int c_e = 0;
+    float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P;
     for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
       __syncthreads();  // A: records + cull vectors of this step are staged, wrench accumulators are zero
@@ -464,39 +469,59 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       STAMP_COUNT(13, redo ? 1 : 0);
       STAMP_COUNT(14, __shfl(nh, 0));
       int log_n = 0;
+      bool touching = false;  // lane_owns path: does my candidate touch (logged after barrier B)
       if (redo) {
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
         if (is_body) cv = cull[b];
         const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, cull, list, is_body, seg, l STAMP_PASS);
         sweep_points<SEGW, 6, PD_W6, true>(m, tabs, rec, cull, list, nlist, hits, slot, facc, seg, l, log_n, contact_hit STAMP_PASS);
         have = false;  // hits[] now holds this step's exact hits
+      } else if (lane_owns) {
+        // evaluate the candidates on the state that now exists: contact_hit applies the reference's exact test
+        if (l < nh) {
+          float out[6];
+          touching = contact_hit(rec + ((c_e >> 24) & 0x3f) * PD_REC, c_P, c_M, out);
+          if (touching) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) atomicAdd(facc + ((c_e >> 24) & 0x3f) * PD_W6 + i, out[i]);
+          }
+        }
+        STAMP(11);
       } else {
-        // evaluate the candidates on the state that now exists: contact_hit applies the reference's exact test; the
-        // ones that touch go to the adjoint's log straight away
+        // more candidates than lanes somewhere in the wave: batches out of the LDS list; the ones that touch go to the
+        // adjoint's log straight away
         // (per-body sums in registers, seg_run_sum, were measured here too: slower than the 6 ds_add_f32 of the few
         // candidates that touch -- the chain runs over ALL candidates)
         for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW) {
           const int j = j0 + l;
-          bool touching = false;
+          bool tch = false;
           int e = 0;
           if (j < nh) {
             e = hits[j];
             float out[6];
-            touching = contact_hit(rec + ((e >> 24) & 0x3f) * PD_REC, tabs.pts[e & 0xffff], tabs.mats[(e >> 16) & 0xff], out);
-            if (touching) {
+            tch = contact_hit(rec + ((e >> 24) & 0x3f) * PD_REC, tabs.pts[e & 0xffff], tabs.mats[(e >> 16) & 0xff], out);
+            if (tch) {
 #pragma unroll
               for (int i = 0; i < 6; ++i) atomicAdd(facc + ((e >> 24) & 0x3f) * PD_W6 + i, out[i]);
             }
           }
-          const int s = seg_slot(touching, sm, log_n);
-          if (touching && env_ok && s < PD_HITLOG - 1) lg[1 + s] = e;
+          const int s = seg_slot(tch, sm, log_n);
+          if (tch && env_ok && s < PD_HITLOG - 1) lg[1 + s] = e;
         }
         if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
         STAMP(11);
       }
       STAMP(12);
       __syncthreads();  // B: contact wrenches are complete
-      if (redo) write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);  // for the adjoint; off the critical path
+      // the adjoint's log is written off the critical path
+      if (redo) {
+        write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);
+      } else if (lane_owns) {
+        const int s = seg_slot(touching, sm, log_n);
+        if (touching && env_ok && s < PD_HITLOG - 1) lg[1 + s] = c_e;
+        if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
+      }
+      if (redo) lane_owns = false;
       if (step % PD_SPEC_K == 0 && step + 1 < a.nsteps) {  // state `step` opened an epoch: cull for the steps it serves
         WAVE_SYNC();  // the log is read out of hits[] before the candidates overwrite it
         const float4 *sp = spec + ((step / PD_SPEC_K) & 1) * nb;
@@ -504,6 +529,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
         if (is_body) cv = sp[b];
         const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, sp, list, is_body, seg, l STAMP_PASS);
         have = sweep_l3_spec<SEGW>(tabs, sp, list, nlist, hits, seg, l, nh);
+        lane_owns = have && __ballot(nh > SEGW) == 0ull;
+        if (lane_owns) {
+          c_e = l < nh ? hits[l] : 0;
+          c_P = tabs.pts[c_e & 0xffff]; c_M = tabs.mats[(c_e >> 16) & 0xff];
+        }
         STAMP(10);
       }
     }
