@@ -222,7 +222,7 @@ static int build_device(pd_model *m, int segw) {
                    (size_t)envs_per_block * d.env_lds_floats * 4;
   // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
   d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;  // keeps the env stride at 16 mod 32
-  m->lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + d.env_lds_jc) * 4 : m->lds_rollout;
+  m->lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + 2 * d.env_lds_jc) * 4 : m->lds_rollout;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (m->lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   if (m->lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");

@@ -101,6 +101,19 @@ PD_DEV void seg_run_sum(float *acc, int pb, int l, int nh, bool &last) {
   }
 }
 
+// Pairwise hand-over between a body wave and its contact wave through an LDS word (a step counter): the producer
+// publishes after a workgroup-scope release, the consumer polls.  Unlike s_barrier it does not tie the four wave pairs of
+// a workgroup together.
+PD_DEV void pair_signal(int *flag, int value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+PD_DEV void pair_wait(int *flag, int value) {
+  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < value)
+    __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Ground-contact sweep for one segment (= one env).  Conservative three-level cull, then the exact
 // test of the reference inside on_hit.  All tables are in LDS (copied once per workgroup):
 //   L1  per body  : bounding sphere of all its candidate points vs y = 0               (lane = body)
@@ -430,8 +443,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   const int spec_off = ((4 + PD_REC + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;  // 16-byte aligned like cull
   float4 *spec = (float4 *)(scratch + spec_off);
   int *spec_bad = (int *)(scratch + spec_off + 8 * nb);
+  int *sig = (int *)(scratch - (size_t)seg * m.env_lds_floats + spec_off + 8 * nb) + 1;  // pair signals: words 1, 2 after the first env's flag
   int *list = spec_bad + 4, *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
+  if (SPLIT) {
+    if (lane == 0) { sig[0] = 0; sig[1] = 0; }
+    __syncthreads();
+  }
 
   BodyConst c = load_body_const(m, b);
 #pragma unroll
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P;
     for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
-      __syncthreads();  // A: records + cull vectors of this step are staged, wrench accumulators are zero
+      pair_wait(sig, step + 1);  // A: records + cull vectors of this step are staged, wrench accumulators are zero
       STAMP(7);
       const bool redo = !have || __ballot(env_ok && *spec_bad != 0) != 0ull;  // wave-uniform
       STAMP_COUNT(13, redo ? 1 : 0);
@@ -512,7 +530,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
         STAMP(11);
       }
       STAMP(12);
-      __syncthreads();  // B: contact wrenches are complete
+      pair_signal(sig + 1, step + 1);  // B: contact wrenches are complete
       // the adjoint's log is written off the critical path
       if (redo) {
         write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     // barrier A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
     // contact wave starts sweeping while this wave still unpacks controls and spills the state
     if (SPLIT) {
-      __syncthreads();  // A: hand this step's records to the contact wave
+      pair_signal(sig, step + 1);  // A: hand this step's records to the contact wave
     }
     STAMP(0);
     PD_WAIT_VMEM();
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       }
     }
     STAMP(6);
-    if (SPLIT) __syncthreads();  // B: contact wrenches are complete
+    if (SPLIT) pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
     else WAVE_SYNC();
     if (is_body) {
       float *f = facc + b * PD_W6;
@@ -734,13 +752,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), !SPLIT>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats + (SPLIT ? m.env_lds_jc : 0));
+  const int env_stride = m.env_lds_floats + (SPLIT ? 2 * m.env_lds_jc : 0);
+  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), !SPLIT>(m, smem, tabs, wave * EPW + seg, env_stride);
   float4 *cull = (float4 *)scratch;
   // cslot: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
   float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + (nb + 1) * PD_ADJ;
   int *list = (int *)(cacc + nb * PD_ADJ), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
-  float *jc = scratch + m.env_lds_floats;  // SPLIT: revolute joint hand-over records, PD_JC floats per body
+  // SPLIT: revolute joint hand-over records, PD_JC floats per body, two generations (by step parity: the contact wave
+  // writes step k - 1's while the body wave may still read step k's)
+  float *jc = scratch + m.env_lds_floats;
+  // pair signals: the spare words at the end of the first env's area
+  int *sig = (int *)(scratch - (size_t)seg * env_stride + m.env_lds_floats - 4);
+  if (SPLIT) {
+    if (lane == 0 && !contact_wave) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
+    __syncthreads();
+  }
 
   BodyConst c = load_body_const(m, b);
 #pragma unroll
@@ -809,7 +836,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       PD_WAIT_VMEM();
       // the body wave finished reading the previous hand-over records at barrier B
       if (rev)
-        rev_cache_store(jc + b * PD_JC, rev_forward(m, c, Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), V3(pose[1].x, pose[1].y, pose[1].z),
+        rev_cache_store(jc + (step & 1) * m.env_lds_jc + b * PD_JC, rev_forward(m, c, Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), V3(pose[1].x, pose[1].y, pose[1].z),
                                                     V3(pose[4].x, pose[4].y, pose[4].z), Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w),
                                                     V3(pose[3].x, pose[3].y, pose[3].z), tgt_c, act_c, ke1, kd1));
       STAMP(8);
@@ -824,7 +851,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       const bool fast = __ballot(env_ok && (cnt_c < 0 || cnt_c > SEGW)) == 0ull;  // wave-uniform
       const int nh = fast && env_ok ? cnt_c : 0;
       STAMP(7);
-      __syncthreads();  // A: records, cull vectors and wrench adjoints (adjf) of this step are staged; cacc is zero
+      // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
+      pair_signal(sig + 1, a.nsteps - step);
+      pair_wait(sig, a.nsteps - step);
       STAMP(9);
       if (fast) {
         float out[PD_ADJ];
@@ -851,7 +880,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
                                                     contact_hit STAMP_PASS);
       }
       STAMP(12);
-      __syncthreads();  // B: contact adjoints are complete
+      pair_signal(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
       cnt_c = cnt_n; e_c = e_n; P_c = P_n; M_c = M_n; tgt_c = tgt_n; act_c = act_n;
       cnt_n = cnt_n2; e_n = e_n2;
     }
@@ -941,8 +970,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       f[0] = adj_t0.x; f[1] = adj_t0.y; f[2] = adj_t0.z; f[3] = adj_f0.x; f[4] = adj_f0.y; f[5] = adj_f0.z;
     }
     STAMP(1);
-    if (SPLIT) __syncthreads();  // A: hand records + wrench adjoints to the contact wave
-    else WAVE_SYNC();
+    if (SPLIT) {  // A: hand records + wrench adjoints to the contact wave, take its joint hand-over records
+      pair_signal(sig, a.nsteps - step);
+      pair_wait(sig + 1, a.nsteps - step);
+    } else {
+      WAVE_SYNC();
+    }
     // ---- adjoint of eval_body_joints (runs while the contact wave sweeps)
     BodyAdj par = adj_zero();
     float a_tgt[ND], a_act[ND], a_ke[ND], a_kd[ND];
@@ -952,7 +985,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
       if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
       if (SPLIT)  // revolute only: the state-only half was computed by the contact wave
-        rev_adjoint(m, c, s, rc, rec, rev_cache_load(jc + b * PD_JC), tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt[0],
+        rev_adjoint(m, c, s, rc, rec, rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC), tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt[0],
                     a_act[0], a_ke[0], a_kd[0]);
       else
         joint_adj<JT>(m, c, s, rc, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
@@ -988,7 +1021,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     }
     STAMP(3);
     if (SPLIT) {
-      __syncthreads();  // B: contact adjoints are complete
+      pair_wait(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
     } else {
       const bool replay = __ballot(log_cnt < 0) == 0ull;
       int log_n_unused;
