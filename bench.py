@@ -214,7 +214,7 @@ def main():
                 "algorithmic_bytes_per_env_step": bb,
                 "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,
                                "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_env_step": bf},
-                "note": "VALU-issue/latency-bound, not HBM-bound: see DESIGN.md section 4",
+                "note": "dependency-chain latency-bound (two waves per SIMD at 4096 envs), not HBM-bound: see DESIGN.md section 4",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
