@@ -108,10 +108,14 @@ PD_DEV void pair_signal(int *flag, int value) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-PD_DEV void pair_wait(int *flag, int value) {
-  while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < value)
+// The low 30 bits of the word are the counter; the producer may pass a flag in bit 30.  Returns the word.
+#define PD_SIG_FLAG 0x40000000
+PD_DEV int pair_wait(int *flag, int value) {
+  int v;
+  while (((v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) & (PD_SIG_FLAG - 1)) < value)
     __builtin_amdgcn_s_sleep(1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return v;
 }
 
 // Ground-contact sweep for one segment (= one env).  Conservative three-level cull, then the exact
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   // in the room the adjoint kernel's wider per-body slots leave in the shared per-env size
   const int spec_off = ((4 + PD_REC + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;  // 16-byte aligned like cull
   float4 *spec = (float4 *)(scratch + spec_off);
-  int *spec_bad = (int *)(scratch + spec_off + 8 * nb);
+  int *spec_bad = (int *)(scratch + spec_off + 8 * nb);  // 4 words: [0] unused, [1..2] of the wave's first env = pair signals
   int *sig = (int *)(scratch - (size_t)seg * m.env_lds_floats + spec_off + 8 * nb) + 1;  // pair signals: words 1, 2 after the first env's flag
   int *list = spec_bad + 4, *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
@@ -481,9 +485,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P;
     for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
-      pair_wait(sig, step + 1);  // A: records + cull vectors of this step are staged, wrench accumulators are zero
+      // A: records + cull vectors of this step are staged, wrench accumulators are zero; bit 30: a body of one of my envs
+      // outran its margin
+      const int sigA = pair_wait(sig, step + 1);
       STAMP(7);
-      const bool redo = !have || __ballot(env_ok && *spec_bad != 0) != 0ull;  // wave-uniform
+      const bool redo = !have || (sigA & PD_SIG_FLAG) != 0;  // wave-uniform
       STAMP_COUNT(13, redo ? 1 : 0);
       STAMP_COUNT(14, __shfl(nh, 0));
       int log_n = 0;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     WAVE_SYNC();
   }
-  if (SPLIT && l == 0) *spec_bad = 1;  // nothing is speculated for step 0
+  bool spec_failed = true;  // wave-uniform: some body of the wave outran its margin (nothing is speculated for step 0)
 
   // Controls are software-prefetched one step ahead: with one wavefront per SIMD there is no other
   // wave to hide the HBM latency of a load issued at its point of use.
@@ -622,13 +628,41 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       n_rf[2 * k] = v.x; n_rf[2 * k + 1] = v.y;
     }
   };
+  BodyState o_s = s;
+  v3 o_ft = V3(0, 0, 0), o_ff = o_ft, o_gt = o_ft, o_gf = o_ft;
+  int o_fr = -1;
+  auto spill = [&](int step) {  // writes what the o_* registers hold for `step`
+    if (!is_body) return;
+    float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
+    stg4(tj, boff * 4u, make_float4(o_s.r.x, o_s.r.y, o_s.r.z, o_s.r.w));
+    stg4(tj + (size_t)4 * N, boff * 4u, make_float4(o_s.w.x, o_s.w.y, o_s.w.z, o_s.v.x));
+    stg4(tj + (size_t)8 * N, boff * 4u, make_float4(o_s.p.x, o_s.p.y, o_s.p.z, o_s.v.y));
+    stg4(tj + (size_t)12 * N, boff * 4u, make_float4(o_s.v.z, o_ft.x, o_ft.y, o_ft.z));
+    stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, 0.f));
+    if (o_fr >= 0) {  // frame gather (dp_model.py:1231-1248)
+      float *o = a.wp_pos + ((size_t)o_fr * N + idx) * 7;
+      o[0] = o_s.p.x; o[1] = o_s.p.y; o[2] = o_s.p.z; o[3] = o_s.r.x; o[4] = o_s.r.y; o[5] = o_s.r.z; o[6] = o_s.r.w;
+      o = a.wp_vel + ((size_t)o_fr * N + idx) * 6;
+      o[0] = o_s.w.x; o[1] = o_s.w.y; o[2] = o_s.w.z; o[3] = o_s.v.x; o[4] = o_s.v.y; o[5] = o_s.v.z;
+      if (a.grf) {
+        o = a.grf + ((size_t)o_fr * N + idx) * 6;
+        o[0] = o_gt.x; o[1] = o_gt.y; o[2] = o_gt.z; o[3] = o_gf.x; o[4] = o_gf.y; o[5] = o_gf.z;
+      }
+      if (a.jaf) {
+        o = a.jaf + ((size_t)o_fr * N + idx) * 6;
+        o[0] = o_ft.x - o_gt.x; o[1] = o_ft.y - o_gt.y; o[2] = o_ft.z - o_gt.z;
+        o[3] = o_ff.x - o_gf.x; o[4] = o_ff.y - o_gf.y; o[5] = o_ff.z - o_gf.z;
+      }
+    }
+  };
   if (a.nsteps > 0) load_controls(0);
   STAMP_DECL;
   for (int step = 0; step < a.nsteps; ++step) {
     // barrier A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
     // contact wave starts sweeping while this wave still unpacks controls and spills the state
     if (SPLIT) {
-      pair_signal(sig, step + 1);  // A: hand this step's records to the contact wave
+      pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: hand this step's records to the contact wave
+      if (step > 0) spill(step - 1);  // the previous step's trajectory record and frame outputs, off the hand-over chain
     }
     STAMP(0);
     PD_WAIT_VMEM();
@@ -685,30 +719,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     const v3 grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
     ft += jt; ff += jf;
-    if (is_body) {
-      // spill the state and the total wrench of this step for the adjoint
-      float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
-      stg4(tj, boff * 4u, make_float4(s.r.x, s.r.y, s.r.z, s.r.w));
-      stg4(tj + (size_t)4 * N, boff * 4u, make_float4(s.w.x, s.w.y, s.w.z, s.v.x));
-      stg4(tj + (size_t)8 * N, boff * 4u, make_float4(s.p.x, s.p.y, s.p.z, s.v.y));
-      stg4(tj + (size_t)12 * N, boff * 4u, make_float4(s.v.z, ft.x, ft.y, ft.z));
-      stg4(tj + (size_t)16 * N, boff * 4u, make_float4(ff.x, ff.y, ff.z, 0.f));
-      if (fr >= 0) {  // frame gather (dp_model.py:1231-1248)
-        float *o = a.wp_pos + ((size_t)fr * N + idx) * 7;
-        o[0] = s.p.x; o[1] = s.p.y; o[2] = s.p.z; o[3] = s.r.x; o[4] = s.r.y; o[5] = s.r.z; o[6] = s.r.w;
-        o = a.wp_vel + ((size_t)fr * N + idx) * 6;
-        o[0] = s.w.x; o[1] = s.w.y; o[2] = s.w.z; o[3] = s.v.x; o[4] = s.v.y; o[5] = s.v.z;
-        if (a.grf) {
-          o = a.grf + ((size_t)fr * N + idx) * 6;
-          o[0] = grf_t.x; o[1] = grf_t.y; o[2] = grf_t.z; o[3] = grf_f.x; o[4] = grf_f.y; o[5] = grf_f.z;
-        }
-        if (a.jaf) {
-          o = a.jaf + ((size_t)fr * N + idx) * 6;
-          o[0] = ft.x - grf_t.x; o[1] = ft.y - grf_t.y; o[2] = ft.z - grf_t.z;
-          o[3] = ff.x - grf_f.x; o[4] = ff.y - grf_f.y; o[5] = ff.z - grf_f.z;
-        }
-      }
-    }
+    // the state and the total wrench of this step go to the trajectory for the adjoint, frames to the outputs
+    o_s = s; o_ft = ft; o_ff = ff; o_gt = grf_t; o_gf = grf_f; o_fr = fr;
+    if (!SPLIT) spill(step);
     STAMP(3);
     // ---- integrate_bodies
     float sink_rate;
@@ -717,8 +730,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (SPLIT) {  // did every body stay inside the margin the contact wave speculated with?  (NaN counts as "no")
       sunk += sink_rate * a.dt;
       const bool bad = is_body && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin);
-      const bool any = ((__ballot(bad) >> (seg * SEGW)) & Seg<SEGW>::MASK) != 0ull;
-      if (l == 0) *spec_bad = any ? 1 : 0;
+      spec_failed = __ballot(bad) != 0ull;
     }
     WAVE_SYNC();
     if (is_body) {
@@ -732,6 +744,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }
+  if (SPLIT && a.nsteps > 0) spill(a.nsteps - 1);
   STAMP_FLUSH(a);
 }
 
