@@ -139,8 +139,10 @@ def test_full_size_properties_and_batch_invariance(dev):
     F = len(inp["frame2step"])
     assert np.array_equal(small["wp_pos"], full["wp_pos"].reshape(F, bs, nb, 7)[:, :sub].reshape(F, -1, 7))
     assert np.array_equal(small["grads"]["q_init"], full["grads"]["q_init"].reshape(bs, nq)[:sub].reshape(-1))
-    again = gpu_rollout(dm, inp, dev)
-    assert np.array_equal(again["wp_pos"], full["wp_pos"]) and np.array_equal(again["grads"]["refs"], full["grads"]["refs"])  # run-to-run
+    for _ in range(3):  # run-to-run: the wave pairs hand over through polled LDS words, a race would show up as changing bits
+        again = gpu_rollout(dm, inp, dev)
+        assert all(np.array_equal(again[k], full[k]) for k in ("wp_pos", "wp_vel", "grf", "jaf"))
+        assert all(np.array_equal(again["grads"][k], full["grads"][k]) for k in full["grads"])
 
 
 @pytest.mark.parametrize("bs,T,f2s", [(1, 1, [0]), (3, 2, [0, 1]), (17, 5, [4]), (5, 7, [0, 3, 6])])
