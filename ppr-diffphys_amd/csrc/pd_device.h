@@ -40,6 +40,7 @@ struct PdDevModel {
   int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
+  int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (wave-specialised adjoint only)
 };
 

@@ -221,6 +221,11 @@ static int build_device(pd_model *m, int segw) {
                    (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
                    (size_t)envs_per_block * d.env_lds_floats * 4;
   // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
+  {
+    int dev_id = 0, cus = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
+    d.cu_count = cus;
+  }
   d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;  // keeps the env stride at 16 mod 32
   m->lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + 2 * d.env_lds_jc) * 4 : m->lds_rollout;
   m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;

@@ -1165,14 +1165,20 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
 
 // Wave specialisation is used where the body wave fits 256 VGPRs (revolute-only articulations, measured +17 %);
 // compound-joint kernels spill at 2 waves/SIMD and are 2x slower split, so they stay unsplit.
+// Wave specialisation.  Adjoint: revolute-only robots (compound joints need > 256 VGPRs, no room for a partner wave).
+// Forward: every joint mix fits, and it pays while a CU holds at most one workgroup (the latency regime: human at 1024
+// envs -32 %); with several workgroups per CU the unsplit kernel's 4-wave workgroups pack twice as many body waves per
+// SIMD (quad at 8192 envs: split +22 %), so the launcher picks per launch.
 constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
 
 template <int JT>
 static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st) {
   switch (kind) {
     case PD_K_ROLLOUT_FWD:
-      hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(pd_split(JT) ? PD_BLOCK : PD_FK_BLOCK), lds, st, m,
-                         *(const RolloutArgs *)args);
+      if (pd_split(JT) || nblocks <= m.cu_count)
+        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+      else
+        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const RolloutArgs *)args);
       break;
     case PD_K_ROLLOUT_BWD:
       hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(pd_split(JT) ? PD_BLOCK : PD_FK_BLOCK), lds, st, m,
@@ -1193,6 +1199,7 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int
 template <int JT>
 static hipError_t set_lds_jt(int bytes) {
   hipError_t e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
