@@ -111,6 +111,13 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const flo
                    const float *adj_body_q_dev, const float *adj_body_qd_dev,
                    float *g_joint_q_dev, float *g_joint_qd_dev, void *stream);
 
+/* Fused per-frame pose loss and its gradients (replaces the torch composition of
+ * se3_loss, diffphys/dp_utils.py:113-138):  n elements of `dim` floats, dim = 7 (p, real-last quaternion) or 6
+ * (p, axis-angle).  loss[n]; g_pred / g_gt [n][dim] = d loss / d input (either may be NULL).  Entries with a NaN input
+ * give loss 0 and zero gradients, like the reference. */
+int pd_se3_loss(int n, int dim, const float *pred_dev, const float *gt_dev, float rot_ratio, float *loss_dev,
+                float *g_pred_dev, float *g_gt_dev, void *stream);
+
 /* Average device time (ms) of the last `kind` launch measured with hipEvents on its stream:
  * kind 0 = rollout forward, 1 = rollout backward.  Enabled by pd_set_timing(1); used by bench.py. */
 void pd_set_timing(int on);

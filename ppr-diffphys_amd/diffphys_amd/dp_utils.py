@@ -51,8 +51,36 @@ def reduce_loss(loss_seq, clip=False, th=0):
     return loss_seq.mean()
 
 
+class _Se3LossHip(torch.autograd.Function):
+    """se3_loss and both gradients in one HIP launch (C ABI ``pd_se3_loss``)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, rot_ratio):
+        from . import hip_backend
+
+        need = pred.requires_grad or gt.requires_grad
+        loss, gp, gg = hip_backend.se3_loss(pred.detach().contiguous(), gt.detach().contiguous(), rot_ratio, want_grads=need)
+        if need:
+            ctx.save_for_backward(gp, gg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        gp, gg = ctx.saved_tensors
+        g = g.unsqueeze(-1)
+        return (g * gp if ctx.needs_input_grad[0] else None), (g * gg if ctx.needs_input_grad[1] else None), None
+
+
 def se3_loss(pred, gt, rot_ratio=0.1):
-    """|dp|^2 + rot_ratio * angle(R_pred R_gt^T); quaternion (real-last) or axis-angle rotations   dp_utils.py:113-138"""
+    """|dp|^2 + rot_ratio * angle(R_pred R_gt^T); quaternion (real-last) or axis-angle rotations   dp_utils.py:113-138.
+    float32 GPU tensors take the fused HIP kernel (the library must be built: no silent fallback on the GPU); anything
+    else (the CPU host tests, float64 checks) runs the torch composition below, which is also the kernel's test reference."""
+    if pred.is_cuda and pred.dtype == torch.float32 and gt.dtype == torch.float32 and pred.shape == gt.shape:
+        return _Se3LossHip.apply(pred, gt, rot_ratio)
+    return se3_loss_torch(pred, gt, rot_ratio)
+
+
+def se3_loss_torch(pred, gt, rot_ratio=0.1):
     nanid = torch.logical_or(pred.sum(-1).isnan(), gt.sum(-1).isnan())
     trn = (pred[..., :3] - gt[..., :3]).pow(2).sum(-1)
     rp, rg = pred[..., 3:], gt[..., 3:]

@@ -54,6 +54,7 @@ def lib():
         L.pd_rollout_backward.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, vp] + [vp] * 3 + [vp] * 10 + [vp]
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
+        L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
         if L.pd_abi_version() != 1:
             raise RuntimeError("libpprdiffphys_hip.so ABI mismatch")
         _lib = L
@@ -202,6 +203,23 @@ class DeviceModel:
                                     _dev(adj_body_q, "adj_body_q", n * self.nb * 7),
                                     _dev(adj_body_qd, "adj_body_qd", n * self.nb * 6), _dev(gq, "g"), _dev(gqd, "g"), _stream()))
         return gq, gqd
+
+
+def se3_loss(pred, gt, rot_ratio, want_grads=True):
+    """Fused se3_loss (``pd_se3_loss``): (..., 7) or (..., 6) float32 GPU tensors -> loss (...), d loss/d pred, d loss/d gt."""
+    dim = pred.shape[-1]
+    if dim not in (6, 7) or gt.shape != pred.shape:
+        raise ValueError("se3_loss: pred and gt must both be (..., 7) or (..., 6); got %s and %s" % (tuple(pred.shape), tuple(gt.shape)))
+    n = pred.numel() // dim
+    loss = torch.empty(pred.shape[:-1], device=pred.device, dtype=torch.float32)
+    gp = torch.empty_like(pred) if want_grads else None
+    gg = torch.empty_like(gt) if want_grads else None
+    null = ctypes.c_void_p(0)
+    rc = lib().pd_se3_loss(n, dim, _dev(pred, "pred"), _dev(gt, "gt"), ctypes.c_float(float(rot_ratio)), _dev(loss, "loss"),
+                           _dev(gp, "g_pred") if want_grads else null, _dev(gg, "g_gt") if want_grads else null, _stream())
+    if rc != 0:
+        raise RuntimeError("pd_se3_loss failed (rc %d)" % rc)
+    return loss, gp, gg
 
 
 def set_timing(on):

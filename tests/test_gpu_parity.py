@@ -503,3 +503,44 @@ def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle
     out2 = gpu_rollout(hip_backend.DeviceModel(tpl), sub, dev)
     assert np.array_equal(out2["wp_pos"].reshape(F, len(pick), -1), out["wp_pos"].reshape(F, bs, -1)[:, pick])
     assert np.array_equal(out2["grads"]["q_init"].reshape(len(pick), -1), out["grads"]["q_init"].reshape(bs, -1)[pick])
+
+
+@pytest.mark.parametrize("dim", [7, 6])
+def test_fused_se3_loss_matches_the_torch_composition(dim, dev):
+    """pd_se3_loss (one launch: loss + both gradients) against the torch restatement of the reference's
+    se3_loss (diffphys/dp_utils.py:113-138) evaluated in float64 -- random poses, tiny / zero axis-angles, identical
+    rotations (clamped acos: zero rotation gradient), NaN entries (loss and gradients 0).  Tolerances: loss 2e-5
+    relative to max, gradients 5e-4 relative to max (fp32 acos near the clamp)."""
+    from diffphys_amd import dp_utils
+
+    g = torch.Generator().manual_seed(5)
+    n = 4099
+    pred = torch.randn(n, dim, generator=g)
+    gt = pred + 0.3 * torch.randn(n, dim, generator=g)
+    if dim == 7:
+        pred[:, 3:] *= 1.7                      # the conversion normalises: non-unit quaternions are legal inputs
+        gt[10:20, 3:] = pred[10:20, 3:] * 0.5   # same rotation, different norm -> cos = 1 -> clamped
+    else:
+        pred[30:40, 3:] = 1e-8 * torch.randn(10, 3, generator=g)   # series branch of axis_angle_to_quaternion
+        gt[30:35, 3:] = 0.0                                       # |a| = 0 exactly (d|a|/da taken as 0)
+        gt[10:20, 3:] = pred[10:20, 3:]
+    pred[50, 1] = float("nan"); gt[51, 4] = float("nan")
+    p32, g32 = pred.to(dev).requires_grad_(True), gt.to(dev).requires_grad_(True)
+    w = torch.randn(n, generator=g).to(dev)
+    loss = dp_utils.se3_loss(p32, g32, 0.1)
+    (loss * w).sum().backward()
+    p64, g64 = pred.double().to(dev).requires_grad_(True), gt.double().to(dev).requires_grad_(True)
+    ref = dp_utils.se3_loss_torch(p64, g64, 0.1)
+    ok = torch.ones(n, dtype=torch.bool, device=dev); ok[50] = False; ok[51] = False
+    (ref[ok] * w.double()[ok]).sum().backward()
+    assert loss[50].item() == 0.0 and loss[51].item() == 0.0
+    assert p32.grad[50].abs().max().item() == 0.0 and g32.grad[51].abs().max().item() == 0.0
+    assert torch.isfinite(loss).all() and torch.isfinite(p32.grad).all() and torch.isfinite(g32.grad).all()
+    rel = lambda a, b: float((a.detach().double() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
+    assert rel(loss[ok], ref[ok]) < 2e-5
+    assert rel(p32.grad[ok], p64.grad[ok]) < 5e-4 and rel(g32.grad[ok], g64.grad[ok]) < 5e-4
+    # clamped entries: translation gradient only
+    assert p32.grad[10:20, 3:].abs().max().item() == 0.0
+    # shapes with leading dims and no-grad calls go through the same kernel
+    l2 = dp_utils.se3_loss(pred.to(dev).reshape(1, n, dim), gt.to(dev).reshape(1, n, dim))
+    assert l2.shape == (1, n) and torch.equal(l2.reshape(-1), loss.detach())
