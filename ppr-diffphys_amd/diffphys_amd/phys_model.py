@@ -191,6 +191,9 @@ class phys_model(nn.Module):
                 self.scheduler.load_state_dict(self.scheduler_cache[0])
             return {}
         grad_dict, queue_length, scale_threshold = {}, 10, 5.0
+        # per-parameter norms and queue medians first, ONE host transfer for all the "is it an outlier" decisions
+        # (the reference branches on a GPU scalar per parameter: one synchronisation each)
+        entries, meds = [], []
         for d in self.params_ref_list:
             ((name, p),) = d.items()
             if not (p.requires_grad and p.grad is not None):
@@ -198,10 +201,19 @@ class phys_model(nn.Module):
             grad = p.grad.reshape(-1).norm(2, -1)
             grad_dict["grad/" + name] = grad
             q = self.grad_queue.setdefault(name, [])
+            med = None
             if len(q) > queue_length:
                 med = torch.stack(q[:-1]).median()
                 grad_dict["grad_med/" + name] = med
-                if grad > scale_threshold * med:
+                meds.append((len(entries), grad, med))
+            entries.append((name, p, grad, q, med))
+        outlier = {}
+        if meds:
+            flags = (torch.stack([g for _, g, _ in meds]) > scale_threshold * torch.stack([m for _, _, m in meds])).tolist()
+            outlier = {i: f for (i, _, _), f in zip(meds, flags)}
+        for i, (name, p, grad, q, med) in enumerate(entries):
+            if med is not None:
+                if outlier[i]:
                     torch.nn.utils.clip_grad_norm_(p, med)
                 else:
                     q.append(grad)

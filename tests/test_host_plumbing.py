@@ -66,3 +66,27 @@ def test_time_mlp_and_schedules():
     assert interp_wt((0, 0.5), (1, 0), 0.25) == 0.5 and interp_wt((0, 0.5), (1, 0), 0.9) == 0
     assert match_param_name("root_pose_mlp.base_quat", {"root_pose_mlp.base_quat": 1e-3}, "with") == (1, 1e-3)
     assert match_param_name("vel_mlp.head.weight", {"vel_mlp": 1e-4, "torque_mlp": 2.0}, "startwith") == (1, 1e-4)
+
+
+def test_reduce_loss_matches_the_reference_loop():
+    """reduce_loss is the reference's per-env loop (dp_utils.py:93-110) without its host synchronisations: same value, same
+    in-place truncation, same gradient -- including the reference's quirk that the threshold comes from the first env only."""
+    torch.manual_seed(0)
+    for trial in range(120):
+        bs, T = int(torch.randint(1, 9, (1,))), int(torch.randint(1, 12, (1,)))
+        x = torch.rand(bs, T) ** 3
+        if trial % 3 == 0:
+            x[0] = 0
+        if trial % 5 == 0:
+            x[torch.rand(bs, T) < 0.4] = 0
+        if trial % 7 == 0:
+            x[int(torch.randint(0, bs, (1,))), int(torch.randint(0, T, (1,)))] = 50.0
+        if trial % 11 == 0:
+            x[:] = 0
+        for clip in (False, True):
+            a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            a2, b2 = a * 1.0, b * 1.0
+            ra, rb = dp_utils.reduce_loss_loop(a2, clip=clip), dp_utils.reduce_loss(b2, clip=clip)
+            assert torch.allclose(ra, rb, atol=1e-7) and torch.equal(a2.detach(), b2.detach())
+            ra.backward(); rb.backward()
+            assert torch.allclose(a.grad, b.grad, atol=1e-7)
