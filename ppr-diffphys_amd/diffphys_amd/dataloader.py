@@ -60,3 +60,24 @@ def bullet2gl(msm, in_bullet):
     msm["orn"] = orn
     msm["vel"] = msm["vel"] @ m.T
     msm["avel"] = msm["avel"] @ m.T
+
+
+def mocap_tensors(table, steps_fr):
+    """``bullet2gl(parse_amp(interp1d(arange(n), table, 'linear', fill_value='extrapolate')(steps_fr)))`` (not in_bullet) as
+    torch ops on the device of ``steps_fr``: ``table`` is the AMP table as a float64 tensor [n, 85] on that device.  Linear
+    inter/extrapolation in float64 like scipy (end segments extrapolate), column map of parse_amp, (x, y, z) -> (y, z, x).
+    Returns float32 tensors keyed like parse_amp."""
+    import torch
+
+    n = table.shape[0]
+    x = steps_fr.detach().to(table.dtype)
+    i0 = x.floor().clamp(0, n - 2).long()
+    lo, hi = table[i0], table[i0 + 1]
+    row = (hi - lo) * (x - i0.to(table.dtype)).unsqueeze(-1) + lo
+    msm = parse_amp(row)
+    perm = [1, 2, 0]  # v @ _ISAAC_TO_GL.T
+    out = {k: msm[k][..., perm] for k in ("pos", "vel", "avel")}
+    out["orn"] = torch.cat([msm["orn"][..., :3][..., perm], msm["orn"][..., 3:]], -1)
+    for k in ("jang", "jvel", "kp", "kp_vel"):
+        out[k] = msm[k]
+    return {k: v.float() for k, v in out.items()}

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import robots, sim
-from .dataloader import bullet2gl, parse_amp
+from .dataloader import mocap_tensors, bullet2gl, parse_amp
 from .dp_model import ForwardKinematics, ForwardWarp, convert_ppr_warp
 from .dp_utils import compose_delta, reduce_loss, rotate_frame, rotate_frame_vel, se3_loss
 from .geom_utils import fid_reindex
@@ -91,6 +91,7 @@ class phys_model(nn.Module):
         self.steps_per_fr_interval = int(self.frame_interval / self.dt)
         self.amp_info_func = scipy.interpolate.interp1d(np.arange(self.total_frames), amp_info, kind="linear",
                                                         fill_value="extrapolate", axis=0)
+        self._amp_dev = {}  # device copies of the AMP table for get_mocap_tensors
 
     def add_nn_modules(self):
         n = self.total_frames
@@ -251,6 +252,19 @@ class phys_model(nn.Module):
         bullet2gl(msm, self.in_bullet)
         return msm
 
+    def get_mocap_tensors(self, steps_fr):
+        """get_mocap_data on the device of ``steps_fr``: the same linear inter/extrapolation of the AMP table (float64, like
+        scipy's interp1d), column map and axis change, without the round trip through numpy and six uploads per iteration.
+        Returns float32 tensors.  (The in_bullet variant goes through scipy's Rotation and keeps the numpy path.)"""
+        if self.in_bullet:
+            msm = self.get_mocap_data(steps_fr.detach().cpu().numpy())
+            return {k: torch.tensor(v, dtype=torch.float32, device=steps_fr.device) for k, v in msm.items()}
+        dev = steps_fr.device
+        tab = self._amp_dev.get(dev)
+        if tab is None:
+            tab = self._amp_dev[dev] = torch.as_tensor(np.asarray(self.amp_info_func.y, dtype=np.float64), device=dev)
+        return mocap_tensors(tab, steps_fr)
+
     def get_net_pred(self, steps_fr):
         bs, nstep = steps_fr.shape
         t = steps_fr.reshape(-1)
@@ -292,8 +306,8 @@ class phys_model(nn.Module):
 
     def get_batch_input(self, steps_fr):
         device = steps_fr.device
-        msm = self.get_mocap_data(steps_fr.detach().cpu().numpy())
-        t = lambda k: torch.tensor(msm[k], dtype=torch.float32, device=device)
+        msm = self.get_mocap_tensors(steps_fr)
+        t = lambda k: msm[k]
         target_ja, target_jad = t("jang"), t("jvel")
         target_q = torch.cat([t("pos"), t("orn")], -1)
         target_qd = torch.cat([t("vel"), t("avel")], -1)

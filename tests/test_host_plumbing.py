@@ -90,3 +90,23 @@ def test_reduce_loss_matches_the_reference_loop():
             assert torch.allclose(ra, rb, atol=1e-7) and torch.equal(a2.detach(), b2.detach())
             ra.backward(); rb.backward()
             assert torch.allclose(a.grad, b.grad, atol=1e-7)
+
+
+def test_device_side_mocap_query_matches_the_numpy_pipeline():
+    """dataloader.mocap_tensors (torch, no host round trip) against interp1d + parse_amp + bullet2gl (row f2), inside and outside
+    the table's range (both extrapolate linearly); float32 outputs, agreement to 1e-6 relative."""
+    import scipy.interpolate
+    from diffphys_amd import dataloader
+
+    dl = dataloader.DataLoader({"seqname": "mi-trot"})
+    n = len(dl.amp_info)
+    f = scipy.interpolate.interp1d(np.arange(n), dl.amp_info, kind="linear", fill_value="extrapolate", axis=0)
+    steps = np.random.RandomState(0).uniform(-3.0, n + 3.0, size=(5, 17))
+    steps[0, :4] = [0.0, n - 1.0, 1.0, n - 2.0]
+    ref = {k: np.array(v, copy=True) for k, v in dataloader.parse_amp(f(steps)).items()}
+    dataloader.bullet2gl(ref, False)
+    got = dataloader.mocap_tensors(torch.as_tensor(np.asarray(dl.amp_info, dtype=np.float64)), torch.as_tensor(steps))
+    assert set(got) == set(ref)
+    for k in ref:
+        assert got[k].dtype == torch.float32 and tuple(got[k].shape) == ref[k].shape
+        assert np.abs(got[k].numpy() - ref[k].astype(np.float32)).max() <= 1e-6 * max(1.0, np.abs(ref[k]).max()), k
