@@ -108,8 +108,15 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
+    red_dev = dev
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        try:  # RCCL (backend "nccl" on ROCm); only the barrier and the MAX of the elapsed time go through it
+            dist.init_process_group(backend="nccl", device_id=dev)
+        except Exception as e:  # keep the measurement alive if RCCL cannot come up on this node: same semantics over gloo
+            if rank == 0:
+                print("bench.py: nccl/RCCL init failed (%s); using gloo for the barrier" % e, file=sys.stderr)
+            dist.init_process_group(backend="gloo")
+            red_dev = torch.device("cpu")
 
     from diffphys_amd import dp_model, hip_backend, robots, synth
 
@@ -151,7 +158,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     bad = int(torch.isnan(g["q_init"]).sum().item())
