@@ -286,7 +286,13 @@ int pd_model_create(const pd_model_desc *d, pd_model **out) {
   m->attach_ke = d->joint_attach_ke; m->attach_kd = d->joint_attach_kd;
   for (int k = 0; k < d->nc; ++k)
     if (m->cbody[k] < 0 || m->cbody[k] >= d->nb) { delete m; return fail("contact_body out of range"); }
-  if (build_device(m, 0)) { free_device(m); delete m; return 1; }
+  // default segment width: the narrowest that holds the bodies AND whose workgroup (contact tables + 64/width envs per
+  // wave) fits the 160 KiB of LDS -- a robot with more contact candidates gets fewer envs per workgroup instead of an error
+  {
+    int rc = 1;
+    for (int w = m->nb <= 16 ? 16 : (m->nb <= 32 ? 32 : 64); w <= 64 && rc; w *= 2) rc = build_device(m, w);
+    if (rc) { free_device(m); delete m; return 1; }
+  }
   *out = m;
   return 0;
 }

@@ -544,3 +544,31 @@ def test_fused_se3_loss_matches_the_torch_composition(dim, dev):
     # shapes with leading dims and no-grad calls go through the same kernel
     l2 = dp_utils.se3_loss(pred.to(dev).reshape(1, n, dim), gt.to(dev).reshape(1, n, dim))
     assert l2.shape == (1, n) and torch.equal(l2.reshape(-1), loss.detach())
+
+
+def test_more_contact_candidates_than_fit_at_the_default_width(dev, oracle_libs):
+    """A robot whose contact tables + 16 envs per workgroup exceed the LDS gets a wider segment (fewer envs per workgroup)
+    instead of an error: Laikago with its candidates duplicated (5 757 points) must build, pick 32 lanes, and match the oracle."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = dict(robots.load_template("laikago"))
+    nc = len(tpl["contact_body"])
+    rng = np.random.RandomState(3)
+    extra = rng.choice(nc, nc // 2, replace=False)
+    for k in ("contact_body", "contact_dist", "contact_material"):
+        tpl[k] = np.concatenate([tpl[k], tpl[k][extra]])
+    jitter = (rng.randn(len(extra), 3) * 2e-4).astype(np.float32)
+    tpl["contact_point"] = np.concatenate([tpl["contact_point"], tpl["contact_point"][extra] + jitter]).astype(np.float32)
+    dm = hip_backend.DeviceModel(tpl)
+    assert dm.segment_width() == 32
+    bs, T = 9, 12
+    inp = synth.make_inputs(robots.load_template("laikago"), "laikago", bs=bs, nsteps=T, seed=4, steps_per_frame=5, penetration=0.003)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert np.abs(st["grf"]).max() > 1.0
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 5e-5 and relmax(out["grf"], st["grf"]) < 5e-3
+    for k in ("q_init", "qd_init", "refs", "body_inv_mass"):
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
