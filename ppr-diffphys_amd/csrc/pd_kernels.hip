@@ -4,7 +4,7 @@
 // from Python, /root/reference/diffphys/dp_model.py:1209-1234).  Per step the only HBM traffic is
 // the SoA state + wrench spill for the adjoint, the step's controls, the contact hit log and frame
 // outputs.  Revolute-only robots run wave-specialised (body waves + contact waves, two workgroup
-// barriers per step).  See DESIGN.md section 3.
+// hand-overs per step through LDS signal words).  See DESIGN.md section 3.
 #include "pd_device.h"
 #include "pd_args.h"
 
@@ -466,9 +466,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     return touching;
   };
   if (SPLIT && contact_wave) {
-    // ---- contact wave: eval_body_contacts for the partner body wave's envs, between barriers A and B of each step.
+    // ---- contact wave: eval_body_contacts for the partner body wave's envs, between hand-overs A and B of each step.
     // The cull (L1-L3) is SPECULATED, once per epoch of PD_SPEC_K steps, in the wait for the body wave's integration:
-    // after barrier B of an epoch's first step s this wave culls with the vectors of state s lowered by margin_b(s), a
+    // after hand-over B of an epoch's first step s this wave culls with the vectors of state s lowered by margin_b(s), a
     // guess of how far body b can sink over the epoch.  The body wave checks the guess against the motion it then
     // integrates (integrate_fwd: sink_rate, summed over the epoch) and raises the env's flag when a body sank further;
     // a raised flag makes this wave redo the exact sweep.  The candidates are a superset, in the same order, of what
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       STAMP_COUNT(13, redo ? 1 : 0);
       STAMP_COUNT(14, __shfl(nh, 0));
       int log_n = 0;
-      bool touching = false;  // lane_owns path: does my candidate touch (logged after barrier B)
+      bool touching = false;  // lane_owns path: does my candidate touch (logged after hand-over B)
       if (redo) {
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
         if (is_body) cv = cull[b];
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   if (a.nsteps > 0) load_controls(0);
   STAMP_DECL;
   for (int step = 0; step < a.nsteps; ++step) {
-    // barrier A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
+    // hand-over A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
     // contact wave starts sweeping while this wave still unpacks controls and spills the state
     if (SPLIT) {
       pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: hand this step's records to the contact wave
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     }
     for (int step = a.nsteps - 1; step >= 0; --step) {
       PD_WAIT_VMEM();
-      // the body wave finished reading the previous hand-over records at barrier B
+      // (the hand-over records are double-buffered by step parity: the body wave may still be reading the previous ones)
       if (rev)
         rev_cache_store(jc + (step & 1) * m.env_lds_jc + b * PD_JC, rev_forward(m, c, Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), V3(pose[1].x, pose[1].y, pose[1].z),
                                                     V3(pose[4].x, pose[4].y, pose[4].z), Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w),
