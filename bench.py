@@ -5,14 +5,22 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   * one process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK / WORLD_SIZE from env)
   * a "step" = one forward rollout + one adjoint rollout over the rank's batch: bs envs x T sim steps
   * workload (BASELINE.json metric / SURVEY.md section 8(d) config C4): Laikago, mixed mi-trot / mi-spin
-    mocap targets, bs = 4096 envs PER GPU (weak scaling: envs are independent, batch split only, no
-    collective on the data path), T = 100 sim steps (4 frames, frame2step = 0,33,66,99), dt = 5e-4, fp32
+    mocap targets, T = 100 sim steps (4 frames, frame2step = 0,33,66,99), dt = 5e-4, fp32.
+    --scaling weak (default): 4096 envs PER GPU, global batch N x 4096.
+    --scaling strong: 4096 envs GLOBAL, rank r rolls out the contiguous slice shard_envs(4096, N, r) (C4 as SURVEY
+    writes it: 512 per GPU at N = 8).
+    Either way every rank builds ITS slice of one global batch (per-env seeded: the slices concatenate to the
+    same global batch for any N), envs are independent, and there is no collective on the data path
   * inputs are resident in HBM before the timed region; timed region is bracketed by barrier + synchronize
   * rank 0 prints ONE JSON line (value = whole-job env-steps/s, max time over ranks)
 
 Extra objects on the line:
   roofline     dominant kernel (the adjoint rollout): algorithmic HBM bytes per launch / its average launch
-               duration measured live with HIP events on the launch stream (pd_set_timing); peak = 8 TB/s
+               duration measured live with HIP events on the launch stream (pd_model_set_timing) in an extra
+               un-timed pass; peak = 8 TB/s nominal (frac) and 6.3 TB/s achievable (frac_of_achievable);
+               traffic = HBM bytes per launch from the PMC counters of the LAST COMMITTED PROFILE (traffic_source
+               names it -- counters cannot be read inside this run); secondary = what actually bounds the kernel
+               (waves per SIMD, VALU busy, LDS per workgroup) from the same profile + this run's launch geometry
   cpu_baseline the C oracle (oracle/ref_c, fp32, OpenMP over envs: "CPU restatement of the reference
                algorithm, not Warp") timed on this host, rank 0, N = 1 only, on a bounded sample
 """
@@ -29,7 +37,9 @@ sys.path.insert(0, os.path.join(ROOT, "ppr-diffphys_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_BYTES = 8.0e12  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_BYTES = 8.0e12        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_ACHIEVABLE_BYTES = 6.3e12  # same guide: what a streaming kernel reaches in practice
+GLOBAL_BS = 4096               # BASELINE.json: "batch=4096"
 
 
 def algorithmic_bytes(nb, nqd):
@@ -47,6 +57,21 @@ def shard_envs(global_bs, world, rank):
     rem = global_bs % world
     lo = rank * per + min(rank, rem)
     return lo, lo + per + (1 if rank < rem else 0)
+
+
+def rank_inputs(tpl, robot, nsteps, world, rank, scaling, bs, seqs, seed=1000):
+    """The rank's contiguous env slice of ONE global batch: weak = `bs` envs per rank out of
+    world * bs, strong = shard_envs(bs, world, rank) out of `bs`.  Returns (inputs, (lo, hi), global batch size).
+    tests/test_shard_gloo.py drives this same function."""
+    from diffphys_amd import synth
+
+    if scaling == "weak":
+        gbs, (lo, hi) = world * bs, (rank * bs, (rank + 1) * bs)
+    elif scaling == "strong":
+        gbs, (lo, hi) = bs, shard_envs(bs, world, rank)
+    else:
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    return synth.make_env_inputs(tpl, robot, range(lo, hi), nsteps, seed=seed, seqs=seqs), (lo, hi), gbs
 
 
 def cpu_baseline(tpl, robot, nsteps, seqs, budget_s=12.0):
@@ -88,7 +113,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --bs envs per GPU; strong: --bs envs in total, sharded across the GPUs")
+    ap.add_argument("--bs", type=int, default=GLOBAL_BS, help="envs per GPU (weak) / global batch (strong)")
     ap.add_argument("--T", type=int, default=100, help="sim steps per rollout")
     ap.add_argument("--robot", default="laikago")
     ap.add_argument("--segw", type=int, default=0, help="lanes per articulation (0 = default)")
@@ -118,29 +145,31 @@ def main():
             dist.init_process_group(backend="gloo")
             red_dev = torch.device("cpu")
 
-    from diffphys_amd import dp_model, hip_backend, robots, synth
+    from diffphys_amd import hip_backend, robots, synth
 
     tpl = robots.load_template(args.robot)
     seqs = ("mi-trot", "mi-spin") if args.robot == "laikago" else ("mi-pace",)
-    bs, T = args.bs, args.T
-    # each rank builds ITS slice of the global batch (seed differs per rank => different envs)
-    inp = synth.make_inputs(tpl, args.robot, bs=bs, nsteps=T, seed=1000 + rank, seqs=seqs)
+    T = args.T
+    inp, (lo, hi), gbs = rank_inputs(tpl, args.robot, T, world, rank, args.scaling, args.bs, seqs)
+    bs = hi - lo
     dm = hip_backend.DeviceModel(tpl)
     if args.segw:
         dm.set_segment_width(args.segw)
     t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
     f2s = inp["frame2step"]
-    fos = dp_model.frame_of_step_tensor(T, f2s, dev)
     fwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass",
                                "body_inertia", "body_inv_inertia")]
     bwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "refs", "target_ke", "target_kd", "body_inv_mass",
                                "body_inertia", "body_inv_inertia")]
     adj_pos = torch.from_numpy(inp["adj_pos"]).to(dev)
     adj_vel = torch.from_numpy(inp["adj_vel"]).to(dev)
+    # workspace, frame outputs and gradient buffers live outside the timed loop (the autograd boundary allocates them per
+    # call through torch's caching allocator; the bench times the two launches, not the allocator)
+    bufs = dm.alloc_rollout(bs, T, len(f2s), dev)
 
     def step():
-        out = dm.rollout_forward(bs, T, inp["dt"], *fwd_args, frame_of_step=fos, nframes=len(f2s))
-        return dm.rollout_backward(bs, T, inp["dt"], *bwd_args, fos, len(f2s), out[4], adj_pos, adj_vel)
+        out = dm.rollout_forward(bs, T, inp["dt"], *fwd_args, frame2step=f2s, out=bufs)
+        return dm.rollout_backward(bs, T, inp["dt"], *bwd_args, f2s, out[4], adj_pos, adj_vel, out=bufs)
 
     def barrier():
         if world > 1:
@@ -163,15 +192,15 @@ def main():
         elapsed = float(tt.item())
     bad = int(torch.isnan(g["q_init"]).sum().item())
 
-    # per-kernel device time (HIP events on the launch stream), outside the timed region
-    hip_backend.set_timing(True)
+    # per-kernel device time (HIP events on the launch stream), in an extra pass outside the timed region
+    dm.set_timing(True)
     kf, kb = [], []
     for _ in range(max(5, min(args.steps, 20))):
         step()
         torch.cuda.synchronize()
-        kf.append(hip_backend.last_kernel_ms(0))
-        kb.append(hip_backend.last_kernel_ms(1))
-    hip_backend.set_timing(False)
+        kf.append(dm.last_kernel_ms(0))
+        kb.append(dm.last_kernel_ms(1))
+    dm.set_timing(False)
     fwd_ms, bwd_ms = float(np.mean(kf)), float(np.mean(kb))
 
     if rank == 0:
@@ -179,31 +208,48 @@ def main():
         bf, bb = algorithmic_bytes(nb, nqd)
         ach_bwd = bs * T * bb / (bwd_ms * 1e-3)
         ach_fwd = bs * T * bf / (fwd_ms * 1e-3)
-        traffic = None
+        prof = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("k_rollout_bwd", {}).get("hbm_bytes_per_launch")
+                    prof = json.load(f)
             except Exception:
-                traffic = None
+                prof = {}
+        pb, pf = prof.get("k_rollout_bwd", {}), prof.get("k_rollout_fwd", {})
+        same_cfg = args.robot == "laikago" and bs == GLOBAL_BS and T == 100  # the committed profile is of this configuration
+        geo_b, geo_f = dm.last_launch_info(1), dm.last_launch_info(0)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+
+        def secondary(geo, p):
+            waves = geo["workgroups"] * geo["threads_per_wg"] / 64.0
+            return {
+                "waves_per_simd": waves / (cus * 4.0),                      # this run's launch geometry
+                "lds_bytes_per_wg": geo["lds_bytes_per_wg"], "workgroups": geo["workgroups"],
+                "threads_per_wg": geo["threads_per_wg"], "compute_units": cus,
+                "valu_busy": p.get("valu_busy") if same_cfg else None,       # from the committed profile (not this run)
+                "wave_wait_share": p.get("wait_share") if same_cfg else None,
+            }
+
         line = {
             "metric": "env-steps/sec (fwd+adjoint), Laikago 12-DoF, batch=4096, 1/2/4/8 MI355X",
-            "value": world * bs * T * args.steps / elapsed,
+            "value": gbs * T * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s, mixed %s mocap targets, %d envs per GPU x %d sim steps (4 frames), dt=5e-4, "
-                "fwd+adjoint, batch split only (no collective)" % (args.robot, "/".join(seqs), bs, T),
-                "global_batch": world * bs,
+                "workload": "%s, mixed %s mocap targets, %s x %d sim steps (4 frames), dt=5e-4, "
+                "fwd+adjoint, batch split only (no collective)" % (
+                    args.robot, "/".join(seqs),
+                    ("%d envs per GPU" % args.bs) if args.scaling == "weak" else ("%d envs in total (%d on rank 0)" % (gbs, bs)), T),
+                "global_batch": gbs,
                 "envs_per_gpu": bs,
                 "sim_steps": T,
                 "segment_lanes": dm.segment_width(),
@@ -216,12 +262,18 @@ def main():
                 "peak": HBM_PEAK_BYTES / 1e9,
                 "unit": "GB/s",
                 "frac": ach_bwd / HBM_PEAK_BYTES,
-                "traffic": traffic,
+                "frac_of_achievable": ach_bwd / HBM_ACHIEVABLE_BYTES,
+                "peak_achievable": HBM_ACHIEVABLE_BYTES / 1e9,
+                "traffic": pb.get("hbm_bytes_per_launch") if same_cfg else None,
+                "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --steps 10`), NOT measured in "
+                                   "this run" % prof.get("tag", "pmc_summary.json")) if (same_cfg and pb) else None,
                 "avg_launch_ms": bwd_ms,
                 "algorithmic_bytes_per_env_step": bb,
+                "secondary": secondary(geo_b, pb),
                 "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,
-                               "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_env_step": bf},
-                "note": "dependency-chain latency-bound (two waves per SIMD at 4096 envs), not HBM-bound: see DESIGN.md section 4",
+                               "frac_of_achievable": ach_fwd / HBM_ACHIEVABLE_BYTES, "avg_launch_ms": fwd_ms,
+                               "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf)},
+                "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

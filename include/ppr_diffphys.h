@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 1
+#define PD_ABI_VERSION 2   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -82,13 +82,25 @@ int pd_model_get_segment_width(const pd_model *m);
  * aligned. */
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps);
 
-/* frame_of_step_dev: [nsteps+1] ints, frame index whose output is state `step`, or -1. */
+/* Per-env joint_X_p (the lab4d path rebinds env.joint_X_p from a torch tensor before every rollout,
+ * diffphys/dp_interface.py:465): joint_X_p_dev is [n_envs][nb][7] DEVICE memory owned by the caller and read by every
+ * later launch on this model until it is re-bound; NULL / 0 returns to the template's joint_X_p.  A rollout then needs
+ * bs == n_envs; FK articulation i uses env i % n_envs (the reference runs eval_fk frame by frame on the same n_envs
+ * model).  Host-side pointer swap only: no copy, no synchronisation, no rebuild of the device model. */
+int pd_model_bind_joint_X_p(pd_model *m, const float *joint_X_p_dev, int n_envs);
+
+/* frame2step_host: [nframes] HOST ints, frame f is state frame2step[f] (ForwardWarp reads self.frame2step,
+ * diffphys/dp_model.py:1231-1248).  Validated before anything is launched: each entry in 0..nsteps, no step twice
+ * (a violation returns non-zero, nothing is written).  State `nsteps` (the state after the last step) is a legal frame
+ * for wp_pos / wp_vel; its grf / jaf rows are zero -- the reference appends no force snapshot for it (:1225-1228).
+ * The device-side step->frame table is cached per model and (nsteps, frame2step); the first call with a new key uploads
+ * it with one synchronous copy, later calls neither allocate nor synchronise (warm up before capturing a graph). */
 int pd_rollout_forward(const pd_model *m, int bs, int nsteps, float dt,
                        const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
                        const float *res_f_dev, const float *refs_dev, const float *target_ke_dev,
                        const float *target_kd_dev, const float *body_inv_mass_dev,
                        const float *body_inertia_dev, const float *body_inv_inertia_dev,
-                       int nframes, const int *frame_of_step_dev, float *workspace_dev,
+                       int nframes, const int *frame2step_host, float *workspace_dev,
                        float *wp_pos_dev, float *wp_vel_dev, float *grf_dev, float *jaf_dev, void *stream);
 
 /* Gradients are OVERWRITTEN (not accumulated).  g_*_dev mirror the input shapes.  body_mass has no
@@ -97,7 +109,7 @@ int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
                         const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
                         const float *refs_dev, const float *target_ke_dev, const float *target_kd_dev,
                         const float *body_inv_mass_dev, const float *body_inertia_dev,
-                        const float *body_inv_inertia_dev, int nframes, const int *frame_of_step_dev,
+                        const float *body_inv_inertia_dev, int nframes, const int *frame2step_host,
                         const float *workspace_dev, const float *adj_pos_dev, const float *adj_vel_dev,
                         float *g_q_init_dev, float *g_qd_init_dev, float *g_torques_dev, float *g_res_f_dev,
                         float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
@@ -118,10 +130,15 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const flo
 int pd_se3_loss(int n, int dim, const float *pred_dev, const float *gt_dev, float rot_ratio, float *loss_dev,
                 float *g_pred_dev, float *g_gt_dev, void *stream);
 
-/* Average device time (ms) of the last `kind` launch measured with hipEvents on its stream:
- * kind 0 = rollout forward, 1 = rollout backward.  Enabled by pd_set_timing(1); used by bench.py. */
-void pd_set_timing(int on);
-float pd_last_kernel_ms(int kind);
+/* Device time (ms) of this model's last `kind` launch, measured with hipEvents recorded on the launch stream around
+ * the kernel: kind 0 = rollout forward, 1 = rollout backward.  Enabled per model by pd_model_set_timing(m, 1); used by
+ * bench.py.  Returns a negative value when nothing was timed.  (Synchronises on the end event.) */
+int pd_model_set_timing(pd_model *m, int on);
+float pd_last_kernel_ms(const pd_model *m, int kind);
+
+/* Launch geometry of the last rollout launch of `kind` on this model (bench.py reports it beside the roofline):
+ * out[0] workgroups, out[1] threads per workgroup, out[2] dynamic LDS bytes per workgroup, out[3] envs per workgroup. */
+int pd_last_launch_info(const pd_model *m, int kind, int out[4]);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,11 @@ class RefC:
         except Exception:
             pass
 
+    def set_acos_policy(self, unguarded):
+        """False: clamped acos/asin with the guarded adjoint (default, what the kernels do); True: unguarded, as SURVEY.md
+        Appendix A.1 recalls Warp.  Process-wide switch of this precision's library: reset it after use."""
+        self.lib.ref_set_acos_policy(1 if unguarded else 0)
+
     def num_threads(self):
         return int(self.lib.ref_num_threads())
 

@@ -105,14 +105,25 @@ static inline qt q_axis_angle(v3 axis, real ang) {
   real s = R_SIN(ang * (real)0.5), c = R_COS(ang * (real)0.5);
   return Q(axis.x * s, axis.y * s, axis.z * s, c);
 }
-/* d/dx acos(x) = -1/sqrt(1-x^2), d/dx asin(x) = +1/sqrt(1-x^2); like Warp's builtin adjoints the
- * contribution is dropped (not inf) where sqrt(1-x^2) is not > 0.  POLICY, see DESIGN.md section 6. */
-static inline real inv_sqrt_1mx2(real x) { real d = R_SQRT((real)1 - x * x); return d > (real)0 ? (real)1 / d : (real)0; }
+/* acos / asin POLICY -- a NAMED DEVIATION from SURVEY.md Appendix A.1, whose recall of warp 0.7.2 is "no guards:
+ * acos(x > 1) = NaN and the adjoint -1/sqrt(1-x^2) = -inf at |x| = 1".  This build's recall of the same builtins is the
+ * opposite (argument clamped to [-1, 1], adjoint contribution dropped where sqrt(1-x^2) is not > 0), and the product
+ * kernels follow it (pd_math.h).  Neither recall can be checked here (Warp is absent), so the oracle runs BOTH:
+ *   ref_set_acos_policy(0)  guarded (default; what the HIP kernels do)
+ *   ref_set_acos_policy(1)  unguarded, as SURVEY App. A.1 recalls Warp
+ * and tests/test_oracle_known_answers.py measures where they differ: identical on inputs away from |x| = 1, NaN
+ * gradients (scrubbed to 0 by remove_nan at the boundary) for an env whose joint passes through angle 0 in fp32. */
+static int g_acos_unguarded = 0;
+void ref_set_acos_policy(int unguarded) { g_acos_unguarded = unguarded; }
+int ref_get_acos_policy(void) { return g_acos_unguarded; }
+static inline real inv_sqrt_1mx2(real x) {
+  real d = R_SQRT((real)1 - x * x);
+  if (g_acos_unguarded) return (real)1 / d;
+  return d > (real)0 ? (real)1 / d : (real)0;
+}
 static inline real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
-/* Warp's acos/asin builtins clamp their argument to [-1, 1] (recall): a unit-quaternion w that rounds to 1.0000001f
- * must not turn into NaN.  Same POLICY note as the adjoint guard above. */
-static inline real acos_c(real x) { return R_ACOS(clampr(x, (real)-1, (real)1)); }
-static inline real asin_c(real x) { return R_ASIN(clampr(x, (real)-1, (real)1)); }
+static inline real acos_c(real x) { return g_acos_unguarded ? R_ACOS(x) : R_ACOS(clampr(x, (real)-1, (real)1)); }
+static inline real asin_c(real x) { return g_acos_unguarded ? R_ASIN(x) : R_ASIN(clampr(x, (real)-1, (real)1)); }
 static inline real clamp_pass(real x, real lo, real hi) { return (x < lo || x > hi) ? (real)0 : (real)1; }
 
 /* adjoints (accumulate into adj_* like Warp's generated code) */
@@ -837,6 +848,13 @@ void ref_rollout_forward(const RefTemplate *t, int bs, int nsteps, real dt, cons
       integrate_fwd(t, bq, bqd, bf, inv_mass + (size_t)e * nb, inertia + (size_t)e * nb * 9, inv_inertia + (size_t)e * nb * 9,
                     dt, states_q + (s + 1) * SQ + oq, states_qd + (s + 1) * SD + od);
     }
+    /* a frame may name state_steps[nsteps] (dp_model.py:396 allocates it, :1241-1246 would read it); no force snapshot
+     * exists for that state (:1225-1228), the caller's zero-initialised grf / jaf rows stay zero */
+    for (int f = 0; f < nframes; ++f)
+      if (frame2step[f] == nsteps) {
+        memcpy(wp_pos + f * SQ + oq, states_q + nsteps * SQ + oq, sizeof(real) * nb * 7);
+        memcpy(wp_vel + f * SD + od, states_qd + nsteps * SD + od, sizeof(real) * nb * 6);
+      }
   }
 }
 

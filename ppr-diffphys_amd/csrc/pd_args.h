@@ -15,6 +15,16 @@
 
 enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
 
+// Which rollout launches run wave-specialised (pd_kernels.hip: launch_jt) -- shared with the host so that it can report
+// the launch geometry.  Adjoint: revolute-only robots.  Forward: every joint mix while a CU holds at most one workgroup.
+constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
+inline bool pd_split_launch(int kind, int jt, int nblocks, int cu_count) {
+  return pd_split(jt) || (kind == PD_K_ROLLOUT_FWD && nblocks <= cu_count);
+}
+inline int pd_block_threads(int kind, int jt, int nblocks, int cu_count) {
+  return (kind <= PD_K_ROLLOUT_BWD && pd_split_launch(kind, jt, nblocks, cu_count)) ? PD_BLOCK : PD_FK_BLOCK;
+}
+
 #define PD_TRAJ_FLOATS 20  // floats of saved trajectory per body-step: 5 float4 planes (pd_kernels.hip: PD_TRAJ_G)
 
 struct RolloutArgs {

@@ -42,6 +42,8 @@ struct PdDevModel {
   int env_lds_floats;                                     // per-env LDS scratch
   int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (wave-specialised adjoint only)
+  const float *X_p_env;                                   // [xp_envs][nb][7] per-env joint_X_p bound by the caller, or null (template X_p)
+  int xp_envs;
 };
 
 #define WAVE_SYNC()                                        \
@@ -86,12 +88,14 @@ struct BodyConst {
   int child[4];    // first four children (-1 = none); the rest, if any, are walked from `children`
 };
 
-PD_DEV BodyConst load_body_const(const PdDevModel &m, int b) {
+// env: the articulation this lane works for (only read when a per-env joint_X_p is bound: dp_interface.py:465 of the reference)
+PD_DEV BodyConst load_body_const(const PdDevModel &m, int b, int env) {
   BodyConst c;
   c.type = m.jtype[b]; c.parent = m.jparent[b]; c.qstart = m.qstart[b]; c.qdstart = m.qdstart[b];
   c.depth = m.depth[b]; c.children = m.children[b];
   c.com = ld3(m.com + b * 3); c.axis = ld3(m.axis + b * 3);
-  c.p_pj = ld3(m.X_p + b * 7); c.q_pj = ld4(m.X_p + b * 7 + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
+  const float *xp = m.X_p_env ? m.X_p_env + ((size_t)(env % m.xp_envs) * m.nb + b) * 7 : m.X_p + b * 7;
+  c.p_pj = ld3(xp); c.q_pj = ld4(xp + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
   c.sphere = m.body_sphere[b];
   c.reach = c.sphere.w >= 0.0f ? length(V3(c.sphere.x, c.sphere.y, c.sphere.z) - c.com) + c.sphere.w : 0.0f;

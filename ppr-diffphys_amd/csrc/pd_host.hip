@@ -25,12 +25,18 @@ struct pd_model {
   void *blob = nullptr;
   PdDevModel dev{};
   size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;
-  // timing
+  // per-env joint_X_p bound by the caller (pd_model_bind_joint_X_p); null = the template's
+  const float *xp_env = nullptr;
+  int xp_envs = 0;
+  // step -> frame tables on the device, one per (nsteps, frame2step) seen so far
+  struct FosEntry { int nsteps; std::vector<int> f2s; int *dev; };
+  std::vector<FosEntry> fos;
+  // timing (per model) and the geometry of the last launch of each kind
+  bool timing = false;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   bool ev_valid[2] = {false, false};
+  int last_launch[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 };
-
-static bool g_timing = false;
 
 // kd-order: recursively split along the longest axis so that runs of `leaf` consecutive points are compact
 static void kd_order(std::vector<int> &ids, int lo, int hi, const float *pts, int leaf) {
@@ -94,6 +100,13 @@ static size_t put(std::vector<unsigned char> &buf, const std::vector<T> &v) {
   return off;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a model: keep the running maximum per
+// (segment width, joint mix) so that a second model never lowers what an earlier, larger one needs.
+static int g_lds_attr[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+static int jt_slot(int jt) { return jt == PD_JT_REVOLUTE ? 0 : (jt == PD_JT_COMPOUND ? 1 : 2); }
+
+// Builds the device copy for segment width `segw` into temporaries and commits blob / dev / lds_* / segw / jt only when
+// every check has passed: a failed call leaves the model exactly as it was.
 static int build_device(pd_model *m, int segw) {
   const int nb = m->nb;
   if (segw == 0) segw = nb <= 16 ? 16 : (nb <= 32 ? 32 : 64);
@@ -185,15 +198,52 @@ static int build_device(pd_model *m, int segw) {
   size_t o_lo = put(buf, m->lim_lo), o_hi = put(buf, m->lim_hi), o_lke = put(buf, m->lim_ke), o_lkd = put(buf, m->lim_kd);
   size_t o_pts = put(buf, pts), o_ptm = put(buf, pt_mat), o_mats = put(buf, mats);
   size_t o_bs = put(buf, body_sphere), o_ts = put(buf, tile_lo), o_th = put(buf, tile_hi), o_ti = put(buf, tile_pack), o_bt = put(buf, body_tiles), o_st = put(buf, small_tiles);
-  free_device(m);
-  hipError_t e = hipMalloc(&m->blob, buf.size());
-  if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
-  e = hipMemcpy(m->blob, buf.data(), buf.size(), hipMemcpyHostToDevice);
-  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(model)");
-  unsigned char *base = (unsigned char *)m->blob;
-  PdDevModel &d = m->dev;
+  // ---- sizes first (nothing is touched if the model does not fit)
+  PdDevModel d{};
   d.nb = nb; d.nq = m->nq; d.nqd = m->nqd; d.nc = nc; d.ntiles = ntiles;
   d.max_children = max_children; d.max_depth = max_depth;
+  d.nmat = m->nmat;
+  d.big_bodies = big_bodies; d.n_small = n_small;
+  d.list_cap = std::max(ntiles, 2 * nb);
+  d.has_limits = 0;
+  for (int i = 0; i < m->nqd; ++i) if (m->lim_ke[i] != 0.f || m->lim_kd[i] != 0.f) d.has_limits = 1;
+  d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
+  d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
+  d.X_p_env = m->xp_env; d.xp_envs = m->xp_envs;
+  // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
+  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;  // + PD_ADJ: the zero record
+  // lanes (env e, body b) of one wave address base_e + f(b): an env stride of 16 mod 32 floats lets the envs of a wave
+  // alternate between the two halves of the 32 LDS banks (2-way, the minimum for 64 lanes) instead of piling onto one
+  d.env_lds_floats += (16 - d.env_lds_floats % 32 + 32) % 32;
+  const int envs_per_block = PD_BWAVES * (64 / segw);
+  const size_t lds_tables = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
+                            (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15);
+  const size_t lds_rollout = lds_tables + (size_t)envs_per_block * d.env_lds_floats * 4;
+  {
+    int dev_id = 0, cus = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
+    d.cu_count = cus;
+  }
+  // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
+  d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;  // keeps the env stride at 16 mod 32
+  const size_t lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + 2 * d.env_lds_jc) * 4 : lds_rollout;
+  const size_t lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
+  if (lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
+  if (lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
+  const int lds_max = (int)std::max(std::max(lds_rollout, lds_rollout_bwd), lds_fk);
+  int &attr = g_lds_attr[segw == 16 ? 0 : (segw == 32 ? 1 : 2)][jt_slot(jt)];
+  if (lds_max > attr) {
+    hipError_t ea = segw == 16 ? pd_set_lds_seg16(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32(jt, lds_max) : pd_set_lds_seg64(jt, lds_max));
+    if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(LDS)");
+    attr = lds_max;
+  }
+  // ---- upload into a fresh blob, then commit
+  void *blob = nullptr;
+  hipError_t e = hipMalloc(&blob, buf.size());
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(model)");
+  e = hipMemcpy(blob, buf.data(), buf.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(blob); return hip_fail(e, "hipMemcpy(model)"); }
+  unsigned char *base = (unsigned char *)blob;
   d.jtype = (const int *)(base + o_jtype); d.jparent = (const int *)(base + o_jparent);
   d.qstart = (const int *)(base + o_qstart); d.qdstart = (const int *)(base + o_qdstart);
   d.depth = (const int *)(base + o_depth); d.children = (const unsigned long long *)(base + o_children);
@@ -202,39 +252,13 @@ static int build_device(pd_model *m, int segw) {
   d.lim_lo = (const float *)(base + o_lo); d.lim_hi = (const float *)(base + o_hi);
   d.lim_ke = (const float *)(base + o_lke); d.lim_kd = (const float *)(base + o_lkd);
   d.pts = (const float4 *)(base + o_pts); d.pt_mat = base + o_ptm; d.materials = (const float4 *)(base + o_mats);
-  d.nmat = m->nmat;
   d.body_sphere = (const float4 *)(base + o_bs); d.tile_lo = (const float4 *)(base + o_ts); d.tile_hi = (const float4 *)(base + o_th);
   d.tile_pack = (const int *)(base + o_ti); d.body_tiles = (const int2 *)(base + o_bt);
-  d.small_tiles = (const int *)(base + o_st); d.big_bodies = big_bodies; d.n_small = n_small;
-  d.list_cap = std::max(ntiles, 2 * nb);
-  d.has_limits = 0;
-  for (int i = 0; i < m->nqd; ++i) if (m->lim_ke[i] != 0.f || m->lim_kd[i] != 0.f) d.has_limits = 1;
-  d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
-  d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
-  // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
-  d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;  // + PD_ADJ: the zero record
-  // lanes (env e, body b) of one wave address base_e + f(b): an env stride of 16 mod 32 floats lets the envs of a wave
-  // alternate between the two halves of the 32 LDS banks (2-way, the minimum for 64 lanes) instead of piling onto one
-  d.env_lds_floats += (16 - d.env_lds_floats % 32 + 32) % 32;
-  const int envs_per_block = PD_BWAVES * (64 / segw);
-  m->lds_rollout = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
-                   (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15) +
-                   (size_t)envs_per_block * d.env_lds_floats * 4;
-  // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
-  {
-    int dev_id = 0, cus = 0;
-    if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
-    d.cu_count = cus;
-  }
-  d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;  // keeps the env stride at 16 mod 32
-  m->lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + 2 * d.env_lds_jc) * 4 : m->lds_rollout;
-  m->lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
-  if (m->lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
-  if (m->lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(m->lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
+  d.small_tiles = (const int *)(base + o_st);
+  free_device(m);
+  m->blob = blob; m->dev = d;
+  m->lds_rollout = lds_rollout; m->lds_rollout_bwd = lds_rollout_bwd; m->lds_fk = lds_fk;
   m->segw = segw; m->jt = jt;
-  int lds_max = (int)std::max(std::max(m->lds_rollout, m->lds_rollout_bwd), m->lds_fk);
-  e = segw == 16 ? pd_set_lds_seg16(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32(jt, lds_max) : pd_set_lds_seg64(jt, lds_max));
-  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(LDS)");
   return 0;
 }
 
@@ -242,23 +266,57 @@ static hipError_t launch(const pd_model *m, int kind, const void *args, int n_en
   const int epb = PD_BWAVES * (64 / m->segw);
   const int nblocks = (n_envs + epb - 1) / epb;
   if (nblocks == 0) return hipSuccess;
+  if (kind < 2) {
+    int *ll = const_cast<pd_model *>(m)->last_launch[kind];
+    ll[0] = nblocks; ll[1] = pd_block_threads(kind, m->jt, nblocks, m->dev.cu_count); ll[2] = (int)lds; ll[3] = epb;
+  }
   if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, nblocks, lds, st);
   if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, nblocks, lds, st);
   return pd_launch_seg64(kind, m->jt, m->dev, args, nblocks, lds, st);
 }
 
 static void timing_begin(pd_model *m, int kind, hipStream_t st) {
-  if (!g_timing) return;
+  if (!m->timing) return;
   if (!m->ev[kind][0]) { (void)hipEventCreate(&m->ev[kind][0]); (void)hipEventCreate(&m->ev[kind][1]); }
   (void)hipEventRecord(m->ev[kind][0], st);
 }
 static void timing_end(pd_model *m, int kind, hipStream_t st) {
-  if (!g_timing) return;
+  if (!m->timing) return;
   (void)hipEventRecord(m->ev[kind][1], st);
   m->ev_valid[kind] = true;
 }
 
-static pd_model *g_last_model = nullptr;
+// Validates frame2step (host) and returns the cached device table frame_of_step[nsteps + 1] (frame index of each state, or
+// -1).  A new (nsteps, frame2step) costs one allocation and one synchronous upload; a repeated one costs a compare.
+static int frame_table(pd_model *m, int nsteps, int nframes, const int *f2s, const int **out) {
+  if (nframes < 0) return fail("negative frame count");
+  if (nframes > 0 && !f2s) return fail("null frame2step");
+  std::vector<int> fos((size_t)nsteps + 1, -1);
+  for (int f = 0; f < nframes; ++f) {
+    const int s = f2s[f];
+    if (s < 0 || s > nsteps)
+      return fail("frame2step[" + std::to_string(f) + "] = " + std::to_string(s) + " is outside 0.." + std::to_string(nsteps));
+    if (fos[s] >= 0)
+      return fail("frame2step names step " + std::to_string(s) + " twice (frames " + std::to_string(fos[s]) + " and " + std::to_string(f) + ")");
+    fos[s] = f;
+  }
+  for (const auto &e : m->fos)
+    if (e.nsteps == nsteps && (int)e.f2s.size() == nframes && std::equal(e.f2s.begin(), e.f2s.end(), f2s)) { *out = e.dev; return 0; }
+  if (m->fos.size() >= 64) {  // bounded cache: drain the device before the old tables go
+    (void)hipDeviceSynchronize();
+    for (auto &e : m->fos) (void)hipFree(e.dev);
+    m->fos.clear();
+  }
+  int *dev = nullptr;
+  hipError_t e = hipMalloc((void **)&dev, fos.size() * sizeof(int));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(frame table)");
+  e = hipMemcpy(dev, fos.data(), fos.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(dev); return hip_fail(e, "hipMemcpy(frame table)"); }
+  m->fos.push_back({nsteps, std::vector<int>(f2s, f2s + nframes), dev});
+  *out = dev;
+  return 0;
+}
+
 static unsigned long long *g_dbg = nullptr;  // diagnostic builds only
 
 extern "C" {
@@ -299,20 +357,29 @@ int pd_model_create(const pd_model_desc *d, pd_model **out) {
 
 void pd_model_destroy(pd_model *m) {
   if (!m) return;
-  if (g_last_model == m) g_last_model = nullptr;
   for (int k = 0; k < 2; ++k)
     for (int j = 0; j < 2; ++j)
       if (m->ev[k][j]) (void)hipEventDestroy(m->ev[k][j]);
+  for (auto &e : m->fos) (void)hipFree(e.dev);
   free_device(m);
   delete m;
 }
 
+// Setup-time call: the device copy is rebuilt (one synchronisation, because launches in flight may still read the old one).
 int pd_model_set_segment_width(pd_model *m, int lanes) {
   if (!m) return fail("null model");
   (void)hipDeviceSynchronize();
   return build_device(m, lanes);
 }
 int pd_model_get_segment_width(const pd_model *m) { return m ? m->segw : 0; }
+
+int pd_model_bind_joint_X_p(pd_model *m, const float *joint_X_p_dev, int n_envs) {
+  if (!m) return fail("null model");
+  if ((joint_X_p_dev == nullptr) != (n_envs == 0) || n_envs < 0) return fail("joint_X_p binding needs a device pointer and n_envs > 0 (or NULL and 0 to unbind)");
+  m->xp_env = joint_X_p_dev; m->xp_envs = n_envs;
+  m->dev.X_p_env = joint_X_p_dev; m->dev.xp_envs = n_envs;
+  return 0;
+}
 
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
   return m ? (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb + (size_t)nsteps * (size_t)bs * PD_HITLOG : 0;  // + hit log (ints)
@@ -321,45 +388,53 @@ size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
 int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
                        const float *torques, const float *res_f, const float *refs, const float *target_ke,
                        const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
-                       const int *frame_of_step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, void *stream) {
+                       const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, void *stream) {
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
-  if (!q_init || !qd_init || !torques || !res_f || !refs || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia ||
-      !frame_of_step || !ws || !wp_pos || !wp_vel)
-    return fail("null device pointer");
+  const int *fos = nullptr;
+  if (frame_table(m, nsteps, nframes, frame2step, &fos)) return 1;
+  if (bs == 0) return 0;
+  if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia) return fail("null device pointer");
+  if (nsteps > 0 && (!torques || !res_f || !refs || !ws)) return fail("null device pointer");
+  if (nframes > 0 && (!wp_pos || !wp_vel)) return fail("null device pointer");
+  if (m->xp_env && m->xp_envs != bs) return fail("joint_X_p is bound for " + std::to_string(m->xp_envs) + " envs, rollout has " + std::to_string(bs));
   RolloutArgs a{};
   a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.res_f = res_f; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
-  a.frame_of_step = frame_of_step; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
+  a.frame_of_step = fos; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
   a.hitlog = (int *)(ws + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, m->lds_rollout, st);
   timing_end(m, 0, st);
-  g_last_model = m;
   return e == hipSuccess ? 0 : hip_fail(e, "rollout_forward launch");
 }
 
 int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
                         const float *torques, const float *refs, const float *target_ke, const float *target_kd,
-                        const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame_of_step,
+                        const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
                         const float *ws, const float *adj_pos, const float *adj_vel, float *g_q_init, float *g_qd_init,
                         float *g_torques, float *g_res_f, float *g_refs, float *g_ke, float *g_kd, float *g_inv_mass,
                         float *g_inertia, float *g_inv_inertia, void *stream) {
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
-  if (!q_init || !qd_init || !torques || !refs || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia ||
-      !frame_of_step || !ws || !adj_pos || !adj_vel || !g_q_init || !g_qd_init || !g_torques || !g_res_f || !g_refs || !g_ke ||
+  const int *fos = nullptr;
+  if (frame_table(m, nsteps, nframes, frame2step, &fos)) return 1;
+  if (bs == 0) return 0;
+  if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia || !g_q_init || !g_qd_init || !g_ke ||
       !g_kd || !g_inv_mass || !g_inertia || !g_inv_inertia)
     return fail("null device pointer");
+  if (nsteps > 0 && (!torques || !refs || !ws || !g_torques || !g_res_f || !g_refs)) return fail("null device pointer");
+  if (nframes > 0 && (!adj_pos || !adj_vel)) return fail("null device pointer");
+  if (m->xp_env && m->xp_envs != bs) return fail("joint_X_p is bound for " + std::to_string(m->xp_envs) + " envs, rollout has " + std::to_string(bs));
   RolloutArgs a{};
   a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
-  a.frame_of_step = frame_of_step; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
+  a.frame_of_step = fos; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
   a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
@@ -367,7 +442,6 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   timing_begin(m, 1, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout_bwd, st);
   timing_end(m, 1, st);
-  g_last_model = m;
   return e == hipSuccess ? 0 : hip_fail(e, "rollout_backward launch");
 }
 
@@ -393,16 +467,26 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *
   return e == hipSuccess ? 0 : hip_fail(e, "fk_backward launch");
 }
 
-// Not part of the public header: buffer for -DPD_STAMPS diagnostic builds ([blocks*waves][8] u64).
+// Not part of the public header: buffer for -DPD_STAMPS diagnostic builds ([blocks*waves][16] u64).
 void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
-void pd_set_timing(int on) { g_timing = on != 0; }
-float pd_last_kernel_ms(int kind) {
-  pd_model *m = g_last_model;
+
+int pd_model_set_timing(pd_model *m, int on) {
+  if (!m) return fail("null model");
+  m->timing = on != 0;
+  if (!m->timing) m->ev_valid[0] = m->ev_valid[1] = false;
+  return 0;
+}
+float pd_last_kernel_ms(const pd_model *m, int kind) {
   if (!m || kind < 0 || kind > 1 || !m->ev_valid[kind]) return -1.0f;
   float ms = -1.0f;
   if (hipEventSynchronize(m->ev[kind][1]) != hipSuccess) return -1.0f;
   if (hipEventElapsedTime(&ms, m->ev[kind][0], m->ev[kind][1]) != hipSuccess) return -1.0f;
   return ms;
+}
+int pd_last_launch_info(const pd_model *m, int kind, int out[4]) {
+  if (!m || !out || kind < 0 || kind > 1) return fail("bad argument");
+  for (int k = 0; k < 4; ++k) out[k] = m->last_launch[kind][k];
+  return 0;
 }
 
 }  // extern "C"

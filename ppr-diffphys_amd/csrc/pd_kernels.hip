@@ -455,7 +455,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     __syncthreads();
   }
 
-  BodyConst c = load_body_const(m, b);
+  BodyConst c = load_body_const(m, b, ec);
 #pragma unroll
   for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {  // body_f -= (t, f)   (:179)
@@ -745,6 +745,21 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     STAMP(5);
   }
   if (SPLIT && a.nsteps > 0) spill(a.nsteps - 1);
+  {  // a frame may name the state after the last step (state_steps[nsteps], dp_model.py:396,1241-1246); no force
+     // snapshot exists for it (the reference appends grf / jaf for step in steps_idx only, :1225-1228): zero rows
+    const int fr_last = ld_uniform(a.frame_of_step, a.nsteps);
+    if (fr_last >= 0 && is_body) {
+      float *o = a.wp_pos + ((size_t)fr_last * N + idx) * 7;
+      o[0] = s.p.x; o[1] = s.p.y; o[2] = s.p.z; o[3] = s.r.x; o[4] = s.r.y; o[5] = s.r.z; o[6] = s.r.w;
+      o = a.wp_vel + ((size_t)fr_last * N + idx) * 6;
+      o[0] = s.w.x; o[1] = s.w.y; o[2] = s.w.z; o[3] = s.v.x; o[4] = s.v.y; o[5] = s.v.z;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (a.grf) a.grf[((size_t)fr_last * N + idx) * 6 + k] = 0.f;
+        if (a.jaf) a.jaf[((size_t)fr_last * N + idx) * 6 + k] = 0.f;
+      }
+    }
+  }
   STAMP_FLUSH(a);
 }
 
@@ -782,7 +797,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     __syncthreads();
   }
 
-  BodyConst c = load_body_const(m, b);
+  BodyConst c = load_body_const(m, b, ec);
 #pragma unroll
   for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
   if (l == 0) {
@@ -1114,7 +1129,7 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
   const int ec = env < a.n ? env : 0;
   float *rec = (float *)smem + (size_t)(wave * EPW + seg) * (nb * (PD_REC + PD_ADJ));
   float *cslot = rec + nb * PD_REC;
-  const BodyConst c = load_body_const(m, b);
+  const BodyConst c = load_body_const(m, b, ec);
   const float *jq = a.joint_q + (size_t)ec * m.nq + c.qstart, *jqd = a.joint_qd + (size_t)ec * m.nqd + c.qdstart;
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
@@ -1163,19 +1178,16 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
 #define PD_CAT2(a, b) a##b
 #define PD_CAT(a, b) PD_CAT2(a, b)
 
-// Wave specialisation is used where the body wave fits 256 VGPRs (revolute-only articulations, measured +17 %);
-// compound-joint kernels spill at 2 waves/SIMD and are 2x slower split, so they stay unsplit.
-// Wave specialisation.  Adjoint: revolute-only robots (compound joints need > 256 VGPRs, no room for a partner wave).
-// Forward: every joint mix fits, and it pays while a CU holds at most one workgroup (the latency regime: human at 1024
-// envs -32 %); with several workgroups per CU the unsplit kernel's 4-wave workgroups pack twice as many body waves per
-// SIMD (quad at 8192 envs: split +22 %), so the launcher picks per launch.
-constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
+// Wave specialisation (pd_split / pd_split_launch in pd_args.h).  Adjoint: revolute-only robots (compound joints need
+// > 256 VGPRs, no room for a partner wave).  Forward: every joint mix fits, and it pays while a CU holds at most one
+// workgroup (the latency regime: human at 1024 envs -32 %); with several workgroups per CU the unsplit kernel's 4-wave
+// workgroups pack twice as many body waves per SIMD (quad at 8192 envs: split +22 %), so the launcher picks per launch.
 
 template <int JT>
 static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st) {
   switch (kind) {
     case PD_K_ROLLOUT_FWD:
-      if (pd_split(JT) || nblocks <= m.cu_count)
+      if (pd_split_launch(kind, JT, nblocks, m.cu_count))
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
       else
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const RolloutArgs *)args);

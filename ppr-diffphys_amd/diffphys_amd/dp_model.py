@@ -9,6 +9,8 @@ Differences that are deliberate:
   * one kernel launch per rollout instead of a Python loop of Warp launches;
   * ``self.state_steps`` is not needed (the trajectory lives in a workspace
     tensor owned by the autograd ctx);
+  * ``self.sim_trajs`` / ``body_q_numpy`` are lazy host views (:class:`HostFrames`): the env-0 copy the reference makes
+    eagerly for visualisation happens on first access, so neither ``forward`` synchronises the host;
   * ``body_mass`` gets a zero gradient: the reference kernel loads it and never
     uses it (/root/reference/diffphys/integrator_euler.py:43).
 """
@@ -28,13 +30,29 @@ def _scrub_nan(t):
     return torch.where(t.isnan(), torch.zeros_like(t), t)
 
 
-def frame_of_step_tensor(nsteps, frame2step, device):
-    fos = np.full(nsteps + 1, -1, dtype=np.int32)
-    for f, s in enumerate(frame2step):
-        if not (0 <= s <= nsteps):
-            raise ValueError("frame2step entry %d outside 0..%d" % (s, nsteps))
-        fos[s] = f
-    return torch.from_numpy(fos).to(device)
+class HostFrames:
+    """Env-0 poses of every frame as a list of numpy arrays -- what the reference builds eagerly for visualisation
+    (``self.sim_trajs`` dp_model.py:1237-1244, ``body_q_numpy`` :1066-1072) and ``query()`` consumes (:855-860).  Here the
+    device-to-host copy happens on first access, so ``forward()`` itself never synchronises the host (SURVEY section 8(b):
+    "no host sync inside the op except the optional env-0 trajectory copy")."""
+
+    def __init__(self, frames_dev):  # [F, nb, 7] device tensor (a detached view; nothing writes it afterwards)
+        self._dev, self._host = frames_dev, None
+
+    def _get(self):
+        if self._host is None:
+            self._host = list(self._dev.detach().cpu().numpy())
+            self._dev = None
+        return self._host
+
+    def __len__(self):
+        return len(self._host) if self._host is not None else int(self._dev.shape[0])
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
 
 
 class ForwardKinematics(torch.autograd.Function):
@@ -54,7 +72,7 @@ class ForwardKinematics(torch.autograd.Function):
         ctx.save_for_backward(jq, jqd)
         body_q = body_q.view(num_frames, bs, dm.nb, 7).permute(1, 0, 2, 3).contiguous()
         body_qd = body_qd.view(num_frames, bs, dm.nb, 6).permute(1, 0, 2, 3).contiguous()
-        body_q_numpy = list(body_q[0].detach().cpu().numpy())  # env 0, one array per frame (visualisation)
+        body_q_numpy = HostFrames(body_q[0])  # env 0, one array per frame (visualisation); copied to the host on first use
         if not is_cuda:
             body_q, body_qd = body_q.cpu(), body_qd.cpu()
         return body_q, body_qd, body_q_numpy
@@ -96,24 +114,25 @@ class ForwardWarp(torch.autograd.Function):
         c = lambda t: t.detach().to(torch.float32).contiguous()
         inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
                               body_inv_inertia)]
-        fos = frame_of_step_tensor(nsteps, frame2step, dev)
-        wp_pos, wp_vel, grf, jaf, ws = dm.rollout_forward(bs, nsteps, self.dt, *inp, frame_of_step=fos,
-                                                          nframes=len(frame2step))
-        ctx.dm, ctx.meta = dm, (bs, nsteps, float(self.dt), len(frame2step))
-        ctx.save_for_backward(ws, fos, *inp)
+        frame2step = [int(s) for s in frame2step]
+        wp_pos, wp_vel, grf, jaf, ws = dm.rollout_forward(bs, nsteps, self.dt, *inp, frame2step=frame2step)
+        ctx.dm, ctx.meta = dm, (bs, nsteps, float(self.dt), frame2step)
+        ctx.save_for_backward(ws, *inp)
         ctx.mass_shape = body_mass.shape
-        # side outputs consumed by phys_model.query() (dp_model.py:855-860)
-        self.grfs = list(grf.unbind(0))
-        self.jafs = list(jaf.unbind(0))
-        self.sim_trajs = list(wp_pos[:, : dm.nb].detach().cpu().numpy())
+        # side outputs consumed by phys_model.query() (dp_model.py:855-860); a frame at state `nsteps` has no force
+        # snapshot in the reference (:1225-1228 append for step in steps_idx only): keep its list lengths
+        has_f = [f for f, s in enumerate(frame2step) if s < nsteps]
+        self.grfs = [grf[f] for f in has_f]
+        self.jafs = [jaf[f] for f in has_f]
+        self.sim_trajs = HostFrames(wp_pos[:, : dm.nb])
         return wp_pos, wp_vel
 
     @staticmethod
     def backward(ctx, adj_body_qs, adj_body_qd):
-        ws, fos, q_init, qd_init, torques, res_f, refs, ke, kd, inv_m, inertia, inv_inertia = ctx.saved_tensors
-        bs, nsteps, dt, nframes = ctx.meta
-        g = ctx.dm.rollout_backward(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia, fos,
-                                    nframes, ws, adj_body_qs.to(torch.float32).contiguous(),
+        ws, q_init, qd_init, torques, res_f, refs, ke, kd, inv_m, inertia, inv_inertia = ctx.saved_tensors
+        bs, nsteps, dt, frame2step = ctx.meta
+        g = ctx.dm.rollout_backward(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia,
+                                    frame2step, ws, adj_body_qs.to(torch.float32).contiguous(),
                                     adj_body_qd.to(torch.float32).contiguous())
         s = _scrub_nan
         return (s(g["q_init"]), s(g["qd_init"]), s(g["torques"]).view_as(torques), s(g["res_f"]).view_as(res_f),

@@ -14,6 +14,8 @@ import torch
 _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
+ABI_VERSION = 2  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
 
@@ -48,15 +50,18 @@ def lib():
         L.pd_model_set_segment_width.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.pd_model_get_segment_width.argtypes = [ctypes.c_void_p]
         L.pd_last_kernel_ms.restype = ctypes.c_float
-        L.pd_last_kernel_ms.argtypes = [ctypes.c_int]
+        L.pd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.pd_model_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.pd_last_launch_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 4)]
+        L.pd_model_bind_joint_X_p.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-        L.pd_rollout_forward.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, vp] + [vp] * 5 + [vp]
-        L.pd_rollout_backward.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, vp] + [vp] * 3 + [vp] * 10 + [vp]
+        L.pd_rollout_forward.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, _ip] + [vp] * 5 + [vp]
+        L.pd_rollout_backward.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 10 + [vp]
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
         L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
-        if L.pd_abi_version() != 1:
-            raise RuntimeError("libpprdiffphys_hip.so ABI mismatch")
+        if L.pd_abi_version() != ABI_VERSION:
+            raise RuntimeError("libpprdiffphys_hip.so ABI mismatch: library %d, binding %d" % (L.pd_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 
@@ -112,6 +117,7 @@ class DeviceModel:
         h = ctypes.c_void_p()
         _check(L.pd_model_create(ctypes.byref(d), ctypes.byref(h)))
         self.h = h
+        self._xp = None
 
     def __del__(self):
         try:
@@ -130,54 +136,96 @@ class DeviceModel:
     def workspace_floats(self, bs, nsteps):
         return int(lib().pd_rollout_workspace_floats(self.h, bs, nsteps))
 
+    # -- per-env joint_X_p (dp_interface.py:465 of the reference rebinds env.joint_X_p before every rollout) ----------
+    def bind_joint_X_p(self, joint_X_p):
+        """[n_envs*nb, 7] float32 GPU tensor (kept alive by this object) or None for the template's joint_X_p.
+        A pointer swap on the host: no copy, no synchronisation, no rebuild."""
+        if joint_X_p is None:
+            _check(lib().pd_model_bind_joint_X_p(self.h, None, 0))
+            self._xp = None
+            return
+        n = joint_X_p.numel() // (self.nb * 7)
+        _check(lib().pd_model_bind_joint_X_p(self.h, _dev(joint_X_p, "joint_X_p", n * self.nb * 7), n))
+        self._xp = joint_X_p
+
+    # -- timing / launch geometry (bench.py) -------------------------------------------------------------------
+    def set_timing(self, on):
+        _check(lib().pd_model_set_timing(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self, kind):
+        return float(lib().pd_last_kernel_ms(self.h, int(kind)))
+
+    def last_launch_info(self, kind):
+        out = (ctypes.c_int * 4)()
+        _check(lib().pd_last_launch_info(self.h, int(kind), ctypes.byref(out)))
+        return dict(workgroups=out[0], threads_per_wg=out[1], lds_bytes_per_wg=out[2], envs_per_wg=out[3])
+
     # -- rollout ----------------------------------------------------------------
+    def alloc_rollout(self, bs, nsteps, nframes, device, want_forces=True, backward=True):
+        """Workspace, frame outputs and gradient buffers of one (bs, nsteps, nframes) rollout, for callers that reuse them
+        across iterations (pass as ``out=`` to rollout_forward / rollout_backward)."""
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        o = dict(ws=e(self.workspace_floats(bs, nsteps)), wp_pos=e(nframes, bs * nb, 7), wp_vel=e(nframes, bs * nb, 6))
+        if want_forces:
+            o.update(grf=e(nframes, bs * nb, 6), jaf=e(nframes, bs * nb, 6))
+        if backward:
+            o["grads"] = self._alloc_grads(bs, nsteps, device)
+        return o
+
+    def _alloc_grads(self, bs, nsteps, device):
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        return dict(q_init=e(bs * nq), qd_init=e(bs * nqd), torques=e(nsteps, bs * nqd), res_f=e(nsteps, bs * nb, 6),
+                    refs=e(nsteps, bs * nqd), target_ke=e(bs * nqd), target_kd=e(bs * nqd), body_inv_mass=e(bs * nb),
+                    body_inertia=e(bs * nb, 3, 3), body_inv_inertia=e(bs * nb, 3, 3))
+
+    @staticmethod
+    def _f2s(frame2step):
+        f = [int(x) for x in frame2step]
+        return (ctypes.c_int * max(len(f), 1))(*f), len(f)
+
     def rollout_forward(self, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass,
-                        body_inertia, body_inv_inertia, frame_of_step, nframes, want_forces=True):
+                        body_inertia, body_inv_inertia, frame2step, want_forces=True, out=None):
+        """-> wp_pos [F, bs*nb, 7], wp_vel [F, bs*nb, 6], grf, jaf [F, bs*nb, 6] (or None), workspace.
+        frame2step: host sequence of F distinct ints in 0..nsteps (validated by the library before the launch)."""
         nb, nq, nqd = self.nb, self.nq, self.nqd
         dev = q_init.device
-        if frame_of_step.dtype != torch.int32 or not frame_of_step.is_cuda or frame_of_step.numel() != nsteps + 1:
-            raise ValueError("frame_of_step must be an int32 GPU tensor of nsteps+1 entries")
-        ws = torch.empty(self.workspace_floats(bs, nsteps), dtype=torch.float32, device=dev)
-        if bs == 0 or nframes == 0:  # empty batch / no output frames: nothing to launch (data_ptr() of an empty tensor is null)
-            z = lambda n: torch.zeros(nframes, bs * nb, n, dtype=torch.float32, device=dev)
-            if bs == 0:
-                return z(7), z(6), (z(6) if want_forces else None), (z(6) if want_forces else None), ws
-        wp_pos = torch.empty(nframes, bs * nb, 7, dtype=torch.float32, device=dev)
-        wp_vel = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev)
-        grf = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev) if want_forces else None
-        jaf = torch.empty(nframes, bs * nb, 6, dtype=torch.float32, device=dev) if want_forces else None
+        f2s, nframes = self._f2s(frame2step)
+        if out is None:
+            out = self.alloc_rollout(bs, nsteps, nframes, dev, want_forces, backward=False)
+        ws, wp_pos, wp_vel = out["ws"], out["wp_pos"], out["wp_vel"]
+        grf, jaf = (out["grf"], out["jaf"]) if want_forces else (None, None)
+        p = lambda t, name, n: _dev(t, name, n) if t.numel() else None  # empty tensors have a null data_ptr: the library accepts it
         _check(lib().pd_rollout_forward(
-            self.h, bs, nsteps, float(dt), _dev(q_init, "q_init", bs * nq), _dev(qd_init, "qd_init", bs * nqd),
-            _dev(torques, "torques", nsteps * bs * nqd), _dev(res_f, "res_f", nsteps * bs * nb * 6),
-            _dev(refs, "refs", nsteps * bs * nqd), _dev(target_ke, "target_ke", bs * nqd),
-            _dev(target_kd, "target_kd", bs * nqd), _dev(body_inv_mass, "body_inv_mass", bs * nb),
-            _dev(body_inertia, "body_inertia", bs * nb * 9), _dev(body_inv_inertia, "body_inv_inertia", bs * nb * 9),
-            nframes, ctypes.c_void_p(frame_of_step.data_ptr()), _dev(ws, "workspace"), _dev(wp_pos, "wp_pos"),
-            _dev(wp_vel, "wp_vel"), _dev(grf, "grf") if want_forces else None, _dev(jaf, "jaf") if want_forces else None,
-            _stream()))
+            self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
+            p(torques, "torques", nsteps * bs * nqd), p(res_f, "res_f", nsteps * bs * nb * 6),
+            p(refs, "refs", nsteps * bs * nqd), p(target_ke, "target_ke", bs * nqd),
+            p(target_kd, "target_kd", bs * nqd), p(body_inv_mass, "body_inv_mass", bs * nb),
+            p(body_inertia, "body_inertia", bs * nb * 9), p(body_inv_inertia, "body_inv_inertia", bs * nb * 9),
+            nframes, f2s, p(ws, "workspace", self.workspace_floats(bs, nsteps)), p(wp_pos, "wp_pos", nframes * bs * nb * 7),
+            p(wp_vel, "wp_vel", nframes * bs * nb * 6), p(grf, "grf", nframes * bs * nb * 6) if want_forces else None,
+            p(jaf, "jaf", nframes * bs * nb * 6) if want_forces else None, _stream()))
         return wp_pos, wp_vel, grf, jaf, ws
 
     def rollout_backward(self, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, body_inv_mass,
-                         body_inertia, body_inv_inertia, frame_of_step, nframes, ws, adj_pos, adj_vel):
+                         body_inertia, body_inv_inertia, frame2step, ws, adj_pos, adj_vel, out=None):
         nb, nq, nqd = self.nb, self.nq, self.nqd
         dev = q_init.device
-        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        g = dict(q_init=e(bs * nq), qd_init=e(bs * nqd), torques=e(nsteps, bs * nqd), res_f=e(nsteps, bs * nb, 6),
-                 refs=e(nsteps, bs * nqd), target_ke=e(bs * nqd), target_kd=e(bs * nqd), body_inv_mass=e(bs * nb),
-                 body_inertia=e(bs * nb, 3, 3), body_inv_inertia=e(bs * nb, 3, 3))
-        if bs == 0:
-            return g
+        f2s, nframes = self._f2s(frame2step)
+        g = out["grads"] if out is not None else self._alloc_grads(bs, nsteps, dev)
+        p = lambda t, name, n=None: _dev(t, name, n) if t.numel() else None
         _check(lib().pd_rollout_backward(
-            self.h, bs, nsteps, float(dt), _dev(q_init, "q_init", bs * nq), _dev(qd_init, "qd_init", bs * nqd),
-            _dev(torques, "torques", nsteps * bs * nqd), _dev(refs, "refs", nsteps * bs * nqd),
-            _dev(target_ke, "target_ke", bs * nqd), _dev(target_kd, "target_kd", bs * nqd),
-            _dev(body_inv_mass, "body_inv_mass", bs * nb), _dev(body_inertia, "body_inertia", bs * nb * 9),
-            _dev(body_inv_inertia, "body_inv_inertia", bs * nb * 9), nframes, ctypes.c_void_p(frame_of_step.data_ptr()),
-            _dev(ws, "workspace", self.workspace_floats(bs, nsteps)), _dev(adj_pos, "adj_pos", nframes * bs * nb * 7),
-            _dev(adj_vel, "adj_vel", nframes * bs * nb * 6), _dev(g["q_init"], "g"), _dev(g["qd_init"], "g"),
-            _dev(g["torques"], "g"), _dev(g["res_f"], "g"), _dev(g["refs"], "g"), _dev(g["target_ke"], "g"),
-            _dev(g["target_kd"], "g"), _dev(g["body_inv_mass"], "g"), _dev(g["body_inertia"], "g"),
-            _dev(g["body_inv_inertia"], "g"), _stream()))
+            self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
+            p(torques, "torques", nsteps * bs * nqd), p(refs, "refs", nsteps * bs * nqd),
+            p(target_ke, "target_ke", bs * nqd), p(target_kd, "target_kd", bs * nqd),
+            p(body_inv_mass, "body_inv_mass", bs * nb), p(body_inertia, "body_inertia", bs * nb * 9),
+            p(body_inv_inertia, "body_inv_inertia", bs * nb * 9), nframes, f2s,
+            p(ws, "workspace", self.workspace_floats(bs, nsteps)), p(adj_pos, "adj_pos", nframes * bs * nb * 7),
+            p(adj_vel, "adj_vel", nframes * bs * nb * 6), p(g["q_init"], "g"), p(g["qd_init"], "g"),
+            p(g["torques"], "g"), p(g["res_f"], "g"), p(g["refs"], "g"), p(g["target_ke"], "g"),
+            p(g["target_kd"], "g"), p(g["body_inv_mass"], "g"), p(g["body_inertia"], "g"),
+            p(g["body_inv_inertia"], "g"), _stream()))
         return g
 
     # -- FK -----------------------------------------------------------------------
@@ -220,14 +268,6 @@ def se3_loss(pred, gt, rot_ratio, want_grads=True):
     if rc != 0:
         raise RuntimeError("pd_se3_loss failed (rc %d)" % rc)
     return loss, gp, gg
-
-
-def set_timing(on):
-    lib().pd_set_timing(1 if on else 0)
-
-
-def last_kernel_ms(kind):
-    return float(lib().pd_last_kernel_ms(int(kind)))
 
 
 def device_model(env):

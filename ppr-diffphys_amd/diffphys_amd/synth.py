@@ -69,13 +69,18 @@ def fk_pose_np(tpl, joint_q):
 
 
 def lowest_contact_y(tpl, joint_q):
-    """min over contact candidates of world y, per env."""
+    """min over contact candidates of world y, per env (only the y-row of each body's rotation is needed)."""
     bq = fk_pose_np(tpl, joint_q)
+    x, y, z, w = np.moveaxis(bq[..., 3:], -1, 0)
+    Ry = np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1)  # [bs, nb, 3]
     cb = tpl["contact_body"].astype(np.int64)
     pts = tpl["contact_point"].astype(np.float64)
-    X = bq[:, cb]
-    y = X[..., 1] + _qrot(X[..., 3:], np.broadcast_to(pts, X[..., :3].shape))[..., 1] - tpl["contact_dist"][None]
-    return y.min(-1)
+    out = np.full(bq.shape[0], np.inf)
+    for b in np.unique(cb):
+        sel = cb == b
+        yb = bq[:, b, 1][:, None] + Ry[:, b] @ pts[sel].T - tpl["contact_dist"][sel][None]
+        out = np.minimum(out, yb.min(-1))
+    return out
 
 
 def make_inputs(tpl, robot, bs, nsteps, seed=0, seqs=("mi-pace",), steps_per_frame=33, dt=DT, dtype=np.float32,
@@ -134,6 +139,75 @@ def make_inputs(tpl, robot, bs, nsteps, seed=0, seqs=("mi-pace",), steps_per_fra
     out["frame2step"] = frame2step
     out["nsteps"] = nsteps
     out["dt"] = dt
+    return out
+
+
+def make_env_inputs(tpl, robot, env_ids, nsteps, seed=0, seqs=("mi-pace",), steps_per_frame=33, dt=DT, dtype=np.float32,
+                    penetration=0.0):
+    """Same workload as :func:`make_inputs`, but every env draws from its OWN generator seeded by (seed, global env id):
+    the inputs of env e do not depend on which other envs are built with it.  A rank of a multi-GPU run builds exactly
+    its contiguous slice of the global batch (bench.py) and the concatenation of the slices is
+    the global batch, bit for bit, for any world size."""
+    env_ids = np.asarray(env_ids, dtype=np.int64)
+    bs = len(env_ids)
+    nb, nq, nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+    ndof = nqd - 6
+    frame2step = list(range(0, nsteps, steps_per_frame))
+    F = len(frame2step)
+    t = np.arange(nsteps)
+    q_init = np.zeros((bs, nq))
+    refs = np.zeros((nsteps, bs, nqd))
+    adj_pos = np.zeros((F, bs, nb, 7))
+    adj_vel = np.zeros((F, bs, nb, 6))
+    amps = {s: DataLoader({"seqname": s}).amp_info for s in set(seqs)} if robot == "laikago" else {}
+    for i, e in enumerate(env_ids):
+        rng = np.random.RandomState([int(seed) & 0x7fffffff, int(e)])
+        yaw = rng.uniform(-0.1, 0.1)
+        q_init[i, 3:7] = [0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)]
+        if robot == "laikago":
+            amp = amps[seqs[int(e) % len(seqs)]]
+            nfr = len(amp)
+            span = (nsteps - 1) / steps_per_frame
+            f0 = rng.randint(0, max(1, int(nfr - span - 1)))
+            fr = f0 + t / steps_per_frame
+            lo = np.clip(np.floor(fr).astype(int), 0, nfr - 2)
+            a = (fr - lo)[:, None]
+            msm = parse_amp(amp[lo] * (1 - a) + amp[lo + 1] * a)
+            refs[:, i, 6:] = msm["jang"]
+            q_init[i, 7:] = msm["jang"][0]
+        else:
+            q_init[i, 7:] = rng.uniform(-0.2, 0.2, size=ndof)
+            phase = rng.uniform(0, 2 * np.pi, size=ndof)
+            refs[:, i, 6:] = q_init[i, 7:][None] + 0.3 * np.sin(2 * np.pi * 2.0 * (t * dt)[:, None] + phase[None])
+        adj_pos[:, i] = rng.randn(F, nb, 7) * 1e-3
+        adj_vel[:, i] = rng.randn(F, nb, 6) * 1e-3
+    q_init[:, 1] = -lowest_contact_y(tpl, q_init) - penetration if bs else 0.0
+    kp, kd = float(tpl["kp"]), float(tpl["kd"])
+    mass = np.tile(tpl["body_mass"].astype(np.float64), bs)
+    inertia = np.tile(tpl["body_inertia"].astype(np.float64), (bs, 1, 1)) * mass[:, None, None]
+    out = dict(
+        q_init=q_init.reshape(-1), qd_init=np.zeros(bs * nqd), torques=np.zeros((nsteps, bs * nqd)),
+        res_f=np.zeros((nsteps, bs * nb, 6)), refs=refs.reshape(nsteps, bs * nqd),
+        target_ke=np.tile(np.r_[np.zeros(6), np.full(ndof, kp)], bs), target_kd=np.tile(np.r_[np.zeros(6), np.full(ndof, kd)], bs),
+        body_mass=mass, body_inv_mass=1.0 / mass, body_inertia=inertia,
+        body_inv_inertia=np.linalg.inv(inertia) if bs else inertia,
+        adj_pos=adj_pos.reshape(F, bs * nb, 7), adj_vel=adj_vel.reshape(F, bs * nb, 6),
+    )
+    out = {k: np.ascontiguousarray(v.astype(dtype)) for k, v in out.items()}
+    out.update(frame2step=frame2step, nsteps=nsteps, dt=dt)
+    return out
+
+
+def concat_envs(parts, nb):
+    """Concatenates per-slice input / output dicts along the env axis (env-major flat layouts of SURVEY.md row a7)."""
+    out = {}
+    for k, v in parts[0].items():
+        if not isinstance(v, np.ndarray):
+            out[k] = v
+        elif k in ("torques", "refs", "res_f", "adj_pos", "adj_vel", "wp_pos", "wp_vel", "grf", "jaf"):  # [T or F, bs*n, ...]
+            out[k] = np.concatenate([p[k] for p in parts], axis=1)
+        else:
+            out[k] = np.concatenate([p[k] for p in parts], axis=0)
     return out
 
 

@@ -17,8 +17,8 @@ if int(z["segw"]):
 FWD = ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia")
 t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in FWD}
 bs = inp["q_init"].size // dm.nq
-fos = dp_model.frame_of_step_tensor(T, f2s, dev)
-pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, dt, *[t[k] for k in FWD], frame_of_step=fos, nframes=len(f2s))
+fos = list(f2s)
+pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, dt, *[t[k] for k in FWD], frame2step=fos)
 F, nb = len(f2s), dm.nb
 e = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = grf.cpu().numpy().reshape(F, bs, nb, 6); r = z["ref_grf"].reshape(F, bs, nb, 6)

@@ -20,8 +20,8 @@ if int(z["segw"]):
 FWD = ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia")
 t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in FWD}
 bs = inp["q_init"].size // dm.nq; nb = dm.nb
-fos = dp_model.frame_of_step_tensor(T, f2s, dev)
-pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, dt, *[t[k] for k in FWD], frame_of_step=fos, nframes=T)
+fos = list(f2s)
+pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, dt, *[t[k] for k in FWD], frame2step=fos)
 ref_c.build()
 s32 = RefC(tpl, np.float32).rollout_forward(inp, T, f2s, dt)
 s64 = RefC(tpl, np.float64).rollout_forward(inp, T, f2s, dt)

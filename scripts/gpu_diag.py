@@ -26,12 +26,12 @@ def run(name, bs, nsteps, segw, seqs=("mi-pace",), perturb=True):
     if segw: dm.set_segment_width(segw)
     dev = torch.device("cuda:0")
     t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
-    fos = dp_model.frame_of_step_tensor(nsteps, f2s, dev)
+    fos = list(f2s)
     args = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
-    wp_pos, wp_vel, grf, jaf, ws = dm.rollout_forward(bs, nsteps, inp["dt"], *args, frame_of_step=fos, nframes=len(f2s))
+    wp_pos, wp_vel, grf, jaf, ws = dm.rollout_forward(bs, nsteps, inp["dt"], *args, frame2step=fos)
     torch.cuda.synchronize()
     a2 = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
-    g = dm.rollout_backward(bs, nsteps, inp["dt"], *a2, fos, len(f2s), ws, torch.from_numpy(inp["adj_pos"]).to(dev), torch.from_numpy(inp["adj_vel"]).to(dev))
+    g = dm.rollout_backward(bs, nsteps, inp["dt"], *a2, fos, ws, torch.from_numpy(inp["adj_pos"]).to(dev), torch.from_numpy(inp["adj_vel"]).to(dev))
     torch.cuda.synchronize()
     print("== %s bs=%d T=%d segw=%d" % (name, bs, nsteps, dm.segment_width()))
     for dt_, lab in ((np.float32, "c32"), (np.float64, "c64")):
@@ -65,21 +65,20 @@ if __name__ == "__main__":
     run("human", 3, 40, 64)
     run("quad", 7, 40, 0)
     # timing
-    hip_backend.set_timing(True)
     for name, bs, segw in (("laikago", 4096, 16), ("laikago", 4096, 32), ("laikago", 4096, 64), ("human", 1024, 32), ("quad", 8192, 32)):
         tpl = robots.load_template(name)
         nsteps = 100
         inp = synth.make_inputs(tpl, name, bs=bs, nsteps=nsteps, seed=0, seqs=("mi-trot", "mi-spin"))
-        dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw)
+        dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw); dm.set_timing(True)
         dev = torch.device("cuda:0")
         t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
-        f2s = inp["frame2step"]; fos = dp_model.frame_of_step_tensor(nsteps, f2s, dev)
+        f2s = inp["frame2step"]; fos = list(f2s)
         args = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
         a2 = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
         ap = torch.from_numpy(inp["adj_pos"]).to(dev); av = torch.from_numpy(inp["adj_vel"]).to(dev)
         for it in range(3):
-            out = dm.rollout_forward(bs, nsteps, inp["dt"], *args, frame_of_step=fos, nframes=len(f2s))
-            g = dm.rollout_backward(bs, nsteps, inp["dt"], *a2, fos, len(f2s), out[4], ap, av)
+            out = dm.rollout_forward(bs, nsteps, inp["dt"], *args, frame2step=fos)
+            g = dm.rollout_backward(bs, nsteps, inp["dt"], *a2, fos, out[4], ap, av)
             torch.cuda.synchronize()
-            f, b = hip_backend.last_kernel_ms(0), hip_backend.last_kernel_ms(1)
+            f, b = dm.last_kernel_ms(0), dm.last_kernel_ms(1)
         print("TIMING %s bs=%d segw=%d T=%d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s" % (name, bs, segw, nsteps, f, b, bs * nsteps / ((f + b) * 1e-3)))

@@ -13,9 +13,9 @@ seqs = ("mi-trot", "mi-spin") if name == "laikago" else ("mi-pace",)
 inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=1000, seqs=seqs)
 dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw)
 t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
-f2s = inp["frame2step"]; fos = dp_model.frame_of_step_tensor(T, f2s, dev)
+f2s = inp["frame2step"]; fos = list(f2s)
 fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
-out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame_of_step=fos, nframes=len(f2s))
+out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=fos)
 torch.cuda.synchronize()
 nb = int(tpl["nb"])
 ws = out[4]

@@ -14,7 +14,7 @@ tpl = robots.load_template(name); T = 100
 inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=0, seqs=("mi-trot", "mi-spin"))
 dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw)
 t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
-f2s = inp["frame2step"]; fos = dp_model.frame_of_step_tensor(T, f2s, dev)
+f2s = inp["frame2step"]; fos = list(f2s)
 fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
 ba = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
 ap = torch.from_numpy(inp["adj_pos"]).to(dev); av = torch.from_numpy(inp["adj_vel"]).to(dev)
@@ -23,11 +23,11 @@ dbg = torch.zeros(nw * 16, dtype=torch.int64, device=dev)
 L = hip_backend.lib()
 L.pd_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
 for it in range(2):
-    out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame_of_step=fos, nframes=len(f2s))
+    out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=fos)
 torch.cuda.synchronize()
 f_all = dbg.view(-1, 16).cpu().numpy().astype(np.float64)[: (nw // 8) * 8]
 dbg.zero_()
-g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, len(f2s), out[4], ap, av)
+g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, out[4], ap, av)
 torch.cuda.synchronize()
 b_all = dbg.view(-1, 16).cpu().numpy().astype(np.float64)[: (nw // 8) * 8]
 def rows(arr, contact):

@@ -20,9 +20,9 @@ def gpu(dm, inp):
     bs = inp["q_init"].size // dm.nq
     T, f2s = inp["nsteps"], inp["frame2step"]
     t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
-    fos = dp_model.frame_of_step_tensor(T, f2s, dev)
-    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame_of_step=fos, nframes=len(f2s))
-    g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, len(f2s), ws, t["adj_pos"], t["adj_vel"])
+    fos = list(f2s)
+    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=fos)
+    g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, ws, t["adj_pos"], t["adj_vel"])
     out = dict(wp_pos=pos.cpu().numpy(), wp_vel=vel.cpu().numpy(), grf=grf.cpu().numpy(), jaf=jaf.cpu().numpy())
     out.update({"g_" + k: v.cpu().numpy() for k, v in g.items()})
     return out

@@ -10,25 +10,24 @@ cfgs = [("laikago", 4096, 16), ("laikago", 4096, 32), ("laikago", 4096, 64), ("l
         ("human", 1024, 32), ("quad", 8192, 32)]
 if len(sys.argv) > 1:
     cfgs = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:]]
-hip_backend.set_timing(True)
 dev = torch.device("cuda:0")
 for name, bs, segw in cfgs:
     tpl = robots.load_template(name)
     T = 100
     inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=0, seqs=("mi-trot", "mi-spin"))
-    dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw)
+    dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw); dm.set_timing(True)
     t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
-    f2s = inp["frame2step"]; fos = dp_model.frame_of_step_tensor(T, f2s, dev)
+    f2s = inp["frame2step"]; fos = list(f2s)
     fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
     ba = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
     ap = torch.from_numpy(inp["adj_pos"]).to(dev); av = torch.from_numpy(inp["adj_vel"]).to(dev)
     fs, bs_ = [], []
     for it in range(8):
-        out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame_of_step=fos, nframes=len(f2s))
-        g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, len(f2s), out[4], ap, av)
+        out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=fos)
+        g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, out[4], ap, av)
         torch.cuda.synchronize()
         if it >= 3:
-            fs.append(hip_backend.last_kernel_ms(0)); bs_.append(hip_backend.last_kernel_ms(1))
+            fs.append(dm.last_kernel_ms(0)); bs_.append(dm.last_kernel_ms(1))
     f, b = np.median(fs), np.median(bs_)
     nb, nqd = int(tpl["nb"]), int(tpl["nqd"]); C = 2 * nqd + 6 * nb; B = 4 * (26 * nb + 3 * C)
     print("TIMING %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (

@@ -87,3 +87,56 @@ def golden_inputs(g):
     inp["frame2step"] = [int(x) for x in g["frame2step"]]
     inp["nsteps"], inp["dt"] = int(g["nsteps"]), float(g["dt"])
     return inp
+
+
+def tight_inputs(tpl, robot, bs, T, seed):
+    """Non-singular inputs for the short-horizon tight-tolerance tests: feet a few mm in the ground, joint angles away
+    from their references (no acos at 1), non-zero twists, torques, residual wrenches, perturbed gains / masses, and
+    frames at states 0 and T (so every gradient is exercised through exactly T steps)."""
+    from diffphys_amd import synth
+
+    inp = synth.make_inputs(tpl, robot, bs=bs, nsteps=T, seed=seed, steps_per_frame=max(T, 1), penetration=0.004)
+    rng = np.random.RandomState(seed + 1)
+    nb, nqd = int(tpl["nb"]), int(tpl["nqd"])
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    inp["qd_init"] = f32(rng.randn(bs * nqd) * 0.2)
+    inp["torques"] = f32(rng.randn(T, bs * nqd) * 0.5)
+    inp["res_f"] = f32(rng.randn(T, bs * nb, 6) * 0.5)
+    inp["refs"] = f32(inp["refs"] + rng.uniform(0.05, 0.15, inp["refs"].shape) * np.sign(rng.randn(*inp["refs"].shape)))
+    inp["refs"].reshape(T, bs, nqd)[:, :, :6] = 0
+    inp["target_ke"] = f32(inp["target_ke"] * rng.uniform(0.8, 1.2, bs * nqd))
+    inp["target_kd"] = f32(inp["target_kd"] * rng.uniform(0.8, 1.2, bs * nqd))
+    scale = rng.uniform(0.8, 1.25, bs * nb)
+    mass = inp["body_mass"].astype(np.float64) * scale
+    inertia = inp["body_inertia"].astype(np.float64) * scale[:, None, None]
+    inp.update(body_mass=f32(mass), body_inv_mass=f32(1.0 / mass), body_inertia=f32(inertia),
+               body_inv_inertia=f32(np.linalg.inv(inertia)))
+    inp["frame2step"] = [0, T]
+    inp["adj_pos"] = f32(rng.randn(2, bs * nb, 7))
+    inp["adj_vel"] = f32(rng.randn(2, bs * nb, 6))
+    return inp
+
+
+def per_env(a, bs, lead):
+    """[lead..., bs*n, ...] -> [bs, -1]: groups a flat env-major tensor by env (lead = number of leading step/frame axes)."""
+    a = np.asarray(a, np.float64)
+    if lead == 0:
+        return a.reshape(bs, -1)
+    t = a.shape[0]
+    return np.moveaxis(a.reshape(t, bs, -1), 1, 0).reshape(bs, -1)
+
+
+GRAD_LEAD = dict(q_init=0, qd_init=0, torques=1, res_f=1, refs=1, target_ke=0, target_kd=0, body_inv_mass=0, body_inertia=0,
+                 body_inv_inertia=0)
+
+
+def grad_env_errors(g, r, bs):
+    """Per gradient tensor: per-env max |g - r| relative to that env's max |r| (envs whose reference gradient is
+    identically zero are compared absolutely against the tensor's max)."""
+    out = {}
+    for k, lead in GRAD_LEAD.items():
+        a, b = per_env(g[k], bs, lead), per_env(r[k], bs, lead)
+        scale = np.abs(b).max(1)
+        scale = np.where(scale > 0, scale, np.abs(b).max() + 1e-30)
+        out[k] = np.abs(a - b).max(1) / scale
+    return out

@@ -35,11 +35,11 @@ def gpu_rollout(dm, inp, dev, backward=True):
     bs = inp["q_init"].size // dm.nq
     T, f2s = inp["nsteps"], inp["frame2step"]
     t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
-    fos = dp_model.frame_of_step_tensor(T, f2s, dev)
-    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame_of_step=fos, nframes=len(f2s))
+    fos = list(f2s)
+    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=fos)
     out = dict(wp_pos=pos.cpu().numpy(), wp_vel=vel.cpu().numpy(), grf=grf.cpu().numpy(), jaf=jaf.cpu().numpy())
     if backward:
-        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, len(f2s), ws, t["adj_pos"], t["adj_vel"])
+        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, ws, t["adj_pos"], t["adj_vel"])
         out["grads"] = {k: v.cpu().numpy() for k, v in g.items()}
     return out
 
@@ -145,7 +145,9 @@ def test_full_size_properties_and_batch_invariance(dev):
         assert all(np.array_equal(again["grads"][k], full["grads"][k]) for k in full["grads"])
 
 
-@pytest.mark.parametrize("bs,T,f2s", [(1, 1, [0]), (3, 2, [0, 1]), (17, 5, [4]), (5, 7, [0, 3, 6])])
+# (1, 50, [0, 33]) is BASELINE config C1: Laikago mi-pace, ONE env, 50-step rollout, frames 0 and 33 -- run on the HIP path
+# (the oracle is only the checker)
+@pytest.mark.parametrize("bs,T,f2s", [(1, 1, [0]), (3, 2, [0, 1]), (17, 5, [4]), (5, 7, [0, 3, 6]), (1, 50, [0, 33])])
 def test_edge_shapes(bs, T, f2s, dev, oracle_libs):
     from diffphys_amd import hip_backend, robots, synth
     from oracle.ref_c import RefC
@@ -392,9 +394,9 @@ def test_empty_batch_and_graph_capture(dev):
     tpl = robots.load_template("laikago")
     dm = hip_backend.DeviceModel(tpl)
     z = lambda *s: torch.zeros(*s, device=dev)
-    fos = dp_model.frame_of_step_tensor(5, [0, 4], dev)
+    fos = [0, 4]
     pos, vel, grf, jaf, ws = dm.rollout_forward(0, 5, 5e-4, z(0), z(0), z(5, 0), z(5, 0, 6), z(5, 0), z(0), z(0), z(0), z(0, 3, 3), z(0, 3, 3),
-                                                frame_of_step=fos, nframes=2)
+                                                frame2step=fos)
     assert pos.shape == (2, 0, 7) and vel.shape == (2, 0, 6) and ws.numel() == 0
     bq, bqd = dm.fk_forward(z(0, 19), z(0, 18))
     assert bq.shape == (0, 13, 7)
@@ -402,12 +404,12 @@ def test_empty_batch_and_graph_capture(dev):
     bs, T = 64, 34
     inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=1, penetration=0.002)
     t = {k: torch.from_numpy(inp[k]).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
-    fos = dp_model.frame_of_step_tensor(T, inp["frame2step"], dev)
+    fos = list(inp["frame2step"])
     F = len(inp["frame2step"])
 
     def run():
-        o = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame_of_step=fos, nframes=F)
-        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, F, o[4], t["adj_pos"], t["adj_vel"])
+        o = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=fos)
+        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, o[4], t["adj_pos"], t["adj_vel"])
         return o[0], g["q_init"]
 
     ref_pos, ref_g = run()

@@ -1,0 +1,278 @@
+"""Round-2 parity hardening (run on a real MI355X with -m gpu; everything goes through the C ABI).
+
+Why these exist: the oracle cannot be pinned to Warp, so the tests are all there is.  Two regimes:
+
+  * SHORT HORIZON (1 and 3 steps), float64 C oracle, every output and all 10 gradient tensors.  Over a few steps nothing
+    is chaotic, so a kernel error cannot hide behind "fp32 divergence".  The bar for each quantity is
+        err(GPU fp32 vs oracle fp64)  <=  max(4 x err(C oracle fp32 vs oracle fp64), floor)   and   <= cap
+    i.e. the kernels must be as accurate as a plain fp32 evaluation of the same formulas (the fp32 C oracle is computed
+    in the test), with absolute caps: poses 2e-6, twists 2e-5 (Laikago 1e-3), wrenches 3e-4, every gradient tensor
+    1e-4 relmax for human / quad (BASELINE config C5's number) and 2e-3 for Laikago, whose 0.16 kg links on 16 kN/m
+    attachment springs turn 1 ulp of position into 1e-4 of angular velocity in ANY fp32 evaluation (the fp32 C oracle
+    itself is at 1.2e-4 / 3.8e-4, measured below).
+  * CONFIG SIZES (BASELINE C2 256x100, C3 human 1024x100, C4 4096x100 trot+spin): every gradient tensor, per env.
+    Human rollouts are well conditioned: per-env max error < 1e-3 for every env and tensor.  Laikago 100-step rollouts
+    are chaotic at the stiff contacts (the fp32 and fp64 C oracles disagree by O(1) in ~10 % of envs), so the bar is the
+    distribution: per tensor the median per-env error < 2e-2, and of the envs on which the two ORACLES agree (< 1e-2)
+    at least 90 % agree on the GPU too (< 5e-2).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GRAD_LEAD, INPUT_NAMES, grad_env_errors, relmax, tight_inputs
+from test_gpu_parity import BWD, FWD, gpu_rollout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on a GPU box"
+    return torch.device("cuda:0")
+
+
+def _oracle(tpl, inp, dtype):
+    from oracle.ref_c import RefC
+
+    rc = RefC(tpl, dtype)
+    st = rc.rollout_forward(inp, inp["nsteps"], inp["frame2step"], inp["dt"])
+    return st, rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+
+
+CAPS = {  # absolute caps (relmax per tensor): pose, twist, wrench, gradient
+    "laikago": (2e-6, 1e-3, 3e-4, 2e-3),
+    "human": (2e-6, 2e-5, 3e-4, 1e-4),
+    "quad": (2e-6, 2e-5, 3e-4, 1e-4),
+}
+
+
+@pytest.mark.parametrize("T", [1, 3])
+@pytest.mark.parametrize("name", ["laikago", "human", "quad"])
+def test_short_horizon_tight(name, T, dev, oracle_libs):
+    from diffphys_amd import hip_backend, robots
+
+    tpl = robots.load_template(name)
+    bs = 48
+    inp = tight_inputs(tpl, name, bs, T, seed=11 + T)
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    s64, g64 = _oracle(tpl, inp, np.float64)
+    s32, g32 = _oracle(tpl, inp, np.float32)
+    assert np.abs(s64["grf"]).max() > 10.0 and np.abs(s64["jaf"]).max() > 1.0, "contacts and joints must be loaded"
+    cap_p, cap_v, cap_w, cap_g = CAPS[name]
+
+    def check(what, a, c32, ref, cap, floor):
+        e_gpu, e_c = relmax(a, ref), relmax(c32, ref)
+        assert np.isfinite(e_gpu) and e_gpu <= cap, "%s: GPU error %.2e above the cap %.1e (fp32 C oracle: %.2e)" % (what, e_gpu, cap, e_c)
+        assert e_gpu <= max(4 * e_c, floor), "%s: GPU error %.2e vs fp32 C oracle %.2e" % (what, e_gpu, e_c)
+
+    check("wp_pos", out["wp_pos"], s32["wp_pos"], s64["wp_pos"], cap_p, 1e-6)
+    check("wp_vel", out["wp_vel"], s32["wp_vel"], s64["wp_vel"], cap_v, 1e-6)
+    check("grf", out["grf"], s32["grf"], s64["grf"], cap_w, 1e-5)
+    check("jaf", out["jaf"], s32["jaf"], s64["jaf"], cap_w, 1e-5)
+    assert np.abs(out["grf"][1]).max() == 0 and np.abs(out["jaf"][1]).max() == 0  # frame at state T: no force snapshot
+    for k in GRAD_LEAD:
+        ref = g64[k]
+        assert np.abs(ref).max() > 0, k
+        check("grad " + k, out["grads"][k].reshape(ref.shape), g32[k], ref, cap_g, 1e-5)
+
+
+def _config_inputs(cfg):
+    from diffphys_amd import robots, synth
+
+    name, bs, seqs, seed = {"C2": ("laikago", 256, ("mi-pace",), 4), "C3": ("human", 1024, ("mi-pace",), 12),
+                            "C4": ("laikago", 4096, ("mi-trot", "mi-spin"), 9)}[cfg]
+    tpl = robots.load_template(name)
+    return name, tpl, bs, synth.make_inputs(tpl, name, bs=bs, nsteps=100, seed=seed, penetration=0.002, seqs=seqs)
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_config_size_gradients_every_tensor_per_env(cfg, dev, oracle_libs):
+    """BASELINE configs C2 / C3 / C4 at full size (C4 = the headline 4096 x 100 batch): poses with the statistical bar of
+    the module docstring of test_gpu_parity, and EVERY gradient tensor per env against the C oracles."""
+    from diffphys_amd import hip_backend
+
+    name, tpl, bs, inp = _config_inputs(cfg)
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    s64, g64 = _oracle(tpl, inp, np.float64)
+    s32, g32 = _oracle(tpl, inp, np.float32)
+    F = len(inp["frame2step"])
+    e = np.abs(out["wp_pos"].astype(np.float64) - s32["wp_pos"]).reshape(F, bs, -1).max((0, 2))
+    assert np.median(e) < 1e-5 and np.percentile(e, 90) < 1e-3, (np.median(e), np.percentile(e, 90))
+    assert all(np.isfinite(v).all() for v in out["grads"].values())
+    e_gpu = grad_env_errors(out["grads"], g64, bs)   # GPU fp32 vs float64 oracle
+    e_c32 = grad_env_errors(g32, g64, bs)            # fp32 oracle vs float64 oracle: the conditioning of each env
+    for k in GRAD_LEAD:
+        if name == "human":  # well conditioned: every env, every tensor
+            assert e_gpu[k].max() < 1e-3, (k, float(e_gpu[k].max()), float(e_c32[k].max()))
+            continue
+        regular = e_c32[k] < 1e-2
+        assert regular.mean() > 0.5, (k, float(regular.mean()))
+        assert np.median(e_gpu[k]) < 2e-2, (k, float(np.median(e_gpu[k])), float(np.median(e_c32[k])))
+        agree = (e_gpu[k][regular] < 5e-2).mean()
+        assert agree >= 0.9, (k, float(agree))
+
+
+def test_frames_validated_on_the_host_and_final_state_frame(dev, oracle_libs):
+    """frame2step is checked before anything is launched (range, no step twice); a frame may name the state after the
+    last step (state_steps has nsteps + 1 entries in the reference) and then matches the oracle, with its
+    gradient seed entering the reverse sweep."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template("laikago")
+    dm = hip_backend.DeviceModel(tpl)
+    bs, T = 5, 7
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=3, penetration=0.002)
+    rng = np.random.RandomState(0)
+    for f2s in ([T], [3, T, 0], []):
+        F = len(f2s)
+        inp["frame2step"] = f2s
+        inp["adj_pos"] = (rng.randn(F, bs * 13, 7) * 1e-3).astype(np.float32)
+        inp["adj_vel"] = (rng.randn(F, bs * 13, 6) * 1e-3).astype(np.float32)
+        out = gpu_rollout(dm, inp, dev)
+        st, gr = _oracle(tpl, inp, np.float32)
+        assert out["wp_pos"].shape == (F, bs * 13, 7)
+        if F == 0:
+            assert all(np.abs(v).max() == 0 for v in out["grads"].values())
+            continue
+        assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 2e-3
+        assert relmax(out["grf"], st["grf"]) < 5e-3 or np.abs(st["grf"]).max() == 0
+        fT = f2s.index(T)
+        assert np.abs(out["grf"][fT]).max() == 0 and np.abs(out["jaf"][fT]).max() == 0
+        for k in ("q_init", "qd_init", "refs", "res_f", "body_inertia"):
+            assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, (f2s, k)
+    t = {k: torch.from_numpy(inp[k]).to(dev) for k in INPUT_NAMES}
+    for bad in ([T + 1], [-1], [2, 2], [0, 3, 0]):
+        with pytest.raises(RuntimeError, match="frame2step"):
+            dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=bad)
+
+
+def test_per_env_joint_X_p_binding(dev, oracle_libs):
+    """pd_model_bind_joint_X_p (the lab4d path's env.joint_X_p rebind, dp_interface.py:465): every env rolls out with its
+    own joint_X_p, equal to an oracle built from that env's template; a pointer swap, no rebuild."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template("laikago")
+    bs, T, nb = 6, 12, 13
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=2, steps_per_frame=5, penetration=0.003)
+    rng = np.random.RandomState(5)
+    xp = np.tile(tpl["joint_X_p"].astype(np.float32), (bs, 1, 1))
+    xp[:, 1:, :3] *= rng.uniform(0.9, 1.15, (bs, nb - 1, 1)).astype(np.float32)   # per-env limb lengths
+    dm = hip_backend.DeviceModel(tpl)
+    base = gpu_rollout(dm, inp, dev)
+    xp_dev = torch.from_numpy(xp.reshape(bs * nb, 7)).to(dev)
+    dm.bind_joint_X_p(xp_dev)
+    out = gpu_rollout(dm, inp, dev)
+    assert relmax(out["wp_pos"], base["wp_pos"]) > 1e-3   # it matters
+    for e in range(bs):
+        te = dict(tpl)
+        te["joint_X_p"] = xp[e]
+        sub = {k: v for k, v in inp.items()}
+        cut = lambda a, lead: np.ascontiguousarray(a.reshape(lead + (bs, -1))[..., e:e + 1, :].reshape(lead + (-1,)))
+        for k in ("q_init", "qd_init", "target_ke", "target_kd", "body_mass", "body_inv_mass"):
+            sub[k] = cut(inp[k], ())
+        for k in ("torques", "refs"):
+            sub[k] = cut(inp[k], (T,))
+        sub["res_f"] = np.ascontiguousarray(inp["res_f"].reshape(T, bs, nb, 6)[:, e].reshape(T, nb, 6))
+        for k in ("body_inertia", "body_inv_inertia"):
+            sub[k] = np.ascontiguousarray(inp[k].reshape(bs, nb, 3, 3)[e])
+        F = len(inp["frame2step"])
+        sub["adj_pos"] = np.ascontiguousarray(inp["adj_pos"].reshape(F, bs, nb, 7)[:, e])
+        sub["adj_vel"] = np.ascontiguousarray(inp["adj_vel"].reshape(F, bs, nb, 6)[:, e])
+        st, gr = _oracle(te, sub, np.float32)
+        assert relmax(out["wp_pos"].reshape(F, bs, nb, 7)[:, e], st["wp_pos"].reshape(F, nb, 7)) < 5e-5, e
+        assert relmax(out["grads"]["q_init"].reshape(bs, -1)[e], gr["q_init"]) < 2e-2, e
+    # FK uses env i % n_envs of the binding (the reference runs eval_fk frame by frame on the same n_envs model)
+    jq = torch.from_numpy(np.tile(inp["q_init"].reshape(bs, -1), (2, 1))).to(dev)
+    bq, _ = dm.fk_forward(jq, torch.zeros(2 * bs, 18, device=dev))
+    assert torch.equal(bq[:bs], bq[bs:])
+    assert relmax(bq[:bs].cpu().numpy().reshape(-1, 7), out["wp_pos"][0]) < 1e-6
+    with pytest.raises(RuntimeError, match="bound for"):   # a rollout of another batch size while 6 envs are bound
+        gpu_rollout(dm, synth.make_inputs(tpl, "laikago", bs=3, nsteps=T, seed=2, steps_per_frame=5), dev)
+    dm.bind_joint_X_p(None)
+    again = gpu_rollout(dm, inp, dev)
+    assert np.array_equal(again["wp_pos"], base["wp_pos"])
+
+
+def test_two_shards_on_two_streams_equal_the_global_batch(dev):
+    """Multi-GPU path on the PRODUCT code: the env slices bench.py gives two ranks -- built by the same
+    bench.rank_inputs -- are rolled out by the HIP library concurrently on two streams, with two device models (as two
+    processes would), and their concatenation equals the single-launch global batch bit for bit, outputs and gradients,
+    in both scaling modes."""
+    import bench
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template("laikago")
+    T, world = 40, 2
+    for scaling, bs_arg, total in (("strong", 71, 71), ("weak", 35, 70)):
+        parts = [bench.rank_inputs(tpl, "laikago", T, world, r, scaling, bs_arg, ("mi-trot", "mi-spin"))[0] for r in range(world)]
+        glob, span, gbs = bench.rank_inputs(tpl, "laikago", T, 1, 0, "strong", total, ("mi-trot", "mi-spin"))
+        assert gbs == total and span == (0, total)
+        cat = synth.concat_envs(parts, 13)
+        assert all(np.array_equal(cat[k], glob[k]) for k in glob if isinstance(glob[k], np.ndarray))
+        full = gpu_rollout(hip_backend.DeviceModel(tpl), glob, dev)
+        outs, streams = [], [torch.cuda.Stream(), torch.cuda.Stream()]
+        for r in range(world):
+            with torch.cuda.stream(streams[r]):
+                outs.append(gpu_rollout(hip_backend.DeviceModel(tpl), parts[r], dev))
+        torch.cuda.synchronize()
+        for k in ("wp_pos", "wp_vel", "grf", "jaf"):
+            assert np.array_equal(np.concatenate([o[k] for o in outs], 1), full[k]), (scaling, k)
+        for k, lead in GRAD_LEAD.items():
+            cg = np.concatenate([o["grads"][k] for o in outs], 1 if lead else 0)
+            assert np.array_equal(cg.reshape(full["grads"][k].shape), full["grads"][k]), (scaling, k)
+
+
+def test_timing_is_per_model_and_launch_info(dev):
+    from diffphys_amd import hip_backend, robots, synth
+
+    tl, th = robots.load_template("laikago"), robots.load_template("human")
+    a, b = hip_backend.DeviceModel(tl), hip_backend.DeviceModel(th)
+    assert a.last_kernel_ms(0) < 0 and b.last_kernel_ms(1) < 0   # nothing timed yet
+    a.set_timing(True)
+    ia = synth.make_inputs(tl, "laikago", bs=64, nsteps=20, seed=1)
+    ib = synth.make_inputs(th, "human", bs=8, nsteps=5, seed=1)
+    gpu_rollout(a, ia, dev)
+    gpu_rollout(b, ib, dev)   # launched later, not timed: must not disturb model a's numbers
+    torch.cuda.synchronize()
+    assert a.last_kernel_ms(0) > 0 and a.last_kernel_ms(1) > 0
+    assert b.last_kernel_ms(0) < 0 and b.last_kernel_ms(1) < 0
+    info = a.last_launch_info(1)
+    assert info["workgroups"] * info["envs_per_wg"] >= 64 and info["threads_per_wg"] % 64 == 0 and info["lds_bytes_per_wg"] > 0
+    a.set_timing(False)
+    assert a.last_kernel_ms(0) < 0
+
+
+@pytest.mark.parametrize("name", ["laikago", "human", "quad"])
+def test_against_round1_bits(name, dev):
+    """A/B against the round-1 library ("keep the A/B in a test"): tests/golden/r01_bits_<robot>.npz
+    hold the raw fp32 outputs of the r01 kernels (scripts/make_r01_bits.py) on the golden inputs and on a 64-env x 100-step
+    batch.  The forward outputs must be bit-identical (the forward arithmetic is unchanged); gradients must either be
+    bit-identical or -- where the adjoint was restructured across waves, which moves FMA contraction boundaries -- agree
+    to 1e-5 of each tensor's max on the golden (34-step) inputs.  The measured distance is printed (pytest -s)."""
+    import os
+
+    from helpers import GOLDEN, golden_inputs, load_golden
+    from diffphys_amd import hip_backend, robots, synth
+
+    path = os.path.join(GOLDEN, "r01_bits_%s.npz" % name)
+    if not os.path.exists(path):
+        pytest.skip("r01 bit fixtures not recorded")
+    with np.load(path) as z:
+        ref = {k: z[k] for k in z.files}
+    tpl = robots.load_template(name)
+    dm = hip_backend.DeviceModel(tpl)
+    for tag, inp in (("golden", golden_inputs(load_golden(name))),
+                     ("bench64", synth.make_env_inputs(tpl, name, range(64), 100, seed=77, seqs=("mi-trot", "mi-spin"), penetration=0.002))):
+        out = gpu_rollout(dm, inp, dev)
+        flat = {k: out[k] for k in ("wp_pos", "wp_vel", "grf", "jaf")}
+        flat.update({"grad_" + k: v for k, v in out["grads"].items()})
+        for k, v in flat.items():
+            r = ref["%s_%s" % (tag, k)]
+            same = np.array_equal(v.reshape(r.shape), r)
+            d = relmax(v.reshape(r.shape), r)
+            print("%s %s %-22s %s relmax %.2e" % (name, tag, k, "bit-identical" if same else "differs", d))
+            if not k.startswith("grad_"):
+                assert same, (tag, k, d)
+            elif tag == "golden":
+                assert same or d < 1e-5, (tag, k, d)

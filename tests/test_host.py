@@ -125,14 +125,40 @@ def test_c_abi_exports_every_declared_symbol():
 
     hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = sorted(set(re.findall(r"\b(pd_[a-z_]+)\s*\(", hdr)))
-    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and len(names) >= 13
+    names = sorted(set(re.findall(r"\b(pd_[A-Za-z0-9_]+)\s*\(", hdr)))
+    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and len(names) == 16
     lib = hip_backend.lib()
     for n in names:
         assert hasattr(lib, n), "missing symbol " + n
-    assert lib.pd_abi_version() == 1
+    assert lib.pd_abi_version() == 2 == hip_backend.ABI_VERSION
+    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == 2
     lib.pd_rollout_workspace_floats.restype = ctypes.c_size_t
     assert lib.pd_rollout_workspace_floats(None, 4, 10) == 0
+
+
+def test_c_abi_argument_errors_without_a_gpu():
+    """Every entry point refuses a null model / bad arguments with a non-zero code and a message (no compute, no GPU
+    needed); creating a model on a box without a GPU fails loudly instead of falling back to anything."""
+    from diffphys_amd import hip_backend
+
+    lib = hip_backend.lib()
+    err = lambda: lib.pd_last_error().decode()
+    f2s = (ctypes.c_int * 2)(0, 1)
+    assert lib.pd_rollout_forward(None, 1, 1, ctypes.c_float(5e-4), *([None] * 10), 2, f2s, *([None] * 5), None) != 0
+    assert "null model" in err()
+    assert lib.pd_rollout_backward(None, 1, 1, ctypes.c_float(5e-4), *([None] * 9), 2, f2s, *([None] * 13), None) != 0
+    assert lib.pd_fk_forward(None, 1, None, None, None, None, None) != 0 and "null model" in err()
+    assert lib.pd_model_bind_joint_X_p(None, None, 0) != 0
+    assert lib.pd_model_set_timing(None, 1) != 0
+    assert lib.pd_last_kernel_ms(None, 0) < 0
+    info = (ctypes.c_int * 4)()
+    assert lib.pd_last_launch_info(None, 0, ctypes.byref(info)) != 0
+    assert lib.pd_model_set_segment_width(None, 16) != 0 and lib.pd_model_get_segment_width(None) == 0
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="ppr_diffphys"):
+            hip_backend.DeviceModel(robots.load_template("laikago"))
 
 
 def test_boundary_rejects_bad_tensors():
@@ -146,13 +172,12 @@ def test_boundary_rejects_bad_tensors():
         hip_backend._dev(np.zeros(4), "x")
 
 
-def test_frame_of_step():
-    from diffphys_amd.dp_model import convert_ppr_warp, frame_of_step_tensor
+def test_convert_and_lazy_host_frames():
+    from diffphys_amd.dp_model import HostFrames, convert_ppr_warp
     import torch
 
-    fos = frame_of_step_tensor(100, [0, 33, 66, 99], "cpu")
-    assert fos.shape == (101,) and fos[33] == 1 and fos[99] == 3 and fos[100] == -1 and int((fos >= 0).sum()) == 4
-    with pytest.raises(ValueError):
-        frame_of_step_tensor(10, [11], "cpu")
+    hf = HostFrames(torch.arange(2 * 3 * 7.0).view(2, 3, 7))
+    assert len(hf) == 2 and hf._host is None          # nothing copied until somebody looks
+    assert hf[1].shape == (3, 7) and hf[1][0, 0] == 21.0 and np.stack(hf, 0).shape == (2, 3, 7)
     x = torch.arange(8.0)
     assert convert_ppr_warp(x).tolist() == [3, 4, 5, 0, 1, 2, 6, 7]

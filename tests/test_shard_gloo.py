@@ -1,6 +1,10 @@
-"""Multi-GPU path on CPU: world_size-2 gloo.  The rollout shards by env slice with no data-path collective
-(SURVEY.md section 8(e)); here two ranks each roll out their slice with the C oracle and the concatenation
-must equal the single-process result bit for bit, and the bench's timing reduction (MAX over ranks) works."""
+"""Multi-GPU path on CPU: world_size-2 gloo, driving the SAME input-building function bench.py uses (bench.rank_inputs).
+
+The rollout shards by contiguous env slices with no data-path collective.  Here two ranks each
+build their slice of the global batch in both scaling modes ("weak": bs envs per rank, "strong": bs envs in total), roll
+it out (with the C oracle -- there is no GPU here; the same check on the HIP library is
+tests/test_gpu_tight.py::test_two_shards_on_two_streams_equal_the_global_batch), gather, and rank 0 compares with the
+single-process global batch bit for bit.  The bench's timing reduction (barrier + MAX over ranks) runs on the same group."""
 import os
 import sys
 
@@ -18,43 +22,45 @@ def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    from diffphys_amd import robots, synth
+    from diffphys_amd import robots
     from oracle.ref_c import RefC
 
     tpl = robots.load_template("laikago")
-    gbs, T = 6, 12
-    inp = synth.make_inputs(tpl, "laikago", bs=gbs, nsteps=T, seed=5, steps_per_frame=5, penetration=0.002)
-    lo, hi = bench.shard_envs(gbs, world, rank)
-    nb, nq, nqd = 13, 19, 18
-
-    def sl(a, per, lead):
-        return np.ascontiguousarray(a.reshape(lead + (gbs, per))[..., lo:hi, :].reshape(lead + ((hi - lo) * per,)))
-
-    loc = dict(q_init=sl(inp["q_init"], nq, ()), qd_init=sl(inp["qd_init"], nqd, ()), torques=sl(inp["torques"], nqd, (T,)),
-               refs=sl(inp["refs"], nqd, (T,)), res_f=np.ascontiguousarray(inp["res_f"].reshape(T, gbs, nb, 6)[:, lo:hi].reshape(T, -1, 6)),
-               target_ke=sl(inp["target_ke"], nqd, ()), target_kd=sl(inp["target_kd"], nqd, ()),
-               body_inv_mass=sl(inp["body_inv_mass"], nb, ()), body_mass=sl(inp["body_mass"], nb, ()),
-               body_inertia=np.ascontiguousarray(inp["body_inertia"].reshape(gbs, nb, 3, 3)[lo:hi].reshape(-1, 3, 3)),
-               body_inv_inertia=np.ascontiguousarray(inp["body_inv_inertia"].reshape(gbs, nb, 3, 3)[lo:hi].reshape(-1, 3, 3)))
+    T, nb = 12, 13
     rc = RefC(tpl, np.float32)
-    st = rc.rollout_forward(loc, T, inp["frame2step"], inp["dt"])
-    pos = torch.from_numpy(st["wp_pos"].reshape(len(inp["frame2step"]), hi - lo, nb * 7).copy())
-    gathered = [torch.zeros_like(pos) for _ in range(world)]
-    dist.all_gather(gathered, pos)  # host-side concatenation of outputs; NOT on the measured path
+    res = []
+    for scaling, bs_arg in (("strong", 7), ("weak", 3)):
+        inp, (lo, hi), gbs = bench.rank_inputs(tpl, "laikago", T, world, rank, scaling, bs_arg, ("mi-trot", "mi-spin"), seed=5)
+        assert hi - lo == inp["q_init"].size // 19 and gbs == (7 if scaling == "strong" else 6)
+        st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+        g = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+        F = len(inp["frame2step"])
+        mine = [st["wp_pos"].reshape(F, hi - lo, nb * 7).transpose(1, 0, 2).copy(), g["q_init"].reshape(hi - lo, 19).copy()]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)  # host-side concatenation of outputs; NOT on the measured path
+        if rank == 0:
+            full_in, span, _ = bench.rank_inputs(tpl, "laikago", T, 1, 0, "strong", gbs, ("mi-trot", "mi-spin"), seed=5)
+            assert span == (0, gbs)
+            fs = rc.rollout_forward(full_in, T, full_in["frame2step"], full_in["dt"])
+            fg = rc.rollout_backward(fs, full_in["adj_pos"], full_in["adj_vel"])
+            pos = np.concatenate([p[0] for p in gathered], 0)
+            gq = np.concatenate([p[1] for p in gathered], 0)
+            res.append(float(np.abs(pos - fs["wp_pos"].reshape(F, gbs, nb * 7).transpose(1, 0, 2)).max()))
+            res.append(float(np.abs(gq - fg["q_init"].reshape(gbs, 19)).max()))
+    dist.barrier()
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        full = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])["wp_pos"].reshape(len(inp["frame2step"]), gbs, nb * 7)
-        np.save(out, np.array([float(np.abs(torch.cat(gathered, 1).numpy() - full).max()), float(t.item())]))
+        np.save(out, np.array(res + [float(t.item())]))
     dist.destroy_process_group()
 
 
 def test_two_rank_shards_reproduce_global_batch(tmp_path, oracle_libs):
     out = str(tmp_path / "res.npy")
     mp.spawn(_worker, args=(2, 29731, out), nprocs=2, join=True)
-    err, tmax = np.load(out)
-    assert err == 0.0          # envs are independent: sharding changes nothing, bit for bit
-    assert abs(tmax - 0.2) < 1e-12
+    r = np.load(out)
+    assert np.all(r[:4] == 0.0)      # envs are independent: sharding changes nothing, bit for bit (both modes)
+    assert abs(r[4] - 0.2) < 1e-12   # MAX over ranks of the elapsed time
 
 
 def test_shard_envs_partitions():
@@ -66,5 +72,6 @@ def test_shard_envs_partitions():
             assert spans[0][0] == 0 and spans[-1][1] == gbs
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    assert bench.shard_envs(4096, 8, 3) == (1536, 2048)   # 512 envs per GPU at 8 GPUs
     f, b = bench.algorithmic_bytes(13, 18)
     assert f + b == 2720  # SURVEY.md section 8(d) canonical figure for Laikago
