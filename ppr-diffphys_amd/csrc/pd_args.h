@@ -8,6 +8,7 @@
 #define PD_BWAVES 4
 #define PD_BLOCK (2 * PD_BWAVES * 64)
 #define PD_FK_BLOCK (PD_BWAVES * 64)
+#define PD_BLOCK3 (3 * PD_BWAVES * 64)  // 3-role adjoint (k_rollout_bwd3): integrate, contact and joint wave per env group
 
 // Forward sweeps log their hit list (count + up to PD_HITLOG-1 entries) so that the adjoint replays it instead of
 // repeating the three cull levels; count -1 = did not fit, the adjoint then culls again for that wave.
@@ -21,8 +22,9 @@ constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
 inline bool pd_split_launch(int kind, int jt, int nblocks, int cu_count) {
   return pd_split(jt) || (kind == PD_K_ROLLOUT_FWD && nblocks <= cu_count);
 }
-inline int pd_block_threads(int kind, int jt, int nblocks, int cu_count) {
-  return (kind <= PD_K_ROLLOUT_BWD && pd_split_launch(kind, jt, nblocks, cu_count)) ? PD_BLOCK : PD_FK_BLOCK;
+inline int pd_block_threads(int kind, int jt, int nblocks, int cu_count, int variant = 0) {
+  if (kind == PD_K_ROLLOUT_BWD) return pd_split(jt) ? (variant == 3 ? PD_BLOCK3 : PD_BLOCK) : (variant == 9 ? PD_FK_BLOCK : PD_BLOCK);
+  return (kind == PD_K_ROLLOUT_FWD && pd_split_launch(kind, jt, nblocks, cu_count)) ? PD_BLOCK : PD_FK_BLOCK;
 }
 
 #define PD_TRAJ_FLOATS 20  // floats of saved trajectory per body-step: 5 float4 planes (pd_kernels.hip: PD_TRAJ_G)
@@ -39,6 +41,7 @@ struct RolloutArgs {
   float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
   int *hitlog;              // workspace tail: per (step, env) the compacted contact hit list of the forward sweep
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
+  int variant;              // A/B experiments (pd_debug_set_variant, not in the public header): which adjoint kernel a revolute robot runs
 };
 
 

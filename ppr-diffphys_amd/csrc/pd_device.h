@@ -41,7 +41,8 @@ struct PdDevModel {
   float gx, gy, gz, attach_ke, attach_kd;
   int env_lds_floats;                                     // per-env LDS scratch
   int cu_count;                                           // compute units of the device (launch heuristics)
-  int env_lds_jc;                                         // + joint hand-over records (wave-specialised adjoint only)
+  int env_lds_jc;                                         // + joint hand-over records (2-role wave-specialised adjoint only)
+  int env_lds_bwd3;                                       // per-env LDS scratch of the 3-role adjoint kernel (k_rollout_bwd3)
   const float *X_p_env;                                   // [xp_envs][nb][7] per-env joint_X_p bound by the caller, or null (template X_p)
   int xp_envs;
 };
@@ -624,16 +625,16 @@ PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 
   return R;
 }
 
-PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const RevCache &R,
-                        float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par, float &a_tgt,
-                        float &a_act, float &a_ke, float &a_kd) {
+// Parent quantities are passed explicitly (pp, qp, w_p, v_p, rc_par = rot(qp, com_par); ignored for a joint to the world).
+PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, v3 pp, qt qp, v3 w_p, v3 v_p, v3 rc_par,
+                             const RevCache &R, float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par,
+                             float &a_tgt, float &a_act, float &a_ke, float &a_kd) {
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
-  v3 pp = V3(0, 0, 0), w_p = pp, v_p = pp, r_p = pp;
-  qt qp = Q4(0, 0, 0, 1);
+  v3 r_p = V3(0, 0, 0);
   if (c.parent >= 0) {
-    const float *r = rec + c.parent * PD_REC;
-    pp = ld3(r); qp = ld4(r + 3); w_p = ld3(r + 7); v_p = ld3(r + 10);
-    r_p = R.x_p - (pp + ld3(r + 13));
+    r_p = R.x_p - (pp + rc_par);
+  } else {
+    pp = V3(0, 0, 0); w_p = pp; v_p = pp; qp = Q4(0, 0, 0, 1);
   }
   const v3 r_c = s.p - (s.p + rc_c);
   const v3 x_err = s.p - R.x_p, v_err = s.v - v_p, w_err = s.w - w_p;
@@ -681,6 +682,18 @@ PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState
   }
 }
 
+PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const RevCache &R,
+                        float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par, float &a_tgt,
+                        float &a_act, float &a_ke, float &a_kd) {
+  v3 pp = V3(0, 0, 0), w_p = pp, v_p = pp, rc_par = pp;
+  qt qp = Q4(0, 0, 0, 1);
+  if (c.parent >= 0) {
+    const float *r = rec + c.parent * PD_REC;
+    pp = ld3(r); qp = ld4(r + 3); w_p = ld3(r + 7); v_p = ld3(r + 10); rc_par = ld3(r + 13);
+  }
+  rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+}
+
 // ---------------------------------------------------------------------------------------------
 // integrate_bodies (integrator_euler.py:21-91) for one body.
 // rc = rot(q, com) of the input state (from the staging); rc_out = the same for the returned state.
@@ -706,9 +719,24 @@ PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const Bo
   return o;
 }
 
-PD_DEV void integrate_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m,
-                          const float *I, const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, v3 &adj_t0, v3 &adj_f0,
-                          float &g_inv_m, float *g_I, float *g_invI) {
+// Two phases: everything the wrench adjoint (adj_t0, adj_f0) needs comes first and is handed to `wrench_ready` -- the
+// role-split adjoint kernel publishes it to the joint and contact waves there -- then the rest (state adjoint, inertia
+// and inverse-mass gradients).  Terms and accumulation order are those of the plain reverse sweep.
+// g_I / g_invI: 9-float accumulators, either registers (float *) or LDS (LdsAcc9: read - fma - write, same rounding).
+#define PD_GACC 37  // LDS floats per body: the two 9-float accumulators + inertia + inverse inertia (odd stride)
+struct LdsAcc9 { float *p; };
+PD_DEV void add_outer(LdsAcc9 M, v3 a, v3 b) {
+  float t[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) t[k] = M.p[k];
+  add_outer(t, a, b);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) M.p[k] = t[k];
+}
+template <typename ACC, typename F>
+PD_DEV void integrate_adj2(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m, const float *I,
+                           const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, float &g_inv_m, ACC g_I, ACC g_invI,
+                           F &&wrench_ready) {
   v3 g = V3(m.gx, m.gy, m.gz);
   float nz = inv_m != 0.0f ? 1.0f : 0.0f;
   v3 v1 = s.v + (f0 * inv_m + g * nz) * dt;
@@ -721,32 +749,45 @@ PD_DEV void integrate_adj(const PdDevModel &m, const BodyConst &c, const BodySta
   qt rq = s.r + qmul(W, s.r) * (0.5f * dt);
   qt r1 = qnormalize(rq);
   v3 w1d = w1 * (1.0f - 0.1f * dt);
-  // reverse
+  // ---- reverse, phase 1: the path to the wrench adjoint
   qt adj_r1 = gn.r;
   adj_qrot_q(r1, c.com, adj_r1, -gn.p);
   v3 adj_v1 = clamp3_pass(v1, gn.v, 10.0f);
   v3 adj_w1 = clamp3_pass(w1d, gn.w, 10.0f) * (1.0f - 0.1f * dt);
   qt adj_rq = Q4(0, 0, 0, 0);
   adj_qnormalize(rq, adj_rq, adj_r1);
-  qt adj_r0 = adj_rq, adj_W = Q4(0, 0, 0, 0);
-  adj_qmul(W, s.r, adj_W, adj_r0, adj_rq * (0.5f * dt));
+  const qt gW = adj_rq * (0.5f * dt);
+  qt adj_W = Q4(0, 0, 0, 0);
+  adj_qmul_a(s.r, adj_W, gW);
   adj_w1 += qvec(adj_W);
   v3 adj_u = V3(0, 0, 0);
-  adj_qrot(s.r, u, adj_r0, adj_u, adj_w1);
+  adj_u += qrot_inv(s.r, adj_w1);
   v3 adj_wb = adj_u, adj_a = adj_u * dt;
-  add_outer(g_invI, adj_a, tb);
   v3 adj_tb = matT_vec(invI, adj_a);
-  adj_t0 = V3(0, 0, 0);
-  adj_qrot_inv(s.r, t0, adj_r0, adj_t0, adj_tb);
+  v3 adj_t0 = V3(0, 0, 0);
+  adj_t0 += qrot(s.r, adj_tb);
+  adj_v1 += gn.p * dt;
+  const v3 adj_f0 = adj_v1 * (inv_m * dt);
+  wrench_ready(adj_t0, adj_f0);
+  // ---- phase 2
+  qt adj_r0 = adj_rq;
+  adj_qmul_b(W, adj_r0, gW);
+  adj_qrot_q(s.r, u, adj_r0, adj_w1);
+  add_outer(g_invI, adj_a, tb);
+  adj_qrot_inv_q(s.r, t0, adj_r0, adj_tb);
   v3 adj_Iwb = V3(0, 0, 0);
   adj_cross(wb, Iwb, adj_wb, adj_Iwb, -adj_tb);
   add_outer(g_I, adj_Iwb, wb);
   adj_wb += matT_vec(I, adj_Iwb);
   v3 adj_w0 = V3(0, 0, 0);
   adj_qrot_inv(s.r, s.w, adj_r0, adj_w0, adj_wb);
-  adj_v1 += gn.p * dt;
-  adj_f0 = adj_v1 * (inv_m * dt);
   g_inv_m += dot(adj_v1, f0) * dt;
   adj_qrot_q(s.r, c.com, adj_r0, gn.p);
   a.p = gn.p; a.r = adj_r0; a.w = adj_w0; a.v = adj_v1;
+}
+
+PD_DEV void integrate_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m,
+                          const float *I, const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, v3 &adj_t0, v3 &adj_f0,
+                          float &g_inv_m, float *g_I, float *g_invI) {
+  integrate_adj2(m, c, s, t0, f0, inv_m, I, invI, dt, gn, a, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) { adj_t0 = t; adj_f0 = f; });
 }

@@ -224,9 +224,16 @@ static int build_device(pd_model *m, int segw) {
     if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
     d.cu_count = cus;
   }
-  // the wave-specialised adjoint keeps the contact tables in global memory and adds the joint hand-over records
-  d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;  // keeps the env stride at 16 mod 32
-  const size_t lds_rollout_bwd = jt == PD_JT_REVOLUTE ? (size_t)envs_per_block * (d.env_lds_floats + 2 * d.env_lds_jc) * 4 : lds_rollout;
+  // the role-split adjoint (k_rollout_bwd3) keeps the contact tables in global memory; per env: cull vectors, records,
+  // wrench adjoints, (parent, own) joint slots + the zero record, contact sums, inertia-gradient accumulators, tile list, hit list, per-hit slots, signals
+  d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;
+  d.env_lds_bwd3 = ((nb * (4 + PD_REC + PD_W6 + 3 * PD_ADJ + PD_GACC) + PD_GACC + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
+  d.env_lds_bwd3 += (16 - d.env_lds_bwd3 % 32 + 32) % 32;  // env stride 16 mod 32, as above
+  // revolute-only: 2-role kernel (+ joint hand-over records) or the 3-role one, no tables; other joint mixes: the 2-role
+  // k_rollout_bwd3 with the contact tables in LDS (or the unsplit kernel, A/B only)
+  const size_t lds_rollout_bwd = jt == PD_JT_REVOLUTE
+                                     ? (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats + 2 * d.env_lds_jc) * 4
+                                     : lds_tables + (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats) * 4;
   const size_t lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   if (lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
@@ -262,13 +269,15 @@ static int build_device(pd_model *m, int segw) {
   return 0;
 }
 
+static int g_variant = 0;  // A/B experiments only (pd_debug_set_variant)
+
 static hipError_t launch(const pd_model *m, int kind, const void *args, int n_envs, size_t lds, hipStream_t st) {
   const int epb = PD_BWAVES * (64 / m->segw);
   const int nblocks = (n_envs + epb - 1) / epb;
   if (nblocks == 0) return hipSuccess;
   if (kind < 2) {
     int *ll = const_cast<pd_model *>(m)->last_launch[kind];
-    ll[0] = nblocks; ll[1] = pd_block_threads(kind, m->jt, nblocks, m->dev.cu_count); ll[2] = (int)lds; ll[3] = epb;
+    ll[0] = nblocks; ll[1] = pd_block_threads(kind, m->jt, nblocks, m->dev.cu_count, g_variant); ll[2] = (int)lds; ll[3] = epb;
   }
   if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, nblocks, lds, st);
   if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, nblocks, lds, st);
@@ -437,6 +446,7 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.frame_of_step = fos; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
+  a.variant = g_variant;
   a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
@@ -469,6 +479,10 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *
 
 // Not part of the public header: buffer for -DPD_STAMPS diagnostic builds ([blocks*waves][16] u64).
 void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
+// Not part of the public header: selects the adjoint kernel of revolute-only robots for A/B timing (scripts/gpu_time.py):
+// revolute-only: 0 = shipped default (2-role, hand-over A after integrate_adj), 1 = 2-role with the early hand-over,
+// 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 0 = 2-role k_rollout_bwd3<2>, 9 = the unsplit round-1 kernel.
+void pd_debug_set_variant(int v) { g_variant = v; }
 
 int pd_model_set_timing(pd_model *m, int on) {
   if (!m) return fail("null model");

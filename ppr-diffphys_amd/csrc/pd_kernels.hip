@@ -15,7 +15,7 @@
 #define STAMP_PASS , st_acc, st_t
 #define STAMP(i) do { unsigned long long t2_ = pd_memtime(); st_acc[i] += t2_ - st_t; st_t = t2_; } while (0)
 #define STAMP_COUNT(i, n) do { st_acc[i] += (unsigned long long)(n); } while (0)
-#define STAMP_FLUSH(a) do { if ((a).dbg && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((size_t)blockIdx.x * (PD_BLOCK / 64) + (threadIdx.x >> 6)) * 16 + i_] = st_acc[i_]; } while (0)
+#define STAMP_FLUSH(a) do { if ((a).dbg && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 16; ++i_) (a).dbg[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 16 + i_] = st_acc[i_]; } while (0)
 __device__ __forceinline__ unsigned long long pd_memtime() {
   unsigned long long t;
   __builtin_amdgcn_sched_barrier(0);
@@ -764,7 +764,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
 }
 
 // =============================================================================================
-template <int SEGW, int JT, bool SPLIT>
+// EARLY (SPLIT only): hand-over A is signalled from inside the adjoint of integrate_bodies, as soon as the wrench adjoint
+// exists (integrate_adj2), instead of after it.
+template <int SEGW, int JT, bool SPLIT, bool EARLY = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -988,7 +990,24 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     STAMP(0);
     // ---- adjoint of integrate_bodies
     BodyAdj ga = adj_zero();
-    v3 adj_t0, adj_f0;
+    v3 adj_t0 = V3(0, 0, 0), adj_f0 = adj_t0;
+    if (SPLIT && EARLY) {
+      integrate_adj2(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) {
+        adj_t0 = t; adj_f0 = f;
+        if (is_body) {
+          float *o = adjf + b * PD_W6;
+          o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = f.x; o[4] = f.y; o[5] = f.z;
+        }
+        pair_signal(sig, a.nsteps - step);  // A: records + wrench adjoints are staged
+      });
+      if (is_body) {
+        float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
+        stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
+        stg2(o + 4, boff * 6u, make_float2(adj_f0.y, adj_f0.z));
+      }
+      STAMP(1);
+      pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
+    } else {
     integrate_adj(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
     if (is_body) {
       float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
@@ -1003,6 +1022,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       pair_wait(sig + 1, a.nsteps - step);
     } else {
       WAVE_SYNC();
+    }
     }
     // ---- adjoint of eval_body_joints (runs while the contact wave sweeps)
     BodyAdj par = adj_zero();
@@ -1116,6 +1136,468 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 }
 
 // =============================================================================================
+// Role-split adjoint rollout (revolute-only robots, i.e. the headline Laikago path): THREE waves per group of 64/SEGW envs,
+// one of each per SIMD (12 waves per workgroup; <= 168 VGPRs each so that three fit a SIMD):
+//   I  integrate wave : owns the running state adjoint gn.  Per step: seeds, adjoint of integrate_bodies in two phases --
+//                       the short path to the wrench adjoint (adj_t0, adj_f0) first, published to LDS (hand-over A), then
+//                       the rest (state adjoint, inertia / inverse-mass gradients) while the other two waves work; finally
+//                       it gathers the joint wave's results (own + children, hand-over J) and the contact sums (hand-over C)
+//   J  joint wave     : the whole adjoint of eval_body_joints.  Before A it recomputes the state-only half of its joint
+//                       (rev_forward) from the stored trajectory, prefetched a step ahead, and keeps it in registers; after A
+//                       it reads the wrench adjoints and the staged records, runs rev_adjoint, publishes (own, parent)
+//                       contributions, then writes the control gradients off the critical path
+//   C  contact wave   : adjoint of eval_body_contacts for the logged hits, one lane per hit (as in the 2-role kernel)
+// Per step the critical chain is  phase 1 (I) -> max(rev_adjoint (J), contacts (C), phase 2 (I)) -> gather (I)  instead of
+// integrate_adj + rev_adjoint + gather on one wave.  Arithmetic and summation order are those of the 2-role kernel.
+#ifdef PD_ROLE_PROBE  // diagnostic (scripts/dump_isa.sh): compile ONE role without the register cap to see what it needs
+#ifndef PD_ROLE_PROBE_BOUND
+#define PD_ROLE_PROBE_BOUND 256
+#endif
+#define PD_BWD3_BOUNDS(roles) PD_ROLE_PROBE_BOUND
+#else
+#define PD_BWD3_BOUNDS(roles) ((roles) * PD_BWAVES * 64)
+#endif
+// ROLES = 3: I, C, J waves (<= 168 VGPRs each).  ROLES = 2: the integrate wave also replays the contacts (between its phase 2
+// and the wait for the joint wave) -- compound-joint robots, whose joint adjoint needs more than 168 registers but whose
+// box contacts are a handful of points: two waves per env group, <= 256 VGPRs each.
+template <int SEGW, int JT, int ROLES>
+__global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevModel m, RolloutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int EPW = Seg<SEGW>::EPW;
+  constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
+  constexpr int NT = ROLES * PD_BWAVES * 64;
+  static_assert(ROLES == 2 || ROLES == 3, "two or three roles");
+  const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
+#ifdef PD_ROLE_PROBE
+  const int role = PD_ROLE_PROBE, wave = wave_id % PD_BWAVES;
+#else
+  // 0: I (+ contacts when ROLES == 2), 1: C, 2: J   (wave-uniform)
+  const int role = ROLES == 3 ? wave_id / PD_BWAVES : (wave_id / PD_BWAVES ? 2 : 0), wave = wave_id % PD_BWAVES;
+#endif
+  const int seg = lane / SEGW, l = lane % SEGW;
+  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
+  const bool env_ok = env < a.bs;
+  const int ec = env_ok ? env : 0;  // clamped env for safe addressing
+  const bool is_body = env_ok && l < m.nb;
+  const int b = l < m.nb ? l : m.nb - 1;
+  const int nb = m.nb, N = a.bs * nb;
+
+  SweepTables tabs;
+  // ROLES == 2: the (small) contact tables are copied into LDS, the inline replay then has no exposed global loads
+  float *scratch = lds_setup<NT, ROLES == 2>(m, smem, tabs, wave * EPW + seg, m.env_lds_bwd3);
+  float4 *cull = (float4 *)scratch;
+  // cslot: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
+  float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *oslot = cslot + (nb + 1) * PD_ADJ;
+  float *cacc = oslot + nb * PD_ADJ;
+  // gacc: the integrate wave's running gradients of body_inertia / body_inv_inertia (2 x 9 per body) followed by the body's
+  // inertia and inverse inertia (2 x 9); they live here, not in registers, so that the wave stays within the 168 VGPRs
+  // three waves per SIMD allow (stride 37: odd, conflict-free)
+  float *gacc = cacc + nb * PD_ADJ;
+  int *list = (int *)(gacc + (nb + 1) * PD_GACC), *hits = list + m.list_cap;
+  float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
+  // hand-over words (step counters) at the end of the wave's first env: [0] A (I -> J, C)   [1] J (J -> I)   [2] C (C -> I)
+  int *sig = (int *)(scratch - (size_t)seg * m.env_lds_bwd3 + m.env_lds_bwd3 - 4);
+  if (role == 0) {
+    if (lane == 0) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
+    if (is_body) {
+#pragma unroll
+      for (int k = 0; k < PD_ADJ; ++k) { cacc[b * PD_ADJ + k] = 0.f; oslot[b * PD_ADJ + k] = 0.f; cslot[b * PD_ADJ + k] = 0.f; }
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int k = 0; k < PD_ADJ; ++k) cslot[nb * PD_ADJ + k] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  const size_t idx = (size_t)ec * nb + b;
+  const unsigned boff = (unsigned)idx * 4u;  // per-lane byte offset of this body's float
+
+  // (each role loads the per-body constants itself: what one role needs is dead in the others, and a shared load ahead
+  // of the role branch kept all of them live -- 68 spilled VGPRs at the 168 three waves per SIMD allow)
+  if (ROLES == 3 && role == 1) {
+    // ---- C: contact wave
+    BodyConst c = load_body_const(m, b, ec);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
+    auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {
+      const int pb = (int)(r - rec) / PD_REC;
+      BodyAdj o = adj_zero();
+      contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+      adj_store(out, o);
+    };
+    STAMP_DECL;
+    const int lq = l < PD_HITLOG - 1 ? l : PD_HITLOG - 2;
+    const unsigned boff_lg = (unsigned)ec * (PD_HITLOG * 4u);
+    auto load_log = [&](int step, int &cnt, int &e) {
+      const int *lg = a.hitlog + (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * a.bs * PD_HITLOG;
+      cnt = __float_as_int(ldg((const float *)lg, boff_lg)); e = __float_as_int(ldg((const float *)lg + 1, boff_lg + (unsigned)lq * 4u));
+    };
+    auto fetch_point = [&](int cnt, int &e, float4 &P, float4 &M) {  // entries past the count are uninitialised memory
+      if (!(env_ok && l < cnt && l < PD_HITLOG - 1)) e = 0;
+      P = m.pts[e & 0xffff]; M = m.materials[(e >> 16) & 0xff];
+    };
+    int cnt_c = 0, e_c = 0, cnt_n = 0, e_n = 0;
+    float4 P_c, M_c;
+    if (a.nsteps > 0) {
+      load_log(a.nsteps - 1, cnt_c, e_c);
+      load_log(a.nsteps - 2, cnt_n, e_n);
+      fetch_point(cnt_c, e_c, P_c, M_c);
+    }
+    for (int step = a.nsteps - 1; step >= 0; --step) {
+      PD_WAIT_VMEM();
+      float4 P_n, M_n;
+      int cnt_n2, e_n2;
+      fetch_point(cnt_n, e_n, P_n, M_n);
+      load_log(step - 2, cnt_n2, e_n2);
+      const bool fast = __ballot(env_ok && (cnt_c < 0 || cnt_c > SEGW)) == 0ull;  // wave-uniform
+      const int nh = fast && env_ok ? cnt_c : 0;
+      STAMP(7);
+      pair_wait(sig, a.nsteps - step);  // A: records, cull vectors and wrench adjoints of this step are staged
+      STAMP(9);
+      if (fast) {
+        float out[PD_ADJ];
+#pragma unroll
+        for (int i = 0; i < PD_ADJ; ++i) out[i] = 0.f;
+        const int pb = l < nh ? (e_c >> 24) & 0x3f : -2;
+        if (l < nh) contact_hit(rec + pb * PD_REC, P_c, M_c, out);
+        STAMP(10);
+        bool last;
+        seg_run_sum<PD_ADJ>(out, pb, l, nh, last);
+        if (last) {  // cacc is zero (its owner clears it after reading) and a body has one run
+#pragma unroll
+          for (int i = 0; i < PD_ADJ; ++i) cacc[pb * PD_ADJ + i] = out[i];
+        }
+        STAMP(11);
+      } else {
+        float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (is_body) cv = cull[b];
+        int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
+        const bool replay = __ballot(env_ok && cnt_c < 0) == 0ull;  // -1: the list did not fit the log, cull again (whole wave)
+        int log_n_unused;
+        sweep_contacts<SEGW, PD_ADJ, PD_ADJ, false>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, env_ok, seg, l,
+                                                    replay ? lg : nullptr, replay ? (env_ok ? cnt_c : 0) : PD_NO_REPLAY, log_n_unused,
+                                                    contact_hit STAMP_PASS);
+      }
+      STAMP(12);
+      pair_signal(sig + 2, a.nsteps - step);  // C: contact adjoints are complete
+      cnt_c = cnt_n; e_c = e_n; P_c = P_n; M_c = M_n;
+      cnt_n = cnt_n2; e_n = e_n2;
+    }
+    STAMP_FLUSH(a);
+    return;
+  }
+
+  if (role == 2) {
+    // ---- J: joint wave
+    STAMP_DECL;
+    const BodyConst c = load_body_const(m, b, ec);
+    const unsigned boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;
+    const bool has_par = c.parent >= 0;
+    const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
+    float ke[ND], kd[ND], g_ke[ND], g_kd[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+      const bool on = is_body && k < ndof;
+      ke[k] = on ? a.target_ke[(size_t)ec * m.nqd + c.qdstart + k] : 0.f;
+      kd[k] = on ? a.target_kd[(size_t)ec * m.nqd + c.qdstart + k] : 0.f;
+      g_ke[k] = 0.f; g_kd[k] = 0.f;
+    }
+    // the root's six dof columns of g_refs / g_torques are zero (a FREE joint reads no dof, integrator_euler.py:382): lanes
+    // 1..6 write one each beside their own entries -- two store instructions per array and step instead of seven
+    const bool root_free = m.jtype[0] == PD_JOINT_FREE;
+    const bool zero_by_lanes = root_free && nb >= 7;
+    const unsigned boff_zero = (unsigned)((size_t)ec * m.nqd + m.qdstart[0] + (b >= 1 && b <= 6 ? b - 1 : 0)) * 4u;
+    auto store_controls = [&](int step, const float *a_tgt, const float *a_act, const float *a_ke, const float *a_kd) {
+      const size_t oc = (size_t)__builtin_amdgcn_readfirstlane(step) * a.bs * m.nqd;
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        if (is_body && k < ndof) { stg(a.g_refs + oc + k, boff_qd, a_tgt[k]); stg(a.g_torques + oc + k, boff_qd, a_act[k]); }
+        g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k];
+      }
+      if (zero_by_lanes) {
+        if (is_body && b >= 1 && b <= 6) { stg(a.g_refs + oc, boff_zero, 0.f); stg(a.g_torques + oc, boff_zero, 0.f); }
+      } else if (is_body && c.type == PD_JOINT_FREE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { stg(a.g_refs + oc + k, boff_qd, 0.f); stg(a.g_torques + oc + k, boff_qd, 0.f); }
+      }
+    };
+    if constexpr (JT == PD_JT_REVOLUTE) {
+      const bool rev = is_body && c.type == PD_JOINT_REVOLUTE;
+      const unsigned boff_p = (unsigned)((size_t)ec * nb + (has_par ? c.parent : b)) * 4u;
+      const float *prec = rec + (has_par ? c.parent : b) * PD_REC;
+      // stored pose of this lane's body (q, w) and of its parent (p, q, w), and the controls, one iteration ahead
+      float4 pose[5];
+      float tgt_n = 0.f, act_n = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) pose[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      auto load_next = [&](int step) {
+        const int sc = __builtin_amdgcn_readfirstlane(step > 0 ? step : 0);
+        const float *tj = a.ws + (size_t)sc * (PD_TRAJ_G * 4) * N;
+        if (rev) {
+          pose[0] = ldg4(tj, boff * 4u); pose[1] = ldg4(tj + (size_t)4 * N, boff * 4u);
+          pose[2] = ldg4(tj, boff_p * 4u); pose[3] = ldg4(tj + (size_t)4 * N, boff_p * 4u); pose[4] = ldg4(tj + (size_t)8 * N, boff_p * 4u);
+          const size_t o = (size_t)sc * a.bs * m.nqd;
+          tgt_n = ldg(a.refs + o, boff_qd); act_n = ldg(a.torques + o, boff_qd);
+        }
+      };
+      if (a.nsteps > 0) load_next(a.nsteps - 1);
+      for (int step = a.nsteps - 1; step >= 0; --step) {
+        PD_WAIT_VMEM();
+        const qt q_c = Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), qp = Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w);
+        const v3 w_c = V3(pose[1].x, pose[1].y, pose[1].z), pp = V3(pose[4].x, pose[4].y, pose[4].z), w_p = V3(pose[3].x, pose[3].y, pose[3].z);
+        const float tgt = tgt_n, act = act_n;
+        RevCache R = rev_forward(m, c, q_c, w_c, pp, qp, w_p, tgt, act, ke[0], kd[0]);
+        STAMP(8);
+        load_next(step - 1);  // nothing loaded here is touched before the next PD_WAIT_VMEM
+        STAMP(7);
+        pair_wait(sig, a.nsteps - step);  // A: wrench adjoints and records of this step are staged
+        STAMP(9);
+        BodyAdj own = adj_zero(), par = adj_zero();
+        float a_tgt[1] = {0.f}, a_act[1] = {0.f}, a_ke[1] = {0.f}, a_kd[1] = {0.f};
+        if (rev) {
+          // one batch of LDS reads: own wrench adjoint, the parent's, and what rev_adjoint needs beyond the prefetched pose
+          const float *r = rec + b * PD_REC;
+          const v3 gc_t = ld3(adjf + b * PD_W6), gc_f = ld3(adjf + b * PD_W6 + 3);
+          v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
+          if (has_par) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
+          BodyState s;
+          s.p = ld3(r); s.r = q_c; s.w = w_c; s.v = ld3(r + 10);
+          const v3 rc_c = ld3(r + 13), v_p = ld3(prec + 10), rc_par = ld3(prec + 13);
+          rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke[0], kd[0], gc_t, gc_f, gp_t, gp_f, own, par, a_tgt[0], a_act[0],
+                           a_ke[0], a_kd[0]);
+        }
+        if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
+        STAMP(10);
+        pair_signal(sig + 1, a.nsteps - step);  // J: (own, parent) contributions are complete
+        store_controls(step, a_tgt, a_act, a_ke, a_kd);  // control gradients, off the critical path
+        STAMP(11);
+      }
+    } else {
+      // any joint mix: the whole joint adjoint after hand-over A, state from the staged records; controls a step ahead
+      float n_tgt[ND], n_act[ND];
+      auto load_next = [&](int step) {
+        const size_t o = (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * a.bs * m.nqd;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+          const bool on = is_body && k < ndof;
+          n_tgt[k] = on ? ldg(a.refs + o + k, boff_qd) : 0.f;
+          n_act[k] = on ? ldg(a.torques + o + k, boff_qd) : 0.f;
+        }
+      };
+      load_next(a.nsteps - 1);
+      for (int step = a.nsteps - 1; step >= 0; --step) {
+        PD_WAIT_VMEM();
+        float tgt[ND], act[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
+        load_next(step - 1);
+        STAMP(7);
+        pair_wait(sig, a.nsteps - step);  // A: wrench adjoints and records of this step are staged
+        STAMP(9);
+        BodyAdj own = adj_zero(), par = adj_zero();
+        float a_tgt[ND], a_act[ND], a_ke[ND], a_kd[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f; }
+        if (is_body && c.type != PD_JOINT_FREE) {
+          const float *r = rec + b * PD_REC;
+          BodyState s;
+          s.p = ld3(r); s.r = ld4(r + 3); s.w = ld3(r + 7); s.v = ld3(r + 10);
+          const v3 rc_c = ld3(r + 13);
+          const v3 gc_t = ld3(adjf + b * PD_W6), gc_f = ld3(adjf + b * PD_W6 + 3);
+          v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
+          if (has_par) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
+          joint_adj<JT>(m, c, s, rc_c, rec, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+        }
+        if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
+        STAMP(10);
+        pair_signal(sig + 1, a.nsteps - step);  // J: (own, parent) contributions are complete
+        store_controls(step, a_tgt, a_act, a_ke, a_kd);
+        STAMP(11);
+      }
+    }
+    if (is_body) {
+      const size_t og = (size_t)ec * m.nqd + c.qdstart;
+#pragma unroll
+      for (int k = 0; k < ND; ++k)
+        if (k < ndof) { a.g_ke[og + k] = g_ke[k]; a.g_kd[og + k] = g_kd[k]; }
+      if (c.type == PD_JOINT_FREE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { a.g_ke[og + k] = 0.f; a.g_kd[og + k] = 0.f; }
+      }
+    }
+    STAMP_FLUSH(a);
+    return;
+  }
+
+  // ---- I: integrate wave.  The loop needs the centre of mass and the child list only; everything else of the per-body
+  // constants is loaded after the loop, for the adjoint of eval_fk (nothing of it is live across the steps)
+  BodyConst c;
+  if (ROLES == 2) {  // the inline contact replay (and its re-cull fallback) needs the cull constants too
+    c = load_body_const(m, b, ec);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
+  } else {
+    c.com = ld3(m.com + b * 3); c.children = m.children[b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int cid = (int)((c.children >> (8 * k)) & 0xffull);
+      c.child[k] = cid == 0xff ? -1 : cid;
+    }
+  }
+  auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {  // ROLES == 2 only
+    const int pb = (int)(r - rec) / PD_REC;
+    BodyAdj o = adj_zero();
+    contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    adj_store(out, o);
+  };
+  // inertia and inverse inertia are read from LDS where they are used (9 + 9 registers less across the step)
+  float inv_m = a.inv_mass[idx];
+  float g_inv_m = 0.f;
+  float *ga_lds = gacc + (l < nb ? l : nb) * PD_GACC;  // idle lanes share a dummy slot: they must not alias body nb - 1's sums
+  float *I = ga_lds + 18, *invI = I + 9;
+#pragma unroll
+  for (int k = 0; k < 18; ++k) ga_lds[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { I[k] = a.inertia[idx * 9 + k]; invI[k] = a.inv_inertia[idx * 9 + k]; }
+  int cz[4];  // first four children, the zero record for a missing one
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cz[k] = is_body && c.child[k] >= 0 ? c.child[k] : nb;
+
+  BodyAdj gn = adj_zero();  // adjoint of state step+1
+  BodyState s;
+  s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
+  float4 n_s[PD_TRAJ_G];
+  int n_fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
+  auto load_step = [&](int step) {
+    const int sc = __builtin_amdgcn_readfirstlane(step >= 0 ? step : 0);  // keeps the address arithmetic scalar
+    n_fr = a.frame_of_step[sc + 1];
+    const float *tj = a.ws + (size_t)sc * (PD_TRAJ_G * 4) * N;
+#pragma unroll
+    for (int g = 0; g < PD_TRAJ_G; ++g) n_s[g] = ldg4(tj + (size_t)(4 * g) * N, boff * 4u);
+  };
+  if (a.nsteps > 0) load_step(a.nsteps - 1);
+  STAMP_DECL;
+  for (int step = a.nsteps - 1; step >= 0; --step) {
+    PD_WAIT_VMEM();
+    {  // seeds of state step+1 (dp_model.py:1264-1271)
+      const int fr = n_fr;
+      if (fr >= 0) {
+        const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
+        gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
+        gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+      }
+    }
+    s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
+    s.p = V3(n_s[2].x, n_s[2].y, n_s[2].z); s.v = V3(n_s[1].w, n_s[2].w, n_s[3].x);
+    const v3 t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w), f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
+    // (ROLES == 2) the forward hit list of this step is replayed inline further down: fetch its length now, far ahead
+    int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
+    const int log_cnt = (ROLES == 2 && env_ok) ? lg[0] : 0;
+    const v3 rc = qrot(s.r, c.com);
+    if (is_body) stage_record(rec, cull, b, s, rc);
+    STAMP(0);
+    // ---- adjoint of integrate_bodies; hand-over A as soon as the wrench adjoint exists
+    BodyAdj ga = adj_zero();
+    v3 adj_t0 = V3(0, 0, 0), adj_f0 = adj_t0;
+    integrate_adj2(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, g_inv_m, LdsAcc9{ga_lds}, LdsAcc9{ga_lds + 9}, [&](v3 t, v3 f) {
+      adj_t0 = t; adj_f0 = f;
+      if (is_body) {
+        float *o = adjf + b * PD_W6;
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = f.x; o[4] = f.y; o[5] = f.z;
+      }
+      pair_signal(sig, a.nsteps - step);  // A
+      // the stored state of the NEXT iteration is requested here, not at the top: its 20 registers are then free during
+      // phase 1, and phase 2 plus the waits for the other two waves (thousands of cycles) cover the HBM latency
+      load_step(step - 1);
+    });
+    if (is_body) {
+      float *o = a.g_res_f + (size_t)__builtin_amdgcn_readfirstlane(step) * N * 6;  // adjoint of wp_add
+      stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
+      stg2(o + 4, boff * 6u, make_float2(adj_f0.y, adj_f0.z));
+    }
+    STAMP(1);
+    if (ROLES == 2) {  // adjoint of eval_body_contacts, while the joint wave works
+      WAVE_SYNC();     // records and wrench adjoints were written by this wave's own lanes
+      const bool replay = __ballot(log_cnt < 0) == 0ull;
+      int log_n_unused;
+      sweep_contacts<SEGW, PD_ADJ, PD_ADJ, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot,
+                                                 cacc, is_body, env_ok, seg, l, replay ? lg : nullptr, replay ? log_cnt : PD_NO_REPLAY,
+                                                 log_n_unused, contact_hit STAMP_PASS);
+      WAVE_SYNC();
+    }
+    pair_wait(sig + 1, a.nsteps - step);  // J: joint contributions are complete
+    STAMP(2);
+    {  // own joint first, then the first four children with all LDS reads in flight together, then any further ones
+      float ow[PD_ADJ], cw[4][PD_ADJ];
+#pragma unroll
+      for (int i = 0; i < PD_ADJ; ++i) ow[i] = oslot[b * PD_ADJ + i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float *pc = cslot + cz[k] * PD_ADJ;
+#pragma unroll
+        for (int i = 0; i < PD_ADJ; ++i) cw[k][i] = pc[i];
+      }
+      adj_add_from(ga, ow);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) adj_add_from(ga, cw[k]);
+    }
+    for (int k = 4; k < m.max_children; ++k) {
+      int cid = (int)((c.children >> (8 * k)) & 0xffull);
+      if (is_body && cid != 0xff) adj_add_from(ga, cslot + cid * PD_ADJ);
+    }
+    STAMP(3);
+    if (ROLES == 3) pair_wait(sig + 2, a.nsteps - step);  // C: contact adjoints are complete
+    if (is_body) {
+      float *d = cacc + b * PD_ADJ;
+      adj_add_from(ga, d);
+#pragma unroll
+      for (int k = 0; k < PD_ADJ; ++k) d[k] = 0.f;
+    }
+    gn = ga;
+    STAMP(4);
+  }
+  STAMP_FLUSH(a);
+  {  // seeds of state 0
+    int fr = a.frame_of_step[0];
+    if (fr >= 0) {
+      const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
+      gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
+      gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+    }
+  }
+  // ---- adjoint of eval_fk: rec holds state 0 (staged in the last loop iteration); the J wave is past its last use of cslot
+  c = load_body_const(m, b, ec);
+  if (a.nsteps == 0) {
+    for (int d = 0; d <= m.max_depth; ++d) {  // nothing staged yet: rebuild state 0
+      if (is_body && c.depth == d) {
+        s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
+        stage_record(rec, b, s, c.com);
+      }
+      WAVE_SYNC();
+    }
+  }
+  WAVE_SYNC();
+  for (int d = m.max_depth; d >= 0; --d) {
+    if (is_body && c.depth == d) {
+      for (int k = 0; k < m.max_children; ++k) {
+        int cid = (int)((c.children >> (8 * k)) & 0xffull);
+        if (cid != 0xff) adj_add_from(gn, cslot + cid * PD_ADJ);
+      }
+      BodyAdj par = fk_joint_adj<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
+                                     gn, a.g_q_init + (size_t)ec * m.nq + c.qstart, a.g_qd_init + (size_t)ec * m.nqd + c.qdstart);
+      adj_store(cslot + b * PD_ADJ, par);
+    }
+    WAVE_SYNC();
+  }
+  if (is_body) {
+    a.g_inv_mass[idx] = g_inv_m;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { a.g_inertia[idx * 9 + k] = ga_lds[k]; a.g_inv_inertia[idx * 9 + k] = ga_lds[9 + k]; }
+  }
+}
+
+// =============================================================================================
 // Batched FK (ForwardKinematics, dp_model.py:1022-1130): n articulations, one per segment.
 template <int SEGW, int JT, bool BWD>
 __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
@@ -1193,8 +1675,20 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const RolloutArgs *)args);
       break;
     case PD_K_ROLLOUT_BWD:
-      hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(pd_split(JT) ? PD_BLOCK : PD_FK_BLOCK), lds, st, m,
-                         *(const RolloutArgs *)args);
+      if constexpr (pd_split(JT)) {
+        const int v = ((const RolloutArgs *)args)->variant;
+        if (v == 3)
+          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 3>), dim3(nblocks), dim3(PD_BLOCK3), lds, st, m, *(const RolloutArgs *)args);
+        else if (v == 1)
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, true>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+        else
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+      } else {
+        if (((const RolloutArgs *)args)->variant == 9)  // A/B: the unsplit round-1 kernel
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, false>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+        else
+          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+      }
       break;
     case PD_K_FK_FWD:
       hipLaunchKernelGGL((k_fk<PD_SEGW, JT, false>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const FkArgs *)args);
@@ -1213,7 +1707,14 @@ static hipError_t set_lds_jt(int bytes) {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if constexpr (pd_split(JT)) {
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  } else {
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  }
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   return hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

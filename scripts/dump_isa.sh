@@ -1,9 +1,18 @@
 #!/bin/bash
-# Emits gfx950 assembly of the SEGW=16 kernels to /tmp/isa/k16.s and splits the revolute rollout kernels out (diagnostic).
+# Emits gfx950 assembly of the SEGW=$1 (default 16) kernels to /tmp/isa/k$1.s and prints register / spill metadata of
+# every rollout kernel (diagnostic).
+W=${1:-16}
 mkdir -p /tmp/isa
 cd /root/repo/ppr-diffphys_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DPD_SEGW=16 -S --cuda-device-only pd_kernels.hip -o /tmp/isa/k16.s 2>/dev/null
-cd /tmp/isa
-awk '/^_Z13k_rollout_fwdILi16ELi1ELb1E/{f=1} f{print} /s_endpgm/{if(f){exit}}' k16.s > fwd.s
-awk '/^_Z13k_rollout_bwdILi16ELi1ELb1E/{f=1} f{print} /s_endpgm/{if(f){exit}}' k16.s > bwd.s
-grep -A12 "^    .name:           _Z13k_rollout_...ILi16ELi1ELb1E" k16.s | grep "name\|vgpr_count\|sgpr_count\|spill"
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DPD_SEGW=$W $EXTRA -S --cuda-device-only pd_kernels.hip -o /tmp/isa/k$W.s 2>/dev/null
+python3 - $W <<'PY'
+import re,sys
+w=sys.argv[1]
+s=open('/tmp/isa/k%s.s'%w).read()
+for m in re.finditer(r'\.name:\s+(_Z\S+)\n(.*?)\.wavefront_size', s, re.S):
+    name=m.group(1)
+    if 'rollout' not in name: continue
+    body=m.group(2)
+    g=lambda k: (re.search(r'\.%s:\s+(\d+)'%k, body) or [0,'?'])[1]
+    print("%-62s vgpr %s agpr %s spill %s sgpr %s sspill %s" % (name[:62], g('vgpr_count'), g('agpr_count'), g('vgpr_spill_count'), g('sgpr_count'), g('sgpr_spill_count')))
+PY

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Records what the ROUND-1 library (build_r01/, rebuilt from the r01 commit's sources; scratch, git-ignored) computes on the
-committed golden inputs and on a 64-env x 100-step bench-like batch: tests/golden/r01_bits_<robot>.npz hold the raw fp32
+committed golden inputs and on a 8-env x 100-step bench-like batch: tests/golden/r01_bits_<robot>.npz hold the raw fp32
 outputs and gradients.  tests/test_gpu_tight.py::test_against_round1_bits compares the current library with them, so a
 kernel restructure shows whether it changed any bit (and by how many ulp).  Run on the GPU box; fixtures are data."""
 import importlib.util, os, sys
@@ -39,7 +39,7 @@ for name in ("laikago", "human", "quad"):
     tpl = robots.load_template(name)
     dm = hb.DeviceModel(tpl)
     a = run(dm, golden_inputs(load_golden(name)))
-    b = run(dm, synth.make_env_inputs(tpl, name, range(64), 100, seed=77, seqs=("mi-trot", "mi-spin"), penetration=0.002))
+    b = run(dm, synth.make_env_inputs(tpl, name, range(8), 100, seed=77, seqs=("mi-trot", "mi-spin"), penetration=0.002))
     np.savez_compressed(os.path.join(out_dir, "r01_bits_%s.npz" % name), **{"golden_" + k: v for k, v in a.items()},
-                        **{"bench64_" + k: v for k, v in b.items()})
+                        **{"bench8_" + k: v for k, v in b.items()})
     print("recorded", name, {k: v.shape for k, v in a.items() if k.startswith("wp")})

