@@ -351,13 +351,16 @@ PD_DEV void joint_force_adj(float q, float qd, float target, float ke, float kd,
   else if (q < lo) { adj_q += -lke * adj_limit; if (qd < 0.0f) adj_qd += -lkd * adj_limit; }
 }
 
-PD_DEV void quat_decompose(qt q, float *ang) {  // :245-258
-  v3 c0 = qrot(q, V3(1, 0, 0)), c1 = qrot(q, V3(0, 1, 0)), c2 = qrot(q, V3(0, 0, 1));
+PD_DEV void quat_decompose(qt q, float *ang, v3 &c0, v3 &c1, v3 &c2) {  // :245-258; also returns the rotated basis
+  c0 = qrot(q, V3(1, 0, 0)); c1 = qrot(q, V3(0, 1, 0)); c2 = qrot(q, V3(0, 0, 1));
   ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
 }
-PD_DEV void quat_decompose_adj(qt q, const float *g, qt &adj_q) {
+PD_DEV void quat_decompose(qt q, float *ang) {
+  v3 c0, c1, c2;
+  quat_decompose(q, ang, c0, c1, c2);
+}
+PD_DEV void quat_decompose_adj(qt q, v3 c0, v3 c1, v3 c2, const float *g, qt &adj_q) {  // c* = the rotated basis of the forward pass
   v3 ex = V3(1, 0, 0), ey = V3(0, 1, 0), ez = V3(0, 0, 1);
-  v3 c0 = qrot(q, ex), c1 = qrot(q, ey), c2 = qrot(q, ez);
   v3 a0 = V3(0, 0, 0), a1 = a0, a2 = a0;
   float gphi = -g[0], gth = -g[1], gpsi = -g[2];
   { float y = c2.y, x = c2.z, d = x * x + y * y; a2.y += gphi * x / d; a2.z += -gphi * y / d; }
@@ -442,15 +445,61 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
 
 // Adjoint.  gc_* = adjoint of the child's wrench accumulator, gp_* = of the parent's (zero if none).
 // own += d/d(child state); par = d/d(parent state); a_* = per-dof gradients (overwritten).
-template <int JT>
-PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
-                      const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
-                      BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
+//
+// Two halves: joint_adj_prep recomputes everything that depends on the stored state and the controls only (the joint
+// frames and errors, and for a COMPOUND joint the whole forward pass: angle decomposition, axes, PD forces) -- the
+// role-split adjoint kernel runs it on the joint wave BEFORE the wrench adjoints exist -- and joint_adj_apply is the part
+// that needs them.  joint_adj = prep + apply.
+struct JointPrep {
   JointCtx j;
-  joint_ctx(c, s, rc_c, rec, j);
+  v3 f_raw, f_total;
+  // COMPOUND only
+  qt qa, q_pc, q_0, q_1, q10, q_w;
+  v3 ax1, ax2, axw[3], t_raw;
+  float ang[3], jf[3], qdk[3];
+  v3 c0, c1, c2;  // columns of R(q_pc): quat_decompose and its adjoint share them
+  float2 sc0, sc1;  // (sin, cos) of ang[0] / 2 and ang[1] / 2, as q_axis_angle computed them
+};
+
+template <int JT>
+PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
+                           const float *act, const float *ke, const float *kd, JointPrep &P) {
+  joint_ctx(c, s, rc_c, rec, P.j);
+  const JointCtx &j = P.j;
+  const float ake = m.attach_ke, akd = m.attach_kd;
+  P.f_raw = j.x_err * ake + j.v_err * akd;
+  P.f_total = ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) ? clamp3(P.f_raw, 1.0e4f) : P.f_raw;
+  if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
+    P.qa = qmul(qconj(c.q_off), qconj(j.q_p));
+    const qt qb = qmul(P.qa, s.r);
+    P.q_pc = qmul(qb, c.q_off);
+    quat_decompose(P.q_pc, P.ang, P.c0, P.c1, P.c2);
+    const v3 ax0 = V3(1, 0, 0);
+    P.q_0 = q_axis_angle_sc(ax0, P.ang[0], P.sc0);
+    P.ax1 = qrot(P.q_0, V3(0, 1, 0));
+    P.q_1 = q_axis_angle_sc(P.ax1, P.ang[1], P.sc1);
+    P.q10 = qmul(P.q_1, P.q_0);
+    P.ax2 = qrot(P.q10, V3(0, 0, 1));
+    P.q_w = qmul(j.q_p, c.q_off);
+    const v3 ax[3] = {ax0, P.ax1, P.ax2};
+    P.t_raw = V3(0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      P.axw[k] = qrot(P.q_w, ax[k]); P.qdk[k] = dot(P.axw[k], j.w_err);
+      const JointLimit L = c.lim[k];
+      P.jf[k] = joint_force(P.ang[k], P.qdk[k], tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
+      P.t_raw += P.axw[k] * P.jf[k];
+    }
+  }
+}
+
+template <int JT>
+PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyState &s, const JointPrep &P, const float *tgt,
+                            const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
+                            BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
+  const JointCtx &j = P.j;
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
-  v3 f_raw = j.x_err * ake + j.v_err * akd;
-  v3 f_total = ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) ? clamp3(f_raw, 1.0e4f) : f_raw;
+  const v3 f_raw = P.f_raw, f_total = P.f_total;
   v3 adj_t = -gc_t, adj_f = -gc_f, adj_r_c = V3(0, 0, 0), adj_r_p = V3(0, 0, 0);
   adj_cross(j.r_c, f_total, adj_r_c, adj_f, -gc_t);
   if (c.parent >= 0) {
@@ -504,61 +553,42 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     adj_qrot_q(s.r, c.axis, adj_q_c, adj_axis_c);
   }
   if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
-    qt qa = qmul(qconj(c.q_off), qconj(j.q_p)), qb = qmul(qa, s.r), q_pc = qmul(qb, c.q_off);
-    float ang[3];
-    quat_decompose(q_pc, ang);
-    v3 ax[3];
-    ax[0] = V3(1, 0, 0);
-    qt q_0 = q_axis_angle(ax[0], ang[0]);
-    ax[1] = qrot(q_0, V3(0, 1, 0));
-    qt q_1 = q_axis_angle(ax[1], ang[1]);
-    qt q10 = qmul(q_1, q_0);
-    ax[2] = qrot(q10, V3(0, 0, 1));
-    qt q_w = qmul(j.q_p, c.q_off);
-    v3 axw[3], t_raw = V3(0, 0, 0);
-    float jf[3], qdk[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      axw[k] = qrot(q_w, ax[k]); qdk[k] = dot(axw[k], j.w_err);
-      const JointLimit L = c.lim[k];
-      jf[k] = joint_force(ang[k], qdk[k], tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
-      t_raw += axw[k] * jf[k];
-    }
+    const v3 ax[3] = {V3(1, 0, 0), P.ax1, P.ax2};
     v3 adj_f_raw = clamp3_pass(f_raw, adj_f, 1.0e4f);
     adj_x_err += adj_f_raw * ake; adj_v_err += adj_f_raw * akd;
-    v3 adj_t_raw = clamp3_pass(t_raw, adj_t, 1.0e4f);
+    v3 adj_t_raw = clamp3_pass(P.t_raw, adj_t, 1.0e4f);
     float adj_ang[3] = {0.f, 0.f, 0.f};
     v3 adj_ax[3] = {V3(0, 0, 0), V3(0, 0, 0), V3(0, 0, 0)};
     qt adj_q_w = Q4(0, 0, 0, 0);
 #pragma unroll
     for (int k = 2; k >= 0; --k) {
-      float adj_jf = dot(adj_t_raw, axw[k]);
-      v3 adj_axw = adj_t_raw * jf[k];
+      float adj_jf = dot(adj_t_raw, P.axw[k]);
+      v3 adj_axw = adj_t_raw * P.jf[k];
       float adj_qdk = 0.f;
       a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f;
       const JointLimit L = c.lim[k];
-      joint_force_adj(ang[k], qdk[k], tgt[k], ke[k], kd[k], L.lo, L.up, L.ke, L.kd, adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k],
+      joint_force_adj(P.ang[k], P.qdk[k], tgt[k], ke[k], kd[k], L.lo, L.up, L.ke, L.kd, adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k],
                       a_kd[k], a_act[k]);
-      adj_axw += j.w_err * adj_qdk; adj_w_err += axw[k] * adj_qdk;
-      adj_qrot(q_w, ax[k], adj_q_w, adj_ax[k], adj_axw);
+      adj_axw += j.w_err * adj_qdk; adj_w_err += P.axw[k] * adj_qdk;
+      adj_qrot(P.q_w, ax[k], adj_q_w, adj_ax[k], adj_axw);
     }
     adj_qmul_a(c.q_off, adj_q_p, adj_q_w);
     qt adj_q10 = Q4(0, 0, 0, 0), adj_q_1 = adj_q10, adj_q_0 = adj_q10;
-    adj_qrot_q(q10, V3(0, 0, 1), adj_q10, adj_ax[2]);
-    adj_qmul(q_1, q_0, adj_q_1, adj_q_0, adj_q10);
-    adj_q_axis_angle(ax[1], ang[1], adj_ax[1], adj_ang[1], adj_q_1);
-    adj_qrot_q(q_0, V3(0, 1, 0), adj_q_0, adj_ax[1]);
-    adj_q_axis_angle_ang(ax[0], ang[0], adj_ang[0], adj_q_0);
+    adj_qrot_q(P.q10, V3(0, 0, 1), adj_q10, adj_ax[2]);
+    adj_qmul(P.q_1, P.q_0, adj_q_1, adj_q_0, adj_q10);
+    adj_q_axis_angle_sc(ax[1], P.sc1.x, P.sc1.y, adj_ax[1], adj_ang[1], adj_q_1);
+    adj_qrot_q(P.q_0, V3(0, 1, 0), adj_q_0, adj_ax[1]);
+    adj_q_axis_angle_ang_sc(ax[0], P.sc0.x, P.sc0.y, adj_ang[0], adj_q_0);
     qt adj_q_pc = Q4(0, 0, 0, 0);
-    quat_decompose_adj(q_pc, adj_ang, adj_q_pc);
+    quat_decompose_adj(P.q_pc, P.c0, P.c1, P.c2, adj_ang, adj_q_pc);
     qt adj_qb = Q4(0, 0, 0, 0), adj_qa = adj_qb, adj_cqp = adj_qb;
     adj_qmul_a(c.q_off, adj_qb, adj_q_pc);
-    adj_qmul(qa, s.r, adj_qa, adj_q_c, adj_qb);
+    adj_qmul(P.qa, s.r, adj_qa, adj_q_c, adj_qb);
     adj_qmul_b(qconj(c.q_off), adj_cqp, adj_qa);
     adj_q_p += qconj(adj_cqp);
   }
-  {  // r_err = conj(q_p) * q_c
-    qt adj_cqp = Q4(0, 0, 0, 0);
+  if (!((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND)) {  // r_err = conj(q_p) * q_c  (a COMPOUND joint does not use r_err:
+    qt adj_cqp = Q4(0, 0, 0, 0);                                  //  its adjoint is exactly zero there)
     adj_qmul(qconj(j.q_p), s.r, adj_cqp, adj_q_c, adj_r_err);
     adj_q_p += qconj(adj_cqp);
   }
@@ -573,6 +603,15 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
     adj_qmul_a(c.q_pj, par.r, adj_q_p);
     par.w = -adj_w_err; par.v = -adj_v_err;
   }
+}
+
+template <int JT>
+PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
+                      const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
+                      BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
+  JointPrep P;
+  joint_adj_prep<JT>(m, c, s, rc_c, rec, tgt, act, ke, kd, P);
+  joint_adj_apply<JT>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -224,10 +224,10 @@ static int build_device(pd_model *m, int segw) {
     if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
     d.cu_count = cus;
   }
-  // the role-split adjoint (k_rollout_bwd3) keeps the contact tables in global memory; per env: cull vectors, records,
+  // the role-split adjoint (k_rollout_bwd3) keeps the contact tables in global memory; per env: two generations of cull vectors and records,
   // wrench adjoints, (parent, own) joint slots + the zero record, contact sums, inertia-gradient accumulators, tile list, hit list, per-hit slots, signals
   d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;
-  d.env_lds_bwd3 = ((nb * (4 + PD_REC + PD_W6 + 3 * PD_ADJ + PD_GACC) + PD_GACC + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
+  d.env_lds_bwd3 = ((nb * (2 * (4 + PD_REC) + PD_W6 + 3 * PD_ADJ + PD_GACC) + PD_GACC + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
   d.env_lds_bwd3 += (16 - d.env_lds_bwd3 % 32 + 32) % 32;  // env stride 16 mod 32, as above
   // revolute-only: 2-role kernel (+ joint hand-over records) or the 3-role one, no tables; other joint mixes: the 2-role
   // k_rollout_bwd3 with the contact tables in LDS (or the unsplit kernel, A/B only)

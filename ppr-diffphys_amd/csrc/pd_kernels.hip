@@ -1185,9 +1185,15 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   SweepTables tabs;
   // ROLES == 2: the (small) contact tables are copied into LDS, the inline replay then has no exposed global loads
   float *scratch = lds_setup<NT, ROLES == 2>(m, smem, tabs, wave * EPW + seg, m.env_lds_bwd3);
-  float4 *cull = (float4 *)scratch;
+  // staged records and cull vectors: TWO generations, by step parity -- the integrate wave stages step - 1 while the other
+  // waves still work on step (the joint wave then starts the state-only half of step - 1 without waiting for anybody)
+  float4 *const cull0 = (float4 *)scratch;
+  float *const rec0 = scratch + 8 * nb;
+  float4 *cull = cull0;
+  float *rec = rec0;
+  auto select_step = [&](int step) { rec = rec0 + (step & 1) * nb * PD_REC; cull = cull0 + (step & 1) * nb; };
   // cslot: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
-  float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *oslot = cslot + (nb + 1) * PD_ADJ;
+  float *adjf = rec0 + 2 * nb * PD_REC, *cslot = adjf + nb * PD_W6, *oslot = cslot + (nb + 1) * PD_ADJ;
   float *cacc = oslot + nb * PD_ADJ;
   // gacc: the integrate wave's running gradients of body_inertia / body_inv_inertia (2 x 9 per body) followed by the body's
   // inertia and inverse inertia (2 x 9); they live here, not in registers, so that the wave stays within the 168 VGPRs
@@ -1196,9 +1202,10 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   int *list = (int *)(gacc + (nb + 1) * PD_GACC), *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
   // hand-over words (step counters) at the end of the wave's first env: [0] A (I -> J, C)   [1] J (J -> I)   [2] C (C -> I)
+  // [3] S (I -> J: records staged; joint mixes other than revolute-only)
   int *sig = (int *)(scratch - (size_t)seg * m.env_lds_bwd3 + m.env_lds_bwd3 - 4);
   if (role == 0) {
-    if (lane == 0) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
+    if (lane == 0) { sig[0] = 0; sig[1] = 0; sig[2] = 0; sig[3] = 0; }
     if (is_body) {
 #pragma unroll
       for (int k = 0; k < PD_ADJ; ++k) { cacc[b * PD_ADJ + k] = 0.f; oslot[b * PD_ADJ + k] = 0.f; cslot[b * PD_ADJ + k] = 0.f; }
@@ -1246,6 +1253,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     }
     for (int step = a.nsteps - 1; step >= 0; --step) {
       PD_WAIT_VMEM();
+      select_step(step);
       float4 P_n, M_n;
       int cnt_n2, e_n2;
       fetch_point(cnt_n, e_n, P_n, M_n);
@@ -1325,7 +1333,6 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     if constexpr (JT == PD_JT_REVOLUTE) {
       const bool rev = is_body && c.type == PD_JOINT_REVOLUTE;
       const unsigned boff_p = (unsigned)((size_t)ec * nb + (has_par ? c.parent : b)) * 4u;
-      const float *prec = rec + (has_par ? c.parent : b) * PD_REC;
       // stored pose of this lane's body (q, w) and of its parent (p, q, w), and the controls, one iteration ahead
       float4 pose[5];
       float tgt_n = 0.f, act_n = 0.f;
@@ -1353,11 +1360,12 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         STAMP(7);
         pair_wait(sig, a.nsteps - step);  // A: wrench adjoints and records of this step are staged
         STAMP(9);
+        select_step(step);
         BodyAdj own = adj_zero(), par = adj_zero();
         float a_tgt[1] = {0.f}, a_act[1] = {0.f}, a_ke[1] = {0.f}, a_kd[1] = {0.f};
         if (rev) {
           // one batch of LDS reads: own wrench adjoint, the parent's, and what rev_adjoint needs beyond the prefetched pose
-          const float *r = rec + b * PD_REC;
+          const float *r = rec + b * PD_REC, *prec = rec + (has_par ? c.parent : b) * PD_REC;
           const v3 gc_t = ld3(adjf + b * PD_W6), gc_f = ld3(adjf + b * PD_W6 + 3);
           v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
           if (has_par) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
@@ -1393,21 +1401,31 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
         load_next(step - 1);
         STAMP(7);
-        pair_wait(sig, a.nsteps - step);  // A: wrench adjoints and records of this step are staged
+        // S: the records of this step are staged -- the integrate wave does that during the PREVIOUS step, before it waits
+        // for this wave -- so the state-only half of the joint adjoint starts right after the previous step's hand-over J
+        pair_wait(sig + 3, a.nsteps - step);
+        select_step(step);
+        BodyState s;
+        s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
+        JointPrep P;
+        const bool jointed = is_body && c.type != PD_JOINT_FREE;
+        if (jointed) {
+          const float *r = rec + b * PD_REC;
+          s.p = ld3(r); s.r = ld4(r + 3); s.w = ld3(r + 7); s.v = ld3(r + 10);
+          joint_adj_prep<JT>(m, c, s, ld3(r + 13), rec, tgt, act, ke, kd, P);
+        }
+        STAMP(8);
+        pair_wait(sig, a.nsteps - step);  // A: the wrench adjoints of this step are staged
         STAMP(9);
         BodyAdj own = adj_zero(), par = adj_zero();
         float a_tgt[ND], a_act[ND], a_ke[ND], a_kd[ND];
 #pragma unroll
         for (int k = 0; k < ND; ++k) { a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f; }
-        if (is_body && c.type != PD_JOINT_FREE) {
-          const float *r = rec + b * PD_REC;
-          BodyState s;
-          s.p = ld3(r); s.r = ld4(r + 3); s.w = ld3(r + 7); s.v = ld3(r + 10);
-          const v3 rc_c = ld3(r + 13);
+        if (jointed) {
           const v3 gc_t = ld3(adjf + b * PD_W6), gc_f = ld3(adjf + b * PD_W6 + 3);
           v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
           if (has_par) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-          joint_adj<JT>(m, c, s, rc_c, rec, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+          joint_adj_apply<JT>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
         }
         if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
         STAMP(10);
@@ -1467,8 +1485,9 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   BodyAdj gn = adj_zero();  // adjoint of state step+1
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
+  v3 t0 = V3(0, 0, 0), f0 = t0;
   float4 n_s[PD_TRAJ_G];
-  int n_fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
+  int n_fr = -1, fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
   auto load_step = [&](int step) {
     const int sc = __builtin_amdgcn_readfirstlane(step >= 0 ? step : 0);  // keeps the address arithmetic scalar
     n_fr = a.frame_of_step[sc + 1];
@@ -1476,26 +1495,30 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
 #pragma unroll
     for (int g = 0; g < PD_TRAJ_G; ++g) n_s[g] = ldg4(tj + (size_t)(4 * g) * N, boff * 4u);
   };
-  if (a.nsteps > 0) load_step(a.nsteps - 1);
-  STAMP_DECL;
-  for (int step = a.nsteps - 1; step >= 0; --step) {
+  // unpacks the fetched state of `step`, stages its record and cull vector (generation step & 1) and tells the joint wave (S)
+  auto stage_step = [&](int step) {
     PD_WAIT_VMEM();
-    {  // seeds of state step+1 (dp_model.py:1264-1271)
-      const int fr = n_fr;
-      if (fr >= 0) {
-        const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
-        gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
-        gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
-      }
-    }
     s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
     s.p = V3(n_s[2].x, n_s[2].y, n_s[2].z); s.v = V3(n_s[1].w, n_s[2].w, n_s[3].x);
-    const v3 t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w), f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
+    t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w); f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
+    fr = n_fr;
+    select_step(step);
+    const v3 rc = qrot(s.r, c.com);
+    if (is_body) stage_record(rec, cull, b, s, rc);
+    if (JT != PD_JT_REVOLUTE) pair_signal(sig + 3, a.nsteps - step);  // S
+  };
+  if (a.nsteps > 0) { load_step(a.nsteps - 1); stage_step(a.nsteps - 1); }
+  STAMP_DECL;
+  for (int step = a.nsteps - 1; step >= 0; --step) {
+    // s, t0, f0, fr and the staged record of `step` are in place (stage_step ran in the previous iteration)
+    if (fr >= 0) {  // seeds of state step+1 (dp_model.py:1264-1271)
+      const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
+      gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
+      gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+    }
     // (ROLES == 2) the forward hit list of this step is replayed inline further down: fetch its length now, far ahead
     int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
     const int log_cnt = (ROLES == 2 && env_ok) ? lg[0] : 0;
-    const v3 rc = qrot(s.r, c.com);
-    if (is_body) stage_record(rec, cull, b, s, rc);
     STAMP(0);
     // ---- adjoint of integrate_bodies; hand-over A as soon as the wrench adjoint exists
     BodyAdj ga = adj_zero();
@@ -1507,8 +1530,8 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = f.x; o[4] = f.y; o[5] = f.z;
       }
       pair_signal(sig, a.nsteps - step);  // A
-      // the stored state of the NEXT iteration is requested here, not at the top: its 20 registers are then free during
-      // phase 1, and phase 2 plus the waits for the other two waves (thousands of cycles) cover the HBM latency
+      // the stored state of the NEXT iteration is requested here: its 20 registers are free during phase 1, and phase 2
+      // (plus the contacts) covers the HBM latency before stage_step consumes it
       load_step(step - 1);
     });
     if (is_body) {
@@ -1525,7 +1548,11 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
                                                  cacc, is_body, env_ok, seg, l, replay ? lg : nullptr, replay ? log_cnt : PD_NO_REPLAY,
                                                  log_n_unused, contact_hit STAMP_PASS);
       WAVE_SYNC();
+      STAMP(5);
     }
+    // the next step's records, staged before this step's results are awaited (the other generation: nobody reads it now)
+    if (step > 0) stage_step(step - 1);
+    STAMP(6);
     pair_wait(sig + 1, a.nsteps - step);  // J: joint contributions are complete
     STAMP(2);
     {  // own joint first, then the first four children with all LDS reads in flight together, then any further ones
@@ -1557,6 +1584,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     gn = ga;
     STAMP(4);
   }
+  select_step(0);
   STAMP_FLUSH(a);
   {  // seeds of state 0
     int fr = a.frame_of_step[0];

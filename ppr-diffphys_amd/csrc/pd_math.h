@@ -50,6 +50,12 @@ PD_DEV qt q_axis_angle(v3 axis, float ang) {
   sincosf(ang * 0.5f, &s, &c);
   return Q4(axis.x * s, axis.y * s, axis.z * s, c);
 }
+PD_DEV qt q_axis_angle_sc(v3 axis, float ang, float2 &sc) {  // also returns (sin, cos) of ang / 2 for the adjoint
+  float s, c;
+  sincosf(ang * 0.5f, &s, &c);
+  sc = make_float2(s, c);
+  return Q4(axis.x * s, axis.y * s, axis.z * s, c);
+}
 // 1/sqrt(1-x^2) for the acos/asin adjoints; 0 (contribution dropped, not inf) where sqrt(1-x^2) is not > 0,
 // as Warp's builtin adjoints do.  POLICY, see DESIGN.md section 6.
 PD_DEV float inv_sqrt_1mx2(float x) { float d = sqrtf(1.0f - x * x); return d > 0.0f ? 1.0f / d : 0.0f; }
@@ -108,6 +114,15 @@ PD_DEV void adj_q_axis_angle(v3 axis, float ang, v3 &adj_axis, float &adj_ang, q
   v3 gv = qvec(g);
   adj_axis += gv * s;
   adj_ang += 0.5f * (c * dot(axis, gv) - s * g.w);
+}
+// the same with (sin, cos) of ang / 2 handed over from the forward pass instead of recomputed
+PD_DEV void adj_q_axis_angle_sc(v3 axis, float s, float c, v3 &adj_axis, float &adj_ang, qt g) {
+  v3 gv = qvec(g);
+  adj_axis += gv * s;
+  adj_ang += 0.5f * (c * dot(axis, gv) - s * g.w);
+}
+PD_DEV void adj_q_axis_angle_ang_sc(v3 axis, float s, float c, float &adj_ang, qt g) {
+  adj_ang += 0.5f * (c * dot(axis, qvec(g)) - s * g.w);
 }
 PD_DEV void adj_q_axis_angle_ang(v3 axis, float ang, float &adj_ang, qt g) {
   float s, c;

@@ -62,6 +62,12 @@ if wb == 12:  # 3-role adjoint
                                                   (12, "tail / generic sweep")])
     report("BWD", "joint wave", rows(b_all, 2), [(8, "rev_forward (state-only half)"), (7, "prefetch issue"), (9, "wait A"),
                                                 (10, "LDS reads + rev_adjoint + slots"), (11, "signal J + control-gradient stores")])
+elif wb == 8 and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ contacts) wave, joint wave
+    report("BWD", "integrate wave", rows(b_all, 0), [(0, "top: seeds + unpack + stage + signal S"), (1, "integrate adj (phase 1, signal A, phase 2) + g_res_f"),
+                                                    (10, "inline contacts: replay setup"), (11, "inline contacts: hit pass"), (5, "inline contacts: rest"),
+                                                    (2, "wait J"), (3, "own + child gather"), (4, "cacc")])
+    report("BWD", "joint wave", rows(b_all, 1), [(7, "top: prefetch controls"), (8, "wait S + joint_adj_prep"), (9, "wait A"),
+                                                (10, "joint_adj_apply + slots"), (11, "signal J + control-gradient stores")])
 else:
     report("BWD", "body wave", rows(b_all, 0), [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"),
                                                (2, "wait A + joints adj + stores"), (3, "child gather"), (4, "wait B + cacc gather")])
