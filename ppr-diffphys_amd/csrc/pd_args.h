@@ -16,15 +16,36 @@
 
 enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
 
-// Which rollout launches run wave-specialised (pd_kernels.hip: launch_jt) -- shared with the host so that it can report
-// the launch geometry.  Adjoint: revolute-only robots.  Forward: every joint mix while a CU holds at most one workgroup.
+// Which rollout launches run wave-specialised -- shared by the kernel TUs and the host.
+//   forward : revolute-only robots always; other joint mixes while a CU holds at most one full workgroup (the latency
+//             regime: human at 1024 envs -32 %), else the unsplit kernel packs twice as many body waves per SIMD
+//   adjoint : revolute-only robots the 2-role kernel (body + contact wave); other joint mixes the 2-role k_rollout_bwd3
+//             (integrate + contacts wave, joint wave).  The other variants exist for A/B timing (pd_debug_set_variant).
 constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
-inline bool pd_split_launch(int kind, int jt, int nblocks, int cu_count) {
-  return pd_split(jt) || (kind == PD_K_ROLLOUT_FWD && nblocks <= cu_count);
+enum { PD_KV_FWD_SPLIT = 0, PD_KV_FWD_UNSPLIT, PD_KV_BWD_2ROLE, PD_KV_BWD_2ROLE_EARLY, PD_KV_BWD_3ROLE, PD_KV_BWD3_2ROLE, PD_KV_BWD_UNSPLIT, PD_KV_FK };
+struct PdLaunchCfg {
+  int kernel;    // PD_KV_*
+  int roles;     // waves per env group
+  int groups;    // env groups (of 64 / segw envs) per workgroup, 1 .. PD_BWAVES
+  int nblocks, threads;
+  size_t lds;    // dynamic LDS bytes per workgroup
+};
+// Env groups per workgroup: as many as it takes to cover the batch with one workgroup per compute unit, at most PD_BWAVES.
+// A small batch (512 Laikago envs = 128 groups) then occupies 128 CUs with one group each instead of 32 CUs with four.
+inline int pd_groups_per_wg(int n_groups, int cu_count) {
+  int g = cu_count > 0 ? (n_groups + cu_count - 1) / cu_count : PD_BWAVES;
+  return g < 1 ? 1 : (g > PD_BWAVES ? PD_BWAVES : g);
 }
-inline int pd_block_threads(int kind, int jt, int nblocks, int cu_count, int variant = 0) {
-  if (kind == PD_K_ROLLOUT_BWD) return pd_split(jt) ? (variant == 3 ? PD_BLOCK3 : PD_BLOCK) : (variant == 9 ? PD_FK_BLOCK : PD_BLOCK);
-  return (kind == PD_K_ROLLOUT_FWD && pd_split_launch(kind, jt, nblocks, cu_count)) ? PD_BLOCK : PD_FK_BLOCK;
+inline int pd_kernel_variant(int kind, int jt, int n_groups, int cu_count, int variant) {
+  if (kind == PD_K_ROLLOUT_FWD) return (pd_split(jt) || n_groups <= PD_BWAVES * cu_count) ? PD_KV_FWD_SPLIT : PD_KV_FWD_UNSPLIT;
+  if (kind == PD_K_ROLLOUT_BWD) {
+    if (pd_split(jt)) return variant == 3 ? PD_KV_BWD_3ROLE : (variant == 1 ? PD_KV_BWD_2ROLE_EARLY : PD_KV_BWD_2ROLE);
+    return variant == 9 ? PD_KV_BWD_UNSPLIT : PD_KV_BWD3_2ROLE;
+  }
+  return PD_KV_FK;
+}
+inline int pd_variant_roles(int kv) {
+  return kv == PD_KV_BWD_3ROLE ? 3 : ((kv == PD_KV_FWD_UNSPLIT || kv == PD_KV_BWD_UNSPLIT || kv == PD_KV_FK) ? 1 : 2);
 }
 
 #define PD_TRAJ_FLOATS 20  // floats of saved trajectory per body-step: 5 float4 planes (pd_kernels.hip: PD_TRAJ_G)
@@ -55,9 +76,9 @@ struct FkArgs {
 };
 
 
-hipError_t pd_launch_seg16(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st);
-hipError_t pd_launch_seg32(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st);
-hipError_t pd_launch_seg64(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st);
+hipError_t pd_launch_seg16(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);
+hipError_t pd_launch_seg32(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);
+hipError_t pd_launch_seg64(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);
 hipError_t pd_set_lds_seg16(int jt, int bytes);
 hipError_t pd_set_lds_seg32(int jt, int bytes);
 hipError_t pd_set_lds_seg64(int jt, int bytes);

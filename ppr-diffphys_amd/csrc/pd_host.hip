@@ -24,7 +24,8 @@ struct pd_model {
   int segw = 0, jt = 0;
   void *blob = nullptr;
   PdDevModel dev{};
-  size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;
+  size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;  // at PD_BWAVES env groups per workgroup (the maximum)
+  size_t lds_tables = 0;                                      // contact tables, for the kernels that copy them into LDS
   // per-env joint_X_p bound by the caller (pd_model_bind_joint_X_p); null = the template's
   const float *xp_env = nullptr;
   int xp_envs = 0;
@@ -234,6 +235,7 @@ static int build_device(pd_model *m, int segw) {
   const size_t lds_rollout_bwd = jt == PD_JT_REVOLUTE
                                      ? (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats + 2 * d.env_lds_jc) * 4
                                      : lds_tables + (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats) * 4;
+  // (the 160 KiB checks below are for PD_BWAVES env groups per workgroup, the most a launch uses)
   const size_t lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   if (lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
@@ -264,24 +266,45 @@ static int build_device(pd_model *m, int segw) {
   d.small_tiles = (const int *)(base + o_st);
   free_device(m);
   m->blob = blob; m->dev = d;
-  m->lds_rollout = lds_rollout; m->lds_rollout_bwd = lds_rollout_bwd; m->lds_fk = lds_fk;
+  m->lds_rollout = lds_rollout; m->lds_rollout_bwd = lds_rollout_bwd; m->lds_fk = lds_fk; m->lds_tables = lds_tables;
   m->segw = segw; m->jt = jt;
   return 0;
 }
 
 static int g_variant = 0;  // A/B experiments only (pd_debug_set_variant)
+static int g_groups = 0;   // A/B experiments only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
 
-static hipError_t launch(const pd_model *m, int kind, const void *args, int n_envs, size_t lds, hipStream_t st) {
-  const int epb = PD_BWAVES * (64 / m->segw);
-  const int nblocks = (n_envs + epb - 1) / epb;
-  if (nblocks == 0) return hipSuccess;
+// Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
+static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
+  const PdDevModel &d = m->dev;
+  const int epw = 64 / m->segw, n_groups = (n_envs + epw - 1) / epw;
+  PdLaunchCfg c{};
+  c.kernel = pd_kernel_variant(kind, m->jt, n_groups, d.cu_count, g_variant);
+  c.roles = pd_variant_roles(c.kernel);
+  c.groups = kind <= PD_K_ROLLOUT_BWD ? (g_groups ? g_groups : pd_groups_per_wg(n_groups, d.cu_count)) : PD_BWAVES;
+  c.nblocks = (n_groups + c.groups - 1) / c.groups;
+  c.threads = c.roles * c.groups * 64;
+  const size_t envs = (size_t)c.groups * epw;
+  switch (c.kernel) {
+    case PD_KV_FWD_SPLIT: case PD_KV_FWD_UNSPLIT: case PD_KV_BWD_UNSPLIT: c.lds = m->lds_tables + envs * d.env_lds_floats * 4; break;
+    case PD_KV_BWD_2ROLE: case PD_KV_BWD_2ROLE_EARLY: c.lds = envs * (d.env_lds_floats + 2 * d.env_lds_jc) * 4; break;
+    case PD_KV_BWD_3ROLE: c.lds = envs * d.env_lds_bwd3 * 4; break;
+    case PD_KV_BWD3_2ROLE: c.lds = m->lds_tables + envs * d.env_lds_bwd3 * 4; break;
+    default: c.lds = m->lds_fk; break;
+  }
+  return c;
+}
+
+static hipError_t launch(const pd_model *m, int kind, const void *args, int n_envs, hipStream_t st) {
+  const PdLaunchCfg c = launch_cfg(m, kind, n_envs);
+  if (c.nblocks == 0) return hipSuccess;
   if (kind < 2) {
     int *ll = const_cast<pd_model *>(m)->last_launch[kind];
-    ll[0] = nblocks; ll[1] = pd_block_threads(kind, m->jt, nblocks, m->dev.cu_count, g_variant); ll[2] = (int)lds; ll[3] = epb;
+    ll[0] = c.nblocks; ll[1] = c.threads; ll[2] = (int)c.lds; ll[3] = c.groups * (64 / m->segw);
   }
-  if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, nblocks, lds, st);
-  if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, nblocks, lds, st);
-  return pd_launch_seg64(kind, m->jt, m->dev, args, nblocks, lds, st);
+  if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, c, st);
+  if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, c, st);
+  return pd_launch_seg64(kind, m->jt, m->dev, args, c, st);
 }
 
 static void timing_begin(pd_model *m, int kind, hipStream_t st) {
@@ -416,7 +439,7 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   a.hitlog = (int *)(ws + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
-  hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, m->lds_rollout, st);
+  hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, st);
   timing_end(m, 0, st);
   return e == hipSuccess ? 0 : hip_fail(e, "rollout_forward launch");
 }
@@ -450,7 +473,7 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
-  hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, m->lds_rollout_bwd, st);
+  hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, st);
   timing_end(m, 1, st);
   return e == hipSuccess ? 0 : hip_fail(e, "rollout_backward launch");
 }
@@ -461,7 +484,7 @@ int pd_fk_forward(const pd_model *m, int n, const float *joint_q, const float *j
   if (!joint_q || !joint_qd || !body_q || !body_qd) return fail("null device pointer");
   FkArgs a{};
   a.n = n; a.joint_q = joint_q; a.joint_qd = joint_qd; a.body_q = body_q; a.body_qd = body_qd;
-  hipError_t e = launch(m, PD_K_FK_FWD, &a, n, m->lds_fk, (hipStream_t)stream);
+  hipError_t e = launch(m, PD_K_FK_FWD, &a, n, (hipStream_t)stream);
   return e == hipSuccess ? 0 : hip_fail(e, "fk_forward launch");
 }
 
@@ -473,7 +496,7 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *
   FkArgs a{};
   a.n = n; a.joint_q = joint_q; a.joint_qd = joint_qd; a.adj_body_q = adj_body_q; a.adj_body_qd = adj_body_qd;
   a.g_joint_q = g_joint_q; a.g_joint_qd = g_joint_qd;
-  hipError_t e = launch(m, PD_K_FK_BWD, &a, n, m->lds_fk, (hipStream_t)stream);
+  hipError_t e = launch(m, PD_K_FK_BWD, &a, n, (hipStream_t)stream);
   return e == hipSuccess ? 0 : hip_fail(e, "fk_backward launch");
 }
 
@@ -483,6 +506,7 @@ void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
 // revolute-only: 0 = shipped default (2-role, hand-over A after integrate_adj), 1 = 2-role with the early hand-over,
 // 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 0 = 2-role k_rollout_bwd3<2>, 9 = the unsplit round-1 kernel.
 void pd_debug_set_variant(int v) { g_variant = v; }
+void pd_debug_set_groups(int g) { g_groups = g < 0 ? 0 : (g > PD_BWAVES ? PD_BWAVES : g); }
 
 int pd_model_set_timing(pd_model *m, int on) {
   if (!m) return fail("null model");

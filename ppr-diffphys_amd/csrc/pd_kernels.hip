@@ -394,8 +394,9 @@ PD_DEV float sink_margin(const BodyConst &c, const BodyState &s, float dt) {
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.  COPY = false leaves
 // the tables in global memory (wave-specialised adjoint: it replays the forward's hit log and fetches the few points it
 // needs a step ahead, so the ~75 KB of LDS go to the joint hand-over records instead).
-template <int NT, bool COPY>
-PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot, int env_floats) {  // all NT threads of the workgroup
+template <bool COPY>
+PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T, int env_slot, int env_floats) {  // all threads of the workgroup
+  const int NT = blockDim.x;
   if (!COPY) {
     T.pts = m.pts; T.tlo = m.tile_lo; T.thi = m.tile_hi; T.mats = m.materials; T.tpack = m.tile_pack; T.btiles = m.body_tiles; T.pmat = m.pt_mat;
     return (float *)smem + (size_t)env_slot * env_floats;
@@ -427,10 +428,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % PD_BWAVES;
-  const bool contact_wave = SPLIT && (threadIdx.x >> 6) >= PD_BWAVES;  // wave-uniform role
+  // env groups (= body waves) per workgroup: chosen by the host per launch (1 .. PD_BWAVES) so that small batches spread
+  // over all compute units instead of filling a few
+  const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
+  const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
+  const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
   const int ec = env_ok ? env : 0;  // clamped env for safe addressing
   const bool is_body = env_ok && l < m.nb;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), true>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats);
+  float *scratch = lds_setup<true>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats);
   float4 *cull = (float4 *)scratch;
   // pcon: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
   float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
@@ -771,10 +775,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % PD_BWAVES;
-  const bool contact_wave = SPLIT && (threadIdx.x >> 6) >= PD_BWAVES;  // wave-uniform role
+  const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);  // env groups per workgroup (host's choice per launch)
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
+  const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
+  const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
   const int ec = env_ok ? env : 0;  // clamped env for safe addressing
   const bool is_body = env_ok && l < m.nb;
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 
   SweepTables tabs;
   const int env_stride = m.env_lds_floats + (SPLIT ? 2 * m.env_lds_jc : 0);
-  float *scratch = lds_setup<(SPLIT ? PD_BLOCK : PD_FK_BLOCK), !SPLIT>(m, smem, tabs, wave * EPW + seg, env_stride);
+  float *scratch = lds_setup<!SPLIT>(m, smem, tabs, wave * EPW + seg, env_stride);
   float4 *cull = (float4 *)scratch;
   // cslot: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
   float *rec = scratch + 4 * nb, *adjf = rec + nb * PD_REC, *cslot = adjf + nb * PD_W6, *cacc = cslot + (nb + 1) * PD_ADJ;
@@ -1165,17 +1170,17 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  constexpr int NT = ROLES * PD_BWAVES * 64;
   static_assert(ROLES == 2 || ROLES == 3, "two or three roles");
+  const int bw = (int)blockDim.x / (64 * ROLES);  // env groups per workgroup (host's choice per launch)
   const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
 #ifdef PD_ROLE_PROBE
-  const int role = PD_ROLE_PROBE, wave = wave_id % PD_BWAVES;
+  const int role = PD_ROLE_PROBE, wave = wave_id % bw;
 #else
   // 0: I (+ contacts when ROLES == 2), 1: C, 2: J   (wave-uniform)
-  const int role = ROLES == 3 ? wave_id / PD_BWAVES : (wave_id / PD_BWAVES ? 2 : 0), wave = wave_id % PD_BWAVES;
+  const int role = ROLES == 3 ? wave_id / bw : (wave_id / bw ? 2 : 0), wave = wave_id % bw;
 #endif
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
+  const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
   const int ec = env_ok ? env : 0;  // clamped env for safe addressing
   const bool is_body = env_ok && l < m.nb;
@@ -1184,7 +1189,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
 
   SweepTables tabs;
   // ROLES == 2: the (small) contact tables are copied into LDS, the inline replay then has no exposed global loads
-  float *scratch = lds_setup<NT, ROLES == 2>(m, smem, tabs, wave * EPW + seg, m.env_lds_bwd3);
+  float *scratch = lds_setup<ROLES == 2>(m, smem, tabs, wave * EPW + seg, m.env_lds_bwd3);
   // staged records and cull vectors: TWO generations, by step parity -- the integrate wave stages step - 1 while the other
   // waves still work on step (the joint wave then starts the state-only half of step - 1 without waiting for anybody)
   float4 *const cull0 = (float4 *)scratch;
@@ -1693,36 +1698,38 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
 // workgroup (the latency regime: human at 1024 envs -32 %); with several workgroups per CU the unsplit kernel's 4-wave
 // workgroups pack twice as many body waves per SIMD (quad at 8192 envs: split +22 %), so the launcher picks per launch.
 
+// cfg: the host's choice for this launch (pd_args.h: pd_launch_cfg) -- kernel variant, workgroups, threads, LDS bytes
 template <int JT>
-static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, int nblocks, size_t lds, hipStream_t st) {
+static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st) {
+  const dim3 g(cfg.nblocks), t(cfg.threads);
+  const size_t lds = cfg.lds;
   switch (kind) {
     case PD_K_ROLLOUT_FWD:
-      if (pd_split_launch(kind, JT, nblocks, m.cu_count))
-        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+      if (cfg.kernel == PD_KV_FWD_SPLIT)
+        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
       else
-        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), g, t, lds, st, m, *(const RolloutArgs *)args);
       break;
     case PD_K_ROLLOUT_BWD:
       if constexpr (pd_split(JT)) {
-        const int v = ((const RolloutArgs *)args)->variant;
-        if (v == 3)
-          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 3>), dim3(nblocks), dim3(PD_BLOCK3), lds, st, m, *(const RolloutArgs *)args);
-        else if (v == 1)
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, true>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+        if (cfg.kernel == PD_KV_BWD_3ROLE)
+          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 3>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        else if (cfg.kernel == PD_KV_BWD_2ROLE_EARLY)
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
         else
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else {
-        if (((const RolloutArgs *)args)->variant == 9)  // A/B: the unsplit round-1 kernel
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, false>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+        if (cfg.kernel == PD_KV_BWD_UNSPLIT)  // A/B: the unsplit round-1 kernel
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
         else
-          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), dim3(nblocks), dim3(PD_BLOCK), lds, st, m, *(const RolloutArgs *)args);
+          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
       }
       break;
     case PD_K_FK_FWD:
-      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, false>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const FkArgs *)args);
+      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, false>), g, t, lds, st, m, *(const FkArgs *)args);
       break;
     case PD_K_FK_BWD:
-      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, true>), dim3(nblocks), dim3(PD_FK_BLOCK), lds, st, m, *(const FkArgs *)args);
+      hipLaunchKernelGGL((k_fk<PD_SEGW, JT, true>), g, t, lds, st, m, *(const FkArgs *)args);
       break;
     default:
       return hipErrorInvalidValue;
@@ -1748,11 +1755,10 @@ static hipError_t set_lds_jt(int bytes) {
 }
 
 // jt: PD_JT_REVOLUTE only, PD_JT_COMPOUND only, anything else -> generic (all joint types)
-hipError_t PD_CAT(pd_launch_seg, PD_SEGW)(int kind, int jt, const PdDevModel &m, const void *args, int nblocks, size_t lds,
-                                          hipStream_t st) {
-  if (jt == PD_JT_REVOLUTE) return launch_jt<PD_JT_REVOLUTE>(kind, m, args, nblocks, lds, st);
-  if (jt == PD_JT_COMPOUND) return launch_jt<PD_JT_COMPOUND>(kind, m, args, nblocks, lds, st);
-  return launch_jt<PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED>(kind, m, args, nblocks, lds, st);
+hipError_t PD_CAT(pd_launch_seg, PD_SEGW)(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st) {
+  if (jt == PD_JT_REVOLUTE) return launch_jt<PD_JT_REVOLUTE>(kind, m, args, cfg, st);
+  if (jt == PD_JT_COMPOUND) return launch_jt<PD_JT_COMPOUND>(kind, m, args, cfg, st);
+  return launch_jt<PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED>(kind, m, args, cfg, st);
 }
 hipError_t PD_CAT(pd_set_lds_seg, PD_SEGW)(int jt, int bytes) {
   if (jt == PD_JT_REVOLUTE) return set_lds_jt<PD_JT_REVOLUTE>(bytes);

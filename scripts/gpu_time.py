@@ -11,6 +11,7 @@ cfgs = [("laikago", 4096, 16), ("laikago", 4096, 32), ("laikago", 4096, 64), ("l
 # PD_VARIANT=n selects an experimental adjoint kernel (pd_debug_set_variant; 0 = shipped default)
 variant = int(os.environ.get("PD_VARIANT", "0"))
 hip_backend.lib().pd_debug_set_variant(variant)
+hip_backend.lib().pd_debug_set_groups(int(os.environ.get("PD_GROUPS", "0")))  # env groups per workgroup, 0 = automatic
 if len(sys.argv) > 1:
     cfgs = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:]]
 dev = torch.device("cuda:0")
@@ -33,5 +34,5 @@ for name, bs, segw in cfgs:
             fs.append(dm.last_kernel_ms(0)); bs_.append(dm.last_kernel_ms(1))
     f, b = np.median(fs), np.median(bs_)
     nb, nqd = int(tpl["nb"]), int(tpl["nqd"]); C = 2 * nqd + 6 * nb; B = 4 * (26 * nb + 3 * C)
-    print("TIMING v%d %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (
-        variant, name, bs, segw, f, b, bs * T / ((f + b) * 1e-3), 100 * bs * T / ((f + b) * 1e-3) * B / 8e12, B), flush=True)
+    print("TIMING v%d g%s %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (
+        variant, os.environ.get("PD_GROUPS", "a"), name, bs, segw, f, b, bs * T / ((f + b) * 1e-3), 100 * bs * T / ((f + b) * 1e-3) * B / 8e12, B), flush=True)
