@@ -65,8 +65,8 @@ def reduce_loss(loss_seq, clip=False, th=0):
             srt = torch.where(rp, row, torch.full_like(row, float("inf"))).sort().values
             med = srt.gather(0, ((rp.sum() - 1).clamp(min=0) // 2).reshape(1))[0]  # torch.median: the lower one
             th = torch.where(has.any(), med * 10, torch.full_like(med, float("inf"))).detach()
-        keep = ((loss_seq.detach() > th).cumsum(1) == 0).to(loss_seq.dtype)
-        loss_seq.mul_(keep)
+        keep = (loss_seq.detach() > th).cumsum(1) == 0
+        loss_seq.masked_fill_(~keep, 0)  # assignment like the reference's loss_seq[i, idx:] = 0: an inf / NaN past the clip is zeroed, not 0 * inf
     pos = loss_seq > 0
     mean_pos = (loss_seq * pos).sum() / pos.sum().clamp(min=1)
     return torch.where(loss_seq.sum() > 0, mean_pos, loss_seq.mean())

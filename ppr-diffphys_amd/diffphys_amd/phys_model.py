@@ -171,6 +171,10 @@ class phys_model(nn.Module):
             anneal_strategy="linear", final_div_factor=1e2, div_factor=25)
 
     def update(self):
+        if getattr(self, "_pending_loss", None) is not None:
+            bad, self._pending_loss = bool(self._pending_loss.isnan()), None
+            if bad:
+                raise FloatingPointError("total_loss is NaN")  # deferred from forward(), see there
         grad_dict = self.check_grad()
         self.optimizer.step()
         self.scheduler.step()
@@ -323,7 +327,22 @@ class phys_model(nn.Module):
         return target_position, ref_ja, queried_q, queried_qd, torques, res_f
 
     # ---------------------------------------------------------------- forward
-    def forward(self, frame_start=None):
+    def make_q_init_noise(self):
+        """The init noise of this iteration (dp_model.py:702-712): N(0, noise_std * ratio), none on the root translation, x5 on
+        the root rotation; None when the model is not training or the noise is off.  A separate method so that a captured
+        iteration (``graphed_step``) can feed it through a static buffer."""
+        if not (self.training and self.noise_std > 0):
+            return None
+        noise_ratio = np.clip(1 - 1.5 * self.progress, 0, 1)
+        nq = self.n_dof + 7
+        noise = torch.tensor(np.random.normal(size=self.num_envs * nq, scale=self.noise_std * noise_ratio), dtype=torch.float32,
+                             device=self.device).view(self.num_envs, -1)
+        noise[:, :3] = 0
+        noise[:, 3:7] *= 5
+        return noise.reshape(-1)
+
+    def forward(self, frame_start=None, q_init_noise=None):
+        """``q_init_noise``: the tensor make_q_init_noise() would draw (a captured iteration passes its static buffer)."""
         frame_start = self.compute_frame_start() if frame_start is None else frame_start[: self.num_envs]
         steps_fr = frame_start[:, None] + self.steps_idx_fr[None]
         vidid, _ = fid_reindex(steps_fr[:, self.frame2step], len(self.frame_offset_raw) - 1, self.frame_offset_raw)
@@ -331,15 +350,14 @@ class phys_model(nn.Module):
         target_position, ref_ja, queried_q, queried_qd, torques, res_f = self.get_batch_input(steps_fr)
 
         res_fin = res_f.clone()
-        q_init = queried_q[0].reshape(-1)
+        q_init = queried_q[0].reshape(-1)  # a VIEW of queried_q, as in the reference
         qd_init = queried_qd[0]
-        if self.training and self.noise_std > 0:  # quirk (iii): also during "eval" rollouts
-            noise_ratio = np.clip(1 - 1.5 * self.progress, 0, 1)
-            noise = torch.tensor(np.random.normal(size=q_init.shape, scale=self.noise_std * noise_ratio), dtype=torch.float32,
-                                 device=self.device).view(self.num_envs, -1)
-            noise[:, :3] = 0
-            noise[:, 3:7] *= 5
-            q_init = q_init + noise.reshape(-1)
+        if q_init_noise is None:
+            q_init_noise = self.make_q_init_noise()  # quirk (iii): also during "eval" rollouts
+        if q_init_noise is not None:
+            # in place, like the reference's `q_init += q_init_noise` (dp_model.py:712): the noise therefore also enters
+            # queried_q[frame2step][0], i.e. the control-reference FK and the pos_state loss of frame 0
+            q_init += q_init_noise
         n = self.num_envs
         target_ke = self.target_ke[None].repeat(n, 1).view(-1)
         target_kd = self.target_kd[None].repeat(n, 1).view(-1)
@@ -380,8 +398,10 @@ class phys_model(nn.Module):
         for k, v in loss_dict.items():
             total_loss = total_loss + v * self.opts[k + "_wt"]
         out = {"loss_" + k: v for k, v in loss_dict.items()}
-        if bool(total_loss.isnan()):
-            raise FloatingPointError("total_loss is NaN")  # the reference drops into pdb here (dp_model.py:832)
+        # the reference drops into pdb on a NaN loss right here (dp_model.py:832): one host synchronisation per forward().
+        # The check is kept but deferred to update(), which has to talk to the host anyway (gradient-norm guard), so that
+        # nothing between forward() and backward() waits for the device
+        self._pending_loss = total_loss.detach()
         out["total_loss"] = total_loss
         return out
 

@@ -29,13 +29,32 @@ KP_LINKS = {
     "human": ["link_24_mixamorig:RightFoot_Y", "link_19_mixamorig:LeftFoot_Y"],
 }
 
+# How `link_weight = clip(1e3 * np.prod(shape_geo_scale[idx]), 1, 5)` (/root/reference/diffphys/dp_model.py:185-191) reads,
+# which depends on what warp_lang 0.7.2's ModelBuilder stores in shape_geo_scale (un-vendored):
+#   "prod3"      a 3-tuple (hx, hy, hz): the product is the box's half-extent volume            <- shipped default
+#   "prod4_zero" a 4-tuple with a trailing 0.0: the product is 0 for every link whose tuple the reference did not rebuild,
+#                i.e. all non-foot links get exactly 1.0; the feet (rebuilt as a 3-tuple at :173-177) keep the volume rule
+# The default follows the reference's own code, which rebuilds the feet's entry as a 3-tuple and multiplies all of a tuple's
+# entries -- consistent only with 3-tuples.  The choice is recorded in the compiled template ("mass_rule").
+MASS_RULES = ("prod3", "prod4_zero")
+DEFAULT_MASS_RULE = "prod3"
+
+
+def link_weight(scale3, rule, is_kp_link):
+    """clip(1e3 * prod(shape_geo_scale entry), 1, 5) under the given reading; scale3 = (hx, hy, hz) after the foot doubling."""
+    if rule not in MASS_RULES:
+        raise ValueError("mass_rule must be one of %s" % (MASS_RULES,))
+    prod = float(np.prod(scale3)) if (rule == "prod3" or is_kp_link) else 0.0
+    return float(min(5.0, max(1.0, 1e3 * prod)))
+
+
 TEMPLATE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "templates")
 
 
-def build_articulation(name, urdf_root):
+def build_articulation(name, urdf_root, mass_rule=DEFAULT_MASS_RULE):
     """Returns (builder, info).  ``urdf_root`` is the directory holding
     ``laikago/laikago.urdf``, ``human.urdf``, ``quad.urdf`` (the reference keeps
-    them under ``data/urdf_templates``)."""
+    them under ``data/urdf_templates``).  ``mass_rule``: see MASS_RULES (human / quad only)."""
     rel, attach_ke, attach_kd, kp, kd, shape_ke, shape_kd = PRESETS[name]
     urdf_path = os.path.join(urdf_root, rel)
     b = sim.ModelBuilder()
@@ -66,8 +85,7 @@ def build_articulation(name, urdf_root):
                 b.body_mass[idx] *= 2 ** 3
                 b.body_inertia[idx] = b.body_inertia[idx] * 2 ** 5
             b.body_inertia[idx] = b.body_inertia[idx] / b.body_mass[idx]
-            tup = b.shape_geo_scale[idx]
-            b.body_mass[idx] = float(min(5.0, max(1.0, 1e3 * np.prod(tup))))
+            b.body_mass[idx] = link_weight(b.shape_geo_scale[idx], mass_rule, link_name in KP_LINKS[name])
     else:
         for idx in range(len(b.body_mass)):  # dp_model.py:194-196
             b.body_inertia[idx] = b.body_inertia[idx] / b.body_mass[idx]
@@ -75,7 +93,8 @@ def build_articulation(name, urdf_root):
     n = len(b.joint_target_ke)
     b.joint_target_ke = [0.0] * 6 + [kp] * (n - 6)  # dp_model.py:200-205
     b.joint_target_kd = [0.0] * 6 + [kd] * (n - 6)
-    info = dict(joint_attach_ke=attach_ke, joint_attach_kd=attach_kd, kp=kp, kd=kd, body_names=body_names)
+    info = dict(joint_attach_ke=attach_ke, joint_attach_kd=attach_kd, kp=kp, kd=kd, body_names=body_names,
+                mass_rule=mass_rule if name in KP_LINKS else "mesh_density")
     return b, info
 
 
@@ -96,9 +115,9 @@ def _body_link_names(urdf_path):
     return names
 
 
-def make_env(name, urdf_root, num_envs, device="cuda"):
+def make_env(name, urdf_root, num_envs, device="cuda", mass_rule=DEFAULT_MASS_RULE):
     """What ``reinit_envs`` does (/root/reference/diffphys/dp_model.py:384-401)."""
-    art, info = build_articulation(name, urdf_root)
+    art, info = build_articulation(name, urdf_root, mass_rule)
     builder = sim.ModelBuilder()
     for _ in range(num_envs):
         builder.add_rigid_articulation(art)
@@ -114,7 +133,9 @@ def load_template(name):
     """Compiled template dict (numpy arrays) from ``templates/<name>.npz``."""
     path = os.path.join(TEMPLATE_DIR, name + ".npz")
     with np.load(path) as z:
-        return {k: z[k] for k in z.files}
+        tpl = {k: z[k] for k in z.files}
+    tpl.setdefault("mass_rule", np.asarray("mesh_density" if name not in KP_LINKS else DEFAULT_MASS_RULE))
+    return tpl
 
 
 def env_from_template(name, num_envs, device="cuda"):

@@ -65,12 +65,16 @@ def main(argv=None):
             model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"], is_eval=False)
         t0 = time.time()
         model.set_progress(it)
-        loss_dict = model.forward()
-        model.backward(loss_dict["total_loss"])
+        loss = 0
+        for _ in range(opts["accu_steps"]):  # gradient accumulation over several windows (main.py:95-99 of the reference)
+            loss_dict = model.forward()
+            loss = loss + loss_dict["total_loss"]
+        loss = loss / float(opts["accu_steps"])
+        model.backward(loss)
         model.update()
         torch.cuda.synchronize()
         print("[iter %4d] total %.6f traj %.5f pos_state %.5f  (%.3f s)" % (
-            it, float(loss_dict["total_loss"]), float(loss_dict["loss_traj"]), float(loss_dict["loss_pos_state"]), time.time() - t0))
+            it, float(loss), float(loss_dict["loss_traj"]), float(loss_dict["loss_pos_state"]), time.time() - t0))
 
 
 if __name__ == "__main__":

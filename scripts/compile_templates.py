@@ -32,6 +32,7 @@ def main():
         tpl["body_names"] = np.asarray(info["body_names"])
         tpl["kp"] = np.float32(info["kp"])
         tpl["kd"] = np.float32(info["kd"])
+        tpl["mass_rule"] = np.asarray(info["mass_rule"])  # which reading of dp_model.py:185-191 produced body_mass (robots.MASS_RULES)
         np.savez_compressed(os.path.join(out, name + ".npz"), **tpl)
         print(
             "%-8s nb=%d nq=%d nqd=%d Nc=%d mass=%s"
