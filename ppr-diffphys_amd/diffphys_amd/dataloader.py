@@ -75,9 +75,9 @@ def mocap_tensors(table, steps_fr):
     lo, hi = table[i0], table[i0 + 1]
     row = (hi - lo) * (x - i0.to(table.dtype)).unsqueeze(-1) + lo
     msm = parse_amp(row)
-    perm = [1, 2, 0]  # v @ _ISAAC_TO_GL.T
-    out = {k: msm[k][..., perm] for k in ("pos", "vel", "avel")}
-    out["orn"] = torch.cat([msm["orn"][..., :3][..., perm], msm["orn"][..., 3:]], -1)
+    perm = lambda v: torch.cat([v[..., 1:3], v[..., 0:1]], -1)  # v @ _ISAAC_TO_GL.T = (y, z, x); slices, no host-built index tensor
+    out = {k: perm(msm[k]) for k in ("pos", "vel", "avel")}
+    out["orn"] = torch.cat([perm(msm["orn"][..., :3]), msm["orn"][..., 3:]], -1)
     for k in ("jang", "jvel", "kp", "kp_vel"):
         out[k] = msm[k]
     return {k: v.float() for k, v in out.items()}

@@ -37,7 +37,7 @@ class HostFrames:
     "no host sync inside the op except the optional env-0 trajectory copy")."""
 
     def __init__(self, frames_dev):  # [F, nb, 7] device tensor (a detached view; nothing writes it afterwards)
-        self._dev, self._host = frames_dev, None
+        self._dev, self._host = frames_dev.detach(), None
 
     def _get(self):
         if self._host is None:

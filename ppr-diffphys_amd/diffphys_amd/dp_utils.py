@@ -13,7 +13,7 @@ def compose_delta(target_q, delta_root):
 
 def remove_nan(t, bs=None, clip=False):
     """in place NaN -> 0 (and optional +-0.01 clip)   dp_utils.py:43-57"""
-    t[t.isnan()] = 0
+    t.masked_fill_(t.isnan(), 0)  # (the reference's t[t.isnan()] = 0 without its host synchronisation)
     if clip:
         t.clamp_(-0.01, 0.01)
 
@@ -28,8 +28,7 @@ def rotate_frame(global_q, target_q):
 
 def rotate_frame_vel(global_q, target_qd):
     """rotate (linear, angular) halves by the rotation of global_q   dp_utils.py:76-84"""
-    gq = global_q.clone()
-    gq[..., :3] = 0
+    gq = torch.cat([torch.zeros_like(global_q[..., :3]), global_q[..., 3:]], -1)
     rev = torch.cat([target_qd[..., 3:], target_qd[..., :3]], -1)
     return torch.cat([rotate_frame(gq, target_qd)[..., :3], rotate_frame(gq, rev)[..., :3]], -1)
 
@@ -108,8 +107,8 @@ def se3_loss_torch(pred, gt, rot_ratio=0.1):
     if rp.shape[-1] == 3:
         rp, rgi = axis_angle_to_matrix(rp), axis_angle_to_matrix(rg).transpose(-1, -2)
     else:
-        rp = quaternion_to_matrix(rp[..., [3, 0, 1, 2]])
-        rgi = quaternion_to_matrix(quaternion_invert(rg[..., [3, 0, 1, 2]]))
+        rp = quaternion_to_matrix(torch.cat([rp[..., 3:4], rp[..., 0:3]], -1))
+        rgi = quaternion_to_matrix(quaternion_invert(torch.cat([rg[..., 3:4], rg[..., 0:3]], -1)))
     loss = trn + rot_angle(rp @ rgi) * rot_ratio
     return torch.where(nanid, torch.zeros_like(loss), loss)
 

@@ -23,10 +23,10 @@ def quaternion_to_matrix(q):
 
 
 def _sqrt_pos(x):
-    ret = torch.zeros_like(x)
+    """sqrt(max(0, x)) with a zero subgradient where x <= 0 -- by selection, not by masked assignment (no nonzero(), hence no
+    host synchronisation and capturable in a HIP graph)"""
     m = x > 0
-    ret[m] = torch.sqrt(x[m])
-    return ret
+    return torch.where(m, torch.sqrt(torch.where(m, x, torch.ones_like(x))), torch.zeros_like(x))
 
 
 def matrix_to_quaternion(matrix):
@@ -40,8 +40,8 @@ def matrix_to_quaternion(matrix):
         torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
         torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
     cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
-    best = F.one_hot(q_abs.argmax(-1), num_classes=4) > 0.5
-    return cand[best, :].reshape(batch + (4,))
+    best = q_abs.argmax(-1)  # gather instead of boolean-mask indexing: same row, no host synchronisation
+    return cand.gather(-2, best[..., None, None].expand(batch + (1, 4))).squeeze(-2)
 
 
 def axis_angle_to_quaternion(aa):
@@ -66,7 +66,7 @@ def quaternion_to_axis_angle(q):
 
 
 def quaternion_invert(q):
-    return q * torch.tensor([1, -1, -1, -1], device=q.device, dtype=q.dtype)
+    return torch.cat([q[..., :1], -q[..., 1:]], -1)  # (no host-built constant: capturable in a HIP graph)
 
 
 def rot_angle(mat):
@@ -80,22 +80,20 @@ def se3_vec2mat(vec):
     """(..., 7) (p, q real-last) or (..., 6) (p, axis-angle) -> (..., 4, 4)   (geom_utils.py:148-174)"""
     if not torch.is_tensor(vec):
         vec = torch.as_tensor(np.asarray(vec), dtype=torch.float32)
-    mat = torch.zeros(vec.shape[:-1] + (4, 4), device=vec.device, dtype=vec.dtype)
     if vec.shape[-1] == 6:
         rmat = axis_angle_to_matrix(vec[..., 3:6])
     else:
-        rmat = quaternion_to_matrix(vec[..., [6, 3, 4, 5]])
-    mat[..., :3, :3] = rmat
-    mat[..., :3, 3] = vec[..., :3]
-    mat[..., 3, 3] = 1
-    return mat
+        rmat = quaternion_to_matrix(torch.cat([vec[..., 6:7], vec[..., 3:6]], -1))  # real-first; slices, not a host-built index
+    top = torch.cat([rmat, vec[..., :3, None]], -1)  # assembled by concatenation (index assignment of Python scalars uploads them)
+    z = torch.zeros_like(top[..., :1, :1])
+    return torch.cat([top, torch.cat([z, z, z, z + 1], -1)], -2)
 
 
 def se3_mat2vec(mat, outdim=7):
     """(..., 4, 4) -> (..., 7) real-last quaternion, or (..., 6) axis-angle   (geom_utils.py:187-203)"""
     quat = matrix_to_quaternion(mat[..., :3, :3])
     if outdim == 7:
-        rot = quat[..., [1, 2, 3, 0]]
+        rot = torch.cat([quat[..., 1:4], quat[..., 0:1]], -1)
     elif outdim == 6:
         rot = quaternion_to_axis_angle(quat)
     else:
@@ -110,7 +108,8 @@ def fid_reindex(fid, num_vids, vid_offset):
     max_ts = (vid_offset[1:] - vid_offset[:-1]).max()
     for i in range(num_vids):
         assign = torch.logical_and(fid >= vid_offset[i], fid < vid_offset[i + 1])
-        vid[assign] = i
         doffset = vid_offset[i + 1] - vid_offset[i]
-        tid[assign] = (fid[assign].float() - vid_offset[i] - doffset / 2) / max_ts * 2
+        # torch.where instead of the reference's masked assignment: same values, no nonzero() -> no host synchronisation
+        vid = torch.where(assign, torch.full_like(vid, i), vid)
+        tid = torch.where(assign, (fid.float() - vid_offset[i] - doffset / 2) / max_ts * 2, tid)
     return vid, tid

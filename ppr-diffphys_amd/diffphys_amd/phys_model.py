@@ -134,6 +134,7 @@ class phys_model(nn.Module):
         self.steps_idx = range(self.steps_per_fr_interval * (frames_per_wdw - 1) + 1)
         self.steps_idx_fr = torch.tensor(list(self.steps_idx), device=self.device) / self.steps_per_fr_interval
         self.frame2step = [i for i in range(len(self.steps_idx)) if i % self.steps_per_fr_interval == 0]
+        self._f2s_t = torch.tensor(self.frame2step, dtype=torch.long, device=self.device)  # device copy for indexing (no upload per use)
         env_name = "eval_env" if is_eval else "train_env"
         if hasattr(self, env_name) and not overwrite and getattr(self, env_name).num_envs == num_envs:
             self.env = getattr(self, env_name)
@@ -317,7 +318,7 @@ class phys_model(nn.Module):
         target_qd = torch.cat([t("vel"), t("avel")], -1)
         target_q = rotate_frame(self.global_q, target_q)
         target_qd = rotate_frame_vel(self.global_q, target_qd)
-        f2s = self.frame2step
+        f2s = self._frame_index()
         target_position, target_velocity, self.target_trajs = self.fk_pos_vel(
             target_q[:, f2s], target_ja[:, f2s], target_qd[:, f2s], target_jad[:, f2s])
         torques, delta_q, delta_ja, queried_qd, res_f = self.get_net_pred(steps_fr)
@@ -330,7 +331,7 @@ class phys_model(nn.Module):
     def make_q_init_noise(self):
         """The init noise of this iteration (dp_model.py:702-712): N(0, noise_std * ratio), none on the root translation, x5 on
         the root rotation; None when the model is not training or the noise is off.  A separate method so that a captured
-        iteration (``graphed_step``) can feed it through a static buffer."""
+        iteration (scripts/gpu_iter_graph.py) can feed it through a static buffer."""
         if not (self.training and self.noise_std > 0):
             return None
         noise_ratio = np.clip(1 - 1.5 * self.progress, 0, 1)
@@ -345,7 +346,7 @@ class phys_model(nn.Module):
         """``q_init_noise``: the tensor make_q_init_noise() would draw (a captured iteration passes its static buffer)."""
         frame_start = self.compute_frame_start() if frame_start is None else frame_start[: self.num_envs]
         steps_fr = frame_start[:, None] + self.steps_idx_fr[None]
-        vidid, _ = fid_reindex(steps_fr[:, self.frame2step], len(self.frame_offset_raw) - 1, self.frame_offset_raw)
+        vidid, _ = fid_reindex(steps_fr[:, self._frame_index()], len(self.frame_offset_raw) - 1, self.frame_offset_raw)
         outseq_idx = (vidid[:, :1] - vidid) != 0
         target_position, ref_ja, queried_q, queried_qd, torques, res_f = self.get_batch_input(steps_fr)
 
@@ -364,7 +365,14 @@ class phys_model(nn.Module):
         body_mass = self.body_mass[None].repeat(n, 1).view(-1)
         body_inv_mass = 1.0 / body_mass
         body_inertia = self.norm_body_inertia[None].repeat(n, 1, 1, 1).view(-1, 3, 3) * body_mass[..., None, None]
-        body_inv_inertia = body_inertia.inverse().contiguous()
+        if torch.cuda.is_current_stream_capturing():
+            # (experiment scripts/gpu_iter_graph.py) the batched LU is not capturable; inverse(norm_inertia * m) =
+            # inverse(norm_inertia) / m exactly in exact arithmetic, with the constant factor inverted once, eagerly
+            body_inv_inertia = (self._inv_norm_inertia()[None].repeat(n, 1, 1, 1).view(-1, 3, 3) / body_mass[..., None, None]).contiguous()
+        else:
+            # the reference's body_inertia.inverse() (dp_model.py:730) without its singular-matrix check, which is a host
+            # synchronisation per forward(): same LU, same values
+            body_inv_inertia = torch.linalg.inv_ex(body_inertia).inverse.contiguous()
         qd_init = convert_ppr_warp(qd_init)  # quirk (i): flat vector
         res_fin = convert_ppr_warp(res_fin)
         sim_position, sim_velocity = ForwardWarp.apply(q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass,
@@ -372,8 +380,8 @@ class phys_model(nn.Module):
         sim_velocity = convert_ppr_warp(sim_velocity)
 
         F_ = self.frames_per_wdw
-        queried_q = queried_q[self.frame2step].reshape(F_, n, -1)
-        queried_qd = convert_ppr_warp(queried_qd[self.frame2step].reshape(F_, n, -1))
+        queried_q = queried_q[self._frame_index()].reshape(F_, n, -1)
+        queried_qd = convert_ppr_warp(queried_qd[self._frame_index()].reshape(F_, n, -1))
         queried_position, queried_velocity, self.pid_ref = ForwardKinematics.apply(queried_q, queried_qd, self.env)
         queried_velocity = convert_ppr_warp(queried_velocity)
         foot_height = self.get_foot_height(queried_position)
@@ -404,6 +412,17 @@ class phys_model(nn.Module):
         self._pending_loss = total_loss.detach()
         out["total_loss"] = total_loss
         return out
+
+    def _frame_index(self):
+        t = getattr(self, "_f2s_t", None)
+        if t is None or t.numel() != len(self.frame2step):  # frame2step set by hand (init_global_q, tests)
+            t = self._f2s_t = torch.tensor(list(self.frame2step), dtype=torch.long, device=self.device)
+        return t
+
+    def _inv_norm_inertia(self):
+        if getattr(self, "_inv_norm_cache", None) is None:
+            self._inv_norm_cache = self.norm_body_inertia.inverse().contiguous()
+        return self._inv_norm_cache
 
     def backward(self, loss):
         loss.backward()

@@ -331,8 +331,22 @@ def test_phys_model_training_iterations(dev):
     assert q["sim_traj"].shape == (4, 13, 7) and q["grf"].shape == (4, 8 * 13, 6)
     model.save_checkpoint(0)
     assert os.path.exists("/tmp/pprdp_test_log/mi-pace-t/ckpt_phys_latest.pth")
+    # nothing between forward() and backward() may wait for the device (lazy env-0 copies, cached step->frame table,
+    # sync-free reduce_loss / SE(3) helpers, NaN check deferred to update()): a forward + backward pair enqueues without a
+    # single host synchronisation -- checked by running it with synchronisation turned into an error
+    torch.cuda.synchronize()
+    prev = torch.cuda.get_sync_debug_mode()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        noise = None
+        out = model.forward(frame_start=fs, q_init_noise=torch.zeros(8 * 19, device=model.device))
+        model.backward(out["total_loss"])
+    finally:
+        torch.cuda.set_sync_debug_mode(prev)
+    model.update()
 
 
+@pytest.mark.gpu
 def test_generic_joint_kernel_on_toy_robot(dev, oracle_libs, tmp_path):
     """A URDF mixing free + revolute + compound + fixed joints and box / sphere / mesh / capsule contacts goes through the
     model compiler and the GENERIC kernel instantiation (all joint types), which none of the three shipped robots uses."""
@@ -387,8 +401,9 @@ def test_generic_joint_kernel_on_toy_robot(dev, oracle_libs, tmp_path):
 
 
 def test_empty_batch_and_graph_capture(dev):
-    """Empty inputs return empty outputs; and the launch path neither allocates through HIP nor synchronises, so a
-    forward + adjoint pair can be captured into a HIP graph (torch.cuda.graphs) and replayed with identical results."""
+    """Empty inputs return empty outputs; and the launch path neither allocates through HIP nor synchronises, so the whole
+    device side of an optimisation iteration -- FK, rollout, fused frame losses, adjoint rollout, FK adjoint -- can be
+    captured into ONE HIP graph (torch.cuda.graphs) and replayed, repeatedly, with bit-identical results."""
     from diffphys_amd import dp_model, hip_backend, robots, synth
 
     tpl = robots.load_template("laikago")
@@ -407,12 +422,21 @@ def test_empty_batch_and_graph_capture(dev):
     fos = list(inp["frame2step"])
     F = len(inp["frame2step"])
 
-    def run():
-        o = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=fos)
-        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, o[4], t["adj_pos"], t["adj_vel"])
-        return o[0], g["q_init"]
+    tq = torch.from_numpy(np.tile(inp["q_init"].reshape(bs, -1), (F, 1))).to(dev)   # target joint coordinates of the F frames
+    tqd = torch.zeros(F * bs, 18, device=dev)
 
-    ref_pos, ref_g = run()
+    def run():
+        """what one optimisation iteration asks of the library: FK of the targets, rollout, fused pose loss of
+        every frame (loss + both gradients in one launch), adjoint rollout seeded by the loss gradient, FK adjoint"""
+        tgt_q, tgt_qd = dm.fk_forward(tq, tqd)
+        o = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=fos)
+        loss, g_pred, _ = hip_backend.se3_loss(o[0].view(F * bs, 13, 7), tgt_q, 0.1)
+        lv, g_vel, _ = hip_backend.se3_loss(o[1].view(F * bs, 13, 6), tgt_qd, 0.1)
+        g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, o[4], g_pred.view(F, bs * 13, 7), g_vel.view(F, bs * 13, 6))
+        gq, _ = dm.fk_backward(tq, tqd, g_pred, g_vel)
+        return o[0], g["q_init"], loss, gq
+
+    ref = [x.clone() for x in run()]
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
@@ -420,12 +444,15 @@ def test_empty_batch_and_graph_capture(dev):
     with torch.cuda.stream(side):
         run()  # warm-up on the capture stream
         with torch.cuda.graph(graph, stream=side):
-            cap_pos, cap_g = run()
+            cap = run()
     torch.cuda.current_stream().wait_stream(side)
-    cap_pos.zero_(); cap_g.zero_()
-    graph.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(cap_pos, ref_pos) and torch.equal(cap_g, ref_g)
+    for _ in range(3):  # several replays: every one must reproduce the eager results bit for bit
+        for x in cap:
+            x.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(cap, ref))
+    assert float(ref[2].abs().max()) > 0 and float(ref[1].abs().max()) > 0
 
 
 @pytest.mark.parametrize("segw", [0, 64])
