@@ -1,12 +1,15 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the bench command.
+#   scripts/profile_gpu.sh TAG [extra bench.py arguments, e.g. --robot human --bs 1024]
 # Outputs under gpurun_out/prof_$TAG/ ; scripts/summarize_profile.py turns them into profiles/*.
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline $@"
+echo "$BENCH" > $OUT/command.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -10,7 +10,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+write_json = "--json" in sys.argv  # only the headline (Laikago 4096 x 100) profile feeds profiles/pmc_summary.json, which bench.py reads
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -45,16 +46,24 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
 mean = lambda k, c: sum(acc[(k, c)]) / max(1, len(acc[(k, c)]))
 avg_ns = {("k_rollout_bwd" if "bwd" in r["Name"] else "k_rollout_fwd"): float(r["AverageNs"]) for r in rows if "rollout" in r["Name"]}
 summary = {}
-lines = ["# rocprofv3 summary `%s` (bench.py --steps 10 --warmup 2, 1x MI355X)\n" % tag,
+cmd_file = os.path.join(src, "command.txt")
+cmd = open(cmd_file).read().strip().split("bench.py", 1)[-1].strip() if os.path.exists(cmd_file) else "--steps 10 --warmup 2"
+N_SIMD = 1024  # 256 CUs x 4
+lines = ["# rocprofv3 summary `%s` (bench.py %s, 1x MI355X)\n" % (tag, cmd),
          "Source: `scripts/profile_gpu.sh %s` on the GPU box; raw csv under `gpurun_out/prof_%s/` (scratch)." % (tag, tag), ""]
 for k in ("k_rollout_fwd", "k_rollout_bwd"):
     if k not in avg_ns:
         continue
     fetch_kb, write_kb = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
     hbm = fetch_kb * 1024 * 2 + write_kb * 1024  # gfx950: FETCH_SIZE counts 128-B requests at 64 B
-    summary[k] = dict(avg_launch_ns=avg_ns[k], fetch_size_kb_raw=fetch_kb, write_size_kb=write_kb, hbm_bytes_per_launch=hbm,
-                      meta=meta.get(k, {}))
     wc = mean(k, "SQ_WAVE_CYCLES")
+    gui = mean(k, "GRBM_GUI_ACTIVE")
+    gui = gui / 8.0  # the counter is summed over the 8 XCDs (each has its own GRBM): per-XCD busy cycles = the launch duration
+    valu_rate = mean(k, "SQ_INSTS_VALU") / max(1.0, gui * N_SIMD)  # wave-instructions issued per SIMD and GPU-busy cycle
+    waves_per_simd = float(meta.get(k, {}).get("grid", 0)) / 64.0 / N_SIMD
+    summary[k] = dict(avg_launch_ns=avg_ns[k], fetch_size_kb_raw=fetch_kb, write_size_kb=write_kb, hbm_bytes_per_launch=hbm,
+                      valu_issue_per_simd_cycle=valu_rate, valu_busy=2.5 * valu_rate,  # 2.5 cycles per wave64 fp32 op (scripts/micro/valu_chain.hip)
+                      wait_share=mean(k, "SQ_WAIT_ANY") / max(1.0, wc), waves_per_simd=waves_per_simd, meta=meta.get(k, {}))
     lines += ["## %s  (%s)" % (k, meta.get(k, {}).get("name", "")),
               "* average launch %.1f us; grid %s x wg %s; VGPR %s (+%s accum), SGPR %s, scratch %s" % (
                   avg_ns[k] / 1e3, meta[k]["grid"], meta[k]["wg"], meta[k]["vgpr"], meta[k]["agpr"], meta[k]["sgpr"], meta[k]["scratch"]),
@@ -65,9 +74,14 @@ for k in ("k_rollout_fwd", "k_rollout_bwd"):
                   mean(k, "SQ_INSTS_VMEM_RD"), mean(k, "SQ_INSTS_VMEM_WR")),
               "* wave cycles (quad-cycles) %.3g: waiting (SQ_WAIT_ANY) %.0f%%, issuing (SQ_ACTIVE_INST_ANY) %.0f%%, issue-stalled (SQ_WAIT_INST_ANY) %.0f%%" % (
                   wc, 100 * mean(k, "SQ_WAIT_ANY") / wc, 100 * mean(k, "SQ_ACTIVE_INST_ANY") / wc, 100 * mean(k, "SQ_WAIT_INST_ANY") / wc),
+              "* secondary bound: %.2f waves per SIMD launched; VALU issue %.3f wave-instructions per SIMD-cycle (x 2.5 cycles each = %.0f%% VALU busy); GPU busy %.3g cycles" % (
+                  waves_per_simd, valu_rate, 250 * valu_rate, gui),
               "* LDS: bank-conflict cycles %.3g of %.3g active (%.0f%%)" % (
                   mean(k, "SQ_LDS_BANK_CONFLICT"), mean(k, "SQ_LDS_IDX_ACTIVE"),
                   100 * mean(k, "SQ_LDS_BANK_CONFLICT") / max(1.0, mean(k, "SQ_LDS_IDX_ACTIVE"))), ""]
 open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines))
-json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+summary["tag"] = tag
+json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
+if write_json:
+    json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print("\n".join(lines))
