@@ -165,7 +165,16 @@ class phys_model(nn.Module):
 
     def add_optimizer(self, opts):
         self.params_ref_list, params_list, lr_list = self.get_optimizable_param_list()
-        self.optimizer = torch.optim.AdamW(params_list, lr=opts["phys_learning_rate"], weight_decay=1e-4)
+        # same AdamW as the reference (dp_model.py:914-918); on the GPU the fused implementation (one launch for all
+        # parameters instead of a few per parameter, identical update rule) where this torch build has it
+        kw = {}
+        if torch.cuda.is_available() and str(self.device).startswith("cuda"):
+            try:
+                torch.optim.AdamW([torch.zeros(1, device=self.device, requires_grad=True)], fused=True)
+                kw["fused"] = True
+            except Exception:
+                kw = {}
+        self.optimizer = torch.optim.AdamW(params_list, lr=opts["phys_learning_rate"], weight_decay=1e-4, **kw)
         total_iters = max(2, self.total_iters)
         self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
             self.optimizer, lr_list, total_iters, pct_start=2.0 / total_iters, cycle_momentum=False,
@@ -318,9 +327,8 @@ class phys_model(nn.Module):
         target_qd = torch.cat([t("vel"), t("avel")], -1)
         target_q = rotate_frame(self.global_q, target_q)
         target_qd = rotate_frame_vel(self.global_q, target_qd)
-        f2s = self._frame_index()
-        target_position, target_velocity, self.target_trajs = self.fk_pos_vel(
-            target_q[:, f2s], target_ja[:, f2s], target_qd[:, f2s], target_jad[:, f2s])
+        fr = lambda x: self._frames_of(x, 1)
+        target_position, target_velocity, self.target_trajs = self.fk_pos_vel(fr(target_q), fr(target_ja), fr(target_qd), fr(target_jad))
         torques, delta_q, delta_ja, queried_qd, res_f = self.get_net_pred(steps_fr)
         queried_q = compose_delta(target_q, delta_q)
         queried_ja = target_ja + delta_ja
@@ -346,7 +354,7 @@ class phys_model(nn.Module):
         """``q_init_noise``: the tensor make_q_init_noise() would draw (a captured iteration passes its static buffer)."""
         frame_start = self.compute_frame_start() if frame_start is None else frame_start[: self.num_envs]
         steps_fr = frame_start[:, None] + self.steps_idx_fr[None]
-        vidid, _ = fid_reindex(steps_fr[:, self._frame_index()], len(self.frame_offset_raw) - 1, self.frame_offset_raw)
+        vidid, _ = fid_reindex(self._frames_of(steps_fr, 1), len(self.frame_offset_raw) - 1, self.frame_offset_raw)
         outseq_idx = (vidid[:, :1] - vidid) != 0
         target_position, ref_ja, queried_q, queried_qd, torques, res_f = self.get_batch_input(steps_fr)
 
@@ -380,8 +388,8 @@ class phys_model(nn.Module):
         sim_velocity = convert_ppr_warp(sim_velocity)
 
         F_ = self.frames_per_wdw
-        queried_q = queried_q[self._frame_index()].reshape(F_, n, -1)
-        queried_qd = convert_ppr_warp(queried_qd[self._frame_index()].reshape(F_, n, -1))
+        queried_q = self._frames_of(queried_q, 0).reshape(F_, n, -1)
+        queried_qd = convert_ppr_warp(self._frames_of(queried_qd, 0).reshape(F_, n, -1))
         queried_position, queried_velocity, self.pid_ref = ForwardKinematics.apply(queried_q, queried_qd, self.env)
         queried_velocity = convert_ppr_warp(queried_velocity)
         foot_height = self.get_foot_height(queried_position)
@@ -412,6 +420,16 @@ class phys_model(nn.Module):
         self._pending_loss = total_loss.detach()
         out["total_loss"] = total_loss
         return out
+
+    def _frames_of(self, x, dim):
+        """x[frame2step] along `dim`.  frame2step is every steps_per_fr_interval-th step (reinit_envs), so this is a strided
+        VIEW whose backward is a strided copy; the reference's list indexing (dp_model.py:621-626, 747-752) has an
+        index_put backward that costs ~1 ms per use on the GPU (3 ms per iteration)."""
+        f2s = list(self.frame2step)
+        k = self.steps_per_fr_interval
+        if f2s == list(range(0, x.shape[dim], k))[: len(f2s)] and len(f2s) == len(range(0, x.shape[dim], k)):
+            return x[(slice(None),) * dim + (slice(None, None, k),)]
+        return x.index_select(dim, self._frame_index())
 
     def _frame_index(self):
         t = getattr(self, "_f2s_t", None)
