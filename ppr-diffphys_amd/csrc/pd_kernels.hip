@@ -950,6 +950,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 
   // The stored state, wrench and controls of the NEXT iteration (step - 1) are software-prefetched.
   const unsigned boff = (unsigned)idx * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;  // per-lane byte offsets
+  const bool zero_by_lanes = m.jtype[0] == PD_JOINT_FREE && nb >= 7;  // see the control-gradient stores below
+  const unsigned boff_zero = (unsigned)((size_t)ec * m.nqd + m.qdstart[0] + (b >= 1 && b <= 6 ? b - 1 : 0)) * 4u;
   float4 n_s[PD_TRAJ_G];
   float n_tgt[ND], n_act[ND];
   int n_fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
@@ -1050,7 +1052,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         if (k < ndof) { stg(a.g_refs + oc + k, boff_qd, a_tgt[k]); stg(a.g_torques + oc + k, boff_qd, a_act[k]); }
         g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k];
       }
-      if (c.type == PD_JOINT_FREE) {
+      // the root's six dof columns are zero (a FREE joint reads no dof, integrator_euler.py:382).  Lanes 1..6 write one each
+      // beside their own entry -- two vector-memory instructions per array and step instead of seven: with eight waves
+      // on a CU it is the NUMBER of such instructions (one per ~27 cycles across the CU), not their bytes, that the loop feels
+      if (zero_by_lanes) {
+        if (b >= 1 && b <= 6) { stg(a.g_refs + oc, boff_zero, 0.f); stg(a.g_torques + oc, boff_zero, 0.f); }
+      } else if (c.type == PD_JOINT_FREE) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { stg(a.g_refs + oc + k, boff_qd, 0.f); stg(a.g_torques + oc + k, boff_qd, 0.f); }
       }
