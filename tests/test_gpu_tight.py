@@ -279,3 +279,34 @@ def test_against_round1_bits(name, dev):
                 assert same, (tag, k, d)
             elif tag == "golden":
                 assert same or d < 1e-5, (tag, k, d)
+
+
+@pytest.mark.parametrize("name,bs", [("human", 1024), ("quad", 2048)])
+def test_role_split_adjoint_is_deterministic_and_batch_invariant(name, bs, dev):
+    """k_rollout_bwd3 (integrate + joint wave handing over through polled LDS words, double-buffered records): a race would
+    show up as changing bits.  Run to run, and against the same envs rolled out alone in a small batch (different workgroup
+    geometry: the host picks fewer env groups per workgroup for small batches), every gradient must be bit-identical."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template(name)
+    T = 100
+    inp = synth.make_env_inputs(tpl, name, range(bs), T, seed=5, penetration=0.002)
+    dm = hip_backend.DeviceModel(tpl)
+    full = gpu_rollout(dm, inp, dev)
+    assert all(np.isfinite(v).all() for v in full["grads"].values())
+    for _ in range(2):
+        again = gpu_rollout(dm, inp, dev)
+        assert all(np.array_equal(again["grads"][k], full["grads"][k]) for k in full["grads"])
+        assert np.array_equal(again["wp_pos"], full["wp_pos"])
+    sub = 37
+    part = synth.make_env_inputs(tpl, name, range(sub), T, seed=5, penetration=0.002)
+    small = gpu_rollout(dm, part, dev)
+    assert dm.last_launch_info(1)["envs_per_wg"] < 8 and dm.last_launch_info(1)["threads_per_wg"] < 512
+    for k, lead in GRAD_LEAD.items():
+        a = small["grads"][k]
+        b = full["grads"][k]
+        if lead:
+            b = b.reshape(T, bs, -1)[:, :sub].reshape(a.shape)
+        else:
+            b = b.reshape(bs, -1)[:sub].reshape(a.shape)
+        assert np.array_equal(a, b), k
