@@ -80,23 +80,33 @@ PD_DEV int seg_slot(bool pred, SegMask sm, int &total) {
   return slot;
 }
 
-// Per-body sums of per-hit results held one hit per lane (lanes 0 .. nh-1 of the segment, hits of a body contiguous):
-// a serial chain of DPP lane shifts, step s folding lane s-1's finished prefix into lane s.  It reproduces the plain
-// left-to-right sum -- the order of the ds_add_f32 path and of every other path, so results do not depend on which path
-// ran, and entries that contribute exactly 0 may sit anywhere -- without touching LDS.  On return the LAST lane of each
-// body's run holds that body's totals.  2 NV VALU instructions per step (v_add_f32_dpp wave_shr:1 + v_cndmask).
+// Per-body sums of per-hit results held one hit per lane (lanes 0 .. nh-1 of the segment, hits of a body contiguous), without
+// touching LDS.  Iteration i lets every lane whose position p in its body's run is >= i take  z(lane - 1) + x(own)  with z the
+// previous iteration's value of the lane below (one DPP lane shift) and x the lane's ORIGINAL term: z_p becomes
+// ((x_{p-i} + x_{p-i+1}) + ...) + x_p, so after (run length - 1) iterations the LAST lane of a run holds the plain left-to-right
+// sum of the run -- the order of the ds_add_f32 path and of every other path, so results do not depend on which path ran,
+// and entries that contribute exactly 0 may sit anywhere.  The loop runs (longest run of the wave - 1) times, typically 1-3
+// (a foot's few points); the first version walked the lanes one by one, (hits of the env - 1) iterations, and was 11 % of the
+// adjoint kernel at 4096 envs.  2 NV VALU instructions per iteration (v_add_f32_dpp wave_shr:1 + v_cndmask).
 template <int NV>
 PD_DEV void seg_run_sum(float *acc, int pb, int l, int nh, bool &last) {
   const int pbp = __builtin_amdgcn_update_dpp(-1, pb, 0x138, 0xf, 0xf, false);  // body of the hit one lane down (wave_shr:1)
   const int pbn = __builtin_amdgcn_update_dpp(-1, pb, 0x130, 0xf, 0xf, false);  // ... one lane up (wave_shl:1)
-  const bool in = l < nh, cont = in && l > 0 && pbp == pb;
+  const bool in = l < nh, start = in && (l == 0 || pbp != pb);
   last = in && (l == nh - 1 || pbn != pb);
-  for (int s = 1; __ballot(s < nh) != 0ull; ++s) {
-    const bool upd = cont && l == s;
+  // position in the run = distance to the nearest run start at or below this lane
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned long long starts = __ballot(start), below = starts & ((2ull << lane) - 1ull);
+  const int pos = in ? lane - (63 - __clzll((long long)below)) : -1;
+  float x[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) x[i] = acc[i];
+  for (int it = 1; __ballot(pos >= it) != 0ull; ++it) {
+    const bool upd = pos >= it;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[i]), 0x138, 0xf, 0xf, true));
-      acc[i] = upd ? prev + acc[i] : acc[i];
+      acc[i] = upd ? prev + x[i] : acc[i];
     }
   }
 }
