@@ -71,3 +71,6 @@ elif wb == 8 and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ conta
 else:
     report("BWD", "body wave", rows(b_all, 0), [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"),
                                                (2, "wait A + joints adj + stores"), (3, "child gather"), (4, "wait B + cacc gather")])
+    if wb == 8:
+        report("BWD", "contact wave", rows(b_all, 1), [(8, "joint state-only half -> LDS"), (7, "prefetch issue"), (9, "wait at hand-over A"),
+                                                      (10, "contact adjoint per hit"), (11, "per-body sums"), (12, "tail / generic sweep")])
