@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 2   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding */
+#define PD_ABI_VERSION 3   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -129,6 +129,31 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const flo
  * give loss 0 and zero gradients, like the reference. */
 int pd_se3_loss(int n, int dim, const float *pred_dev, const float *gt_dev, float rot_ratio, float *loss_dev,
                 float *g_pred_dev, float *g_gt_dev, void *stream);
+
+/* SE(3) pose algebra of the loss plumbing, one launch per op and one per vector-Jacobian
+ * product; replaces the reference's compositions of dqtorch kernels and torch ops:
+ *   PD_POSE_COMPOSE_DELTA  a = target pose [n][7] (p, real-last quaternion), b = delta [n][6] (p, axis-angle) -> out [n][7]
+ *                          = se3_mat2vec(se3_vec2mat(delta) @ se3_vec2mat(target))        diffphys/dp_utils.py:22-31
+ *   PD_POSE_ROTATE_FRAME   a = global pose, b = target pose [n][7] -> out [n][7] = T_global @ T_target   dp_utils.py:60-73
+ *   PD_POSE_ROTATE_VEL     a = global pose, b = (linear, angular) [n][6] -> out [n][6], both halves rotated by the
+ *                          rotation of the global pose                                    dp_utils.py:76-84
+ * with se3_vec2mat / se3_mat2vec / quaternion <-> matrix as in diffphys/geom_utils.py:148-203 (quaternions are divided
+ * by |q|^2, the best-conditioned of the four matrix->quaternion forms is taken).  a_broadcast != 0: `a` is ONE 7-vector
+ * shared by all n elements.  The VJP writes g_a [n][7] (per element also when `a` is broadcast: the caller sums) and
+ * g_b [n][6 or 7]; either may be NULL. */
+enum { PD_POSE_COMPOSE_DELTA = 0, PD_POSE_ROTATE_FRAME = 1, PD_POSE_ROTATE_VEL = 2 };
+int pd_pose_op(int op, int n, const float *a_dev, int a_broadcast, const float *b_dev, float *out_dev, void *stream);
+int pd_pose_op_vjp(int op, int n, const float *a_dev, int a_broadcast, const float *b_dev, const float *g_out_dev,
+                   float *g_a_dev, float *g_b_dev, void *stream);
+
+/* Lowest ground-contact candidate of each of n pose sets (get_foot_height / the reg_foot term, diffphys/dp_model.py:
+ * 574-579,762,814, evaluated on the contact candidates instead of posed visual meshes):  height[i] = min over candidates c of
+ * body_q[i][c_body[c]].p.y + (R(body_q[i][c_body[c]].q) c_point[c]).y - c_dist[c];  arg[i] = the minimising candidate
+ * (lowest index on ties).  body_q [n][nb][7].  The VJP writes g_body_q [n][nb][7] (zero except the arg-min body). */
+int pd_foot_height(int n, int nb, int nc, const float *body_q_dev, const int *c_body_dev, const float *c_point_dev,
+                   const float *c_dist_dev, float *height_dev, int *arg_dev, void *stream);
+int pd_foot_height_vjp(int n, int nb, const float *body_q_dev, const int *c_body_dev, const float *c_point_dev,
+                       const int *arg_dev, const float *g_height_dev, float *g_body_q_dev, void *stream);
 
 /* Device time (ms) of this model's last `kind` launch, measured with hipEvents recorded on the launch stream around
  * the kernel: kind 0 = rollout forward, 1 = rollout backward.  Enabled per model by pd_model_set_timing(m, 1); used by

@@ -6,8 +6,44 @@ from .dataloader import bullet2gl  # noqa: F401  (re-exported like the reference
 from .geom_utils import axis_angle_to_matrix, quaternion_invert, quaternion_to_matrix, rot_angle, se3_mat2vec, se3_vec2mat
 
 
+class _PoseOpHip(torch.autograd.Function):
+    """One of the three pose compositions below as ONE HIP launch, its vector-Jacobian product as one more (C ABI
+    ``pd_pose_op`` / ``pd_pose_op_vjp``; the Jacobian is taken inside the kernel by forward-mode differentiation of the
+    code that computed the value)."""
+
+    @staticmethod
+    def forward(ctx, op, a, b):
+        from . import hip_backend
+
+        a, b = a.detach().contiguous(), b.detach().contiguous()
+        ctx.op = op
+        ctx.save_for_backward(a, b)
+        return hip_backend.pose_op(op, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip_backend
+
+        a, b = ctx.saved_tensors
+        need_a, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        g_a, g_b = hip_backend.pose_op_vjp(ctx.op, a, b, g.contiguous(), need_a, need_b)
+        return None, g_a, g_b
+
+
+def _hip_pose(*ts):
+    """float32 GPU tensors take the HIP kernels (no silent fallback there: a missing library raises); anything else -- the
+    CPU host tests, float64 checks -- runs the torch composition, which is also the kernels' test reference."""
+    return all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
 def compose_delta(target_q, delta_root):
     """delta (bs,T,6 axis-angle) applied on the left of target (bs,T,7)   dp_utils.py:22-31"""
+    if _hip_pose(target_q, delta_root) and target_q.shape[-1] == 7 and delta_root.shape[-1] == 6 and target_q.shape[:-1] == delta_root.shape[:-1]:
+        return _PoseOpHip.apply(0, target_q, delta_root)
+    return compose_delta_torch(target_q, delta_root)
+
+
+def compose_delta_torch(target_q, delta_root):
     return se3_mat2vec(se3_vec2mat(delta_root) @ se3_vec2mat(target_q))
 
 
@@ -20,6 +56,12 @@ def remove_nan(t, bs=None, clip=False):
 
 def rotate_frame(global_q, target_q):
     """T = T_global @ T_target   dp_utils.py:60-73"""
+    if _hip_pose(global_q, target_q) and global_q.shape == (7,) and target_q.shape[-1] == 7:
+        return _PoseOpHip.apply(1, global_q, target_q)
+    return rotate_frame_torch(global_q, target_q)
+
+
+def rotate_frame_torch(global_q, target_q):
     gm = se3_vec2mat(global_q)
     if global_q.dim() == 1:
         gm = gm[None, None]
@@ -28,9 +70,15 @@ def rotate_frame(global_q, target_q):
 
 def rotate_frame_vel(global_q, target_qd):
     """rotate (linear, angular) halves by the rotation of global_q   dp_utils.py:76-84"""
+    if _hip_pose(global_q, target_qd) and global_q.shape == (7,) and target_qd.shape[-1] == 6:
+        return _PoseOpHip.apply(2, global_q, target_qd)
+    return rotate_frame_vel_torch(global_q, target_qd)
+
+
+def rotate_frame_vel_torch(global_q, target_qd):
     gq = torch.cat([torch.zeros_like(global_q[..., :3]), global_q[..., 3:]], -1)
     rev = torch.cat([target_qd[..., 3:], target_qd[..., :3]], -1)
-    return torch.cat([rotate_frame(gq, target_qd)[..., :3], rotate_frame(gq, rev)[..., :3]], -1)
+    return torch.cat([rotate_frame_torch(gq, target_qd)[..., :3], rotate_frame_torch(gq, rev)[..., :3]], -1)
 
 
 def reduce_loss_loop(loss_seq, clip=False, th=0):

@@ -14,7 +14,7 @@ import torch
 _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
-ABI_VERSION = 2  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+ABI_VERSION = 3  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -60,6 +60,10 @@ def lib():
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
         L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
+        L.pd_pose_op.argtypes = [ci, ci, vp, ci, vp, vp, vp]
+        L.pd_pose_op_vjp.argtypes = [ci, ci, vp, ci, vp, vp, vp, vp, vp]
+        L.pd_foot_height.argtypes = [ci, ci, ci] + [vp] * 6 + [vp]
+        L.pd_foot_height_vjp.argtypes = [ci, ci] + [vp] * 6 + [vp]
         if L.pd_abi_version() != ABI_VERSION:
             raise RuntimeError("libpprdiffphys_hip.so ABI mismatch: library %d, binding %d" % (L.pd_abi_version(), ABI_VERSION))
         _lib = L
@@ -268,6 +272,78 @@ def se3_loss(pred, gt, rot_ratio, want_grads=True):
     if rc != 0:
         raise RuntimeError("pd_se3_loss failed (rc %d)" % rc)
     return loss, gp, gg
+
+
+POSE_COMPOSE_DELTA, POSE_ROTATE_FRAME, POSE_ROTATE_VEL = 0, 1, 2
+_POSE_DIMS = {POSE_COMPOSE_DELTA: (7, 6, 7), POSE_ROTATE_FRAME: (7, 7, 7), POSE_ROTATE_VEL: (7, 6, 6)}
+
+
+def _pose_n(op, a, b):
+    na, nb_, no = _POSE_DIMS[op]
+    if b.shape[-1] != nb_ or a.shape[-1] != na:
+        raise ValueError("pose op %d: operands must end in %d and %d floats; got %s and %s" % (op, na, nb_, tuple(a.shape), tuple(b.shape)))
+    n = b.numel() // nb_
+    bcast = a.numel() == na and n != 1
+    if not bcast and a.numel() != n * na:
+        raise ValueError("pose op %d: %d poses against %d operands" % (op, a.numel() // na, n))
+    return n, bcast, no
+
+
+def pose_op(op, a, b):
+    """``pd_pose_op``: compose_delta(a = target (..., 7), b = delta (..., 6)), rotate_frame(a = global (7,) or (..., 7),
+    b = target (..., 7)) or rotate_frame_vel(a = global, b = (..., 6)) in one launch; float32 contiguous GPU tensors."""
+    n, bcast, no = _pose_n(op, a, b)
+    out = torch.empty(b.shape[:-1] + (no,), device=b.device, dtype=torch.float32)
+    rc = lib().pd_pose_op(op, n, _dev(a, "a"), int(bcast), _dev(b, "b"), _dev(out, "out"), _stream())
+    if rc != 0:
+        raise RuntimeError("pd_pose_op failed (rc %d)" % rc)
+    return out
+
+
+def pose_op_vjp(op, a, b, g_out, need_a=True, need_b=True):
+    """``pd_pose_op_vjp``: (g_a, g_b) for the upstream gradient g_out; g_a is already summed when ``a`` was broadcast."""
+    n, bcast, no = _pose_n(op, a, b)
+    na = _POSE_DIMS[op][0]
+    g_a = torch.empty(b.shape[:-1] + (na,), device=b.device, dtype=torch.float32) if need_a else None
+    g_b = torch.empty_like(b) if need_b else None
+    null = ctypes.c_void_p(0)
+    rc = lib().pd_pose_op_vjp(op, n, _dev(a, "a"), int(bcast), _dev(b, "b"), _dev(g_out, "g_out", n * no),
+                              _dev(g_a, "g_a") if need_a else null, _dev(g_b, "g_b") if need_b else null, _stream())
+    if rc != 0:
+        raise RuntimeError("pd_pose_op_vjp failed (rc %d)" % rc)
+    if need_a:
+        g_a = g_a.reshape(-1, na).sum(0).reshape(a.shape) if bcast else g_a.reshape(a.shape)
+    return g_a, g_b
+
+
+def _dev_int(t, name):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise TypeError("%s must be a contiguous int32 GPU tensor" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def foot_height(body_q, c_body, c_point, c_dist):
+    """``pd_foot_height``: body_q (..., nb, 7) -> (height (...), arg-min candidate (...) int32)."""
+    nb = body_q.shape[-2]
+    n = body_q.numel() // (nb * 7)
+    h = torch.empty(body_q.shape[:-2], device=body_q.device, dtype=torch.float32)
+    arg = torch.empty(body_q.shape[:-2], device=body_q.device, dtype=torch.int32)
+    rc = lib().pd_foot_height(n, nb, c_body.numel(), _dev(body_q, "body_q"), _dev_int(c_body, "c_body"), _dev(c_point, "c_point", c_body.numel() * 3),
+                              _dev(c_dist, "c_dist", c_body.numel()), _dev(h, "height"), _dev_int(arg, "arg"), _stream())
+    if rc != 0:
+        raise RuntimeError("pd_foot_height failed (rc %d)" % rc)
+    return h, arg
+
+
+def foot_height_vjp(body_q, c_body, c_point, arg, g_h):
+    nb = body_q.shape[-2]
+    n = body_q.numel() // (nb * 7)
+    g = torch.empty_like(body_q)
+    rc = lib().pd_foot_height_vjp(n, nb, _dev(body_q, "body_q"), _dev_int(c_body, "c_body"), _dev(c_point, "c_point"), _dev_int(arg, "arg"),
+                                  _dev(g_h, "g_height", n), _dev(g, "g_body_q"), _stream())
+    if rc != 0:
+        raise RuntimeError("pd_foot_height_vjp failed (rc %d)" % rc)
+    return g
 
 
 def device_model(env):

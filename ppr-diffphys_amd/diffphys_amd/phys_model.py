@@ -27,6 +27,7 @@ from .dataloader import mocap_tensors, bullet2gl, parse_amp
 from .dp_model import ForwardKinematics, ForwardWarp, convert_ppr_warp
 from .dp_utils import compose_delta, reduce_loss, rotate_frame, rotate_frame_vel, se3_loss
 from .geom_utils import fid_reindex
+from .grad_guard import GradHistory
 from .time_mlp import TimeMLPWrapper, interp_wt, match_param_name
 
 
@@ -35,6 +36,24 @@ def get_local_rank():
         return int(os.environ["LOCAL_RANK"])
     except Exception:
         return 0
+
+
+class _FootHeightHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, body_q, c_body, c_point, c_dist):
+        from . import hip_backend
+
+        body_q = body_q.detach().contiguous()
+        h, arg = hip_backend.foot_height(body_q, c_body, c_point, c_dist)
+        ctx.save_for_backward(body_q, c_body, c_point, arg)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip_backend
+
+        body_q, c_body, c_point, arg = ctx.saved_tensors
+        return hip_backend.foot_height_vjp(body_q, c_body, c_point, arg, g.contiguous()), None, None, None
 
 
 class phys_model(nn.Module):
@@ -71,6 +90,7 @@ class phys_model(nn.Module):
         self.body_mass = nn.Parameter(torch.tensor(tpl["body_mass"], dtype=torch.float32))
         self.register_buffer("norm_body_inertia", torch.tensor(tpl["body_inertia"], dtype=torch.float32))
         self.register_buffer("c_body", torch.tensor(tpl["contact_body"], dtype=torch.long), persistent=False)
+        self.register_buffer("c_body_i32", torch.tensor(tpl["contact_body"], dtype=torch.int32), persistent=False)
         self.register_buffer("c_point", torch.tensor(tpl["contact_point"], dtype=torch.float32), persistent=False)
         self.register_buffer("c_dist", torch.tensor(tpl["contact_dist"], dtype=torch.float32), persistent=False)
 
@@ -79,7 +99,7 @@ class phys_model(nn.Module):
         self.init_global_q()
         self.add_optimizer(opts)
         self.model_cache, self.optimizer_cache, self.scheduler_cache = [None, None], [None, None], [None, None]
-        self.grad_queue = {}
+        self.grad_history = GradHistory(queue_length=10, scale_threshold=5.0)
 
     # ------------------------------------------------------------------ setup
     def preset_data(self, dataloader):
@@ -174,6 +194,12 @@ class phys_model(nn.Module):
                 kw["fused"] = True
             except Exception:
                 kw = {}
+        # the reference makes one parameter group per parameter; AdamW treats every parameter independently, so grouping the
+        # parameters by learning rate is the same update with 2 fused launches instead of 80 (params_ref_list keeps the names)
+        by_lr = {}
+        for g, lr in zip(params_list, lr_list):
+            by_lr.setdefault(lr, []).append(g["params"])
+        params_list, lr_list = [{"params": ps} for ps in by_lr.values()], list(by_lr.keys())
         self.optimizer = torch.optim.AdamW(params_list, lr=opts["phys_learning_rate"], weight_decay=1e-4, **kw)
         total_iters = max(2, self.total_iters)
         self.scheduler = torch.optim.lr_scheduler.OneCycleLR(
@@ -181,60 +207,50 @@ class phys_model(nn.Module):
             anneal_strategy="linear", final_div_factor=1e2, div_factor=25)
 
     def update(self):
-        if getattr(self, "_pending_loss", None) is not None:
-            bad, self._pending_loss = bool(self._pending_loss.isnan()), None
-            if bad:
-                raise FloatingPointError("total_loss is NaN")  # deferred from forward(), see there
-        grad_dict = self.check_grad()
+        grad_dict = self.check_grad()  # also raises on the NaN loss deferred from forward()
         self.optimizer.step()
         self.scheduler.step()
         self.optimizer.zero_grad()
         return grad_dict
 
     def check_grad(self, thresh=10.0):
-        """global-norm guard with rollback to the model cached two rounds ago, then per-parameter
-        median-based clipping (dp_model.py:936-1000)"""
-        params_list = [p for d in self.params_ref_list for p in d.values() if p.requires_grad and p.grad is not None]
+        """global-norm guard with rollback to the model cached two rounds ago, then per-parameter median-based clipping
+        (dp_model.py:936-1000).  Same decisions and values as the reference's per-parameter loop (grad_guard.GradHistory;
+        tests/test_host_plumbing.py compares them), with ONE host transfer per iteration -- the deferred NaN check of the
+        loss, the global norm and "is any parameter an outlier" travel together -- instead of one per parameter."""
+        named = [(name, p) for d in self.params_ref_list for name, p in d.items() if p.requires_grad and p.grad is not None]
+        pending, self._pending_loss = getattr(self, "_pending_loss", None), None
+        if not named:
+            if pending is not None and bool(pending.isnan()):
+                raise FloatingPointError("total_loss is NaN")
+            return {}
+        params_list = [p for _, p in named]
         grad_norm = torch.nn.utils.clip_grad_norm_(params_list, thresh)
-        if grad_norm > thresh:
+        plan = self.grad_history.plan([n for n, _ in named], [p.grad for p in params_list])  # norms AFTER the global clip, like the reference
+        zero = grad_norm.new_zeros(())
+        host = torch.stack([pending.isnan().to(grad_norm.dtype) if pending is not None else zero, grad_norm,
+                            plan["any_outlier"].to(grad_norm.dtype) if plan["any_outlier"] is not None else zero]).tolist()
+        if host[0] != 0:
+            raise FloatingPointError("total_loss is NaN")  # deferred from forward(), see there
+        if host[1] > thresh:
             self.optimizer.zero_grad()
             if get_local_rank() == 0:
-                print("large grad: %.2f, clear gradients" % grad_norm)
+                print("large grad: %.2f, clear gradients" % host[1])
             if self.model_cache[0] is not None:
                 self.load_state_dict(self.model_cache[0])
                 self.optimizer.load_state_dict(self.optimizer_cache[0])
                 self.scheduler.load_state_dict(self.scheduler_cache[0])
             return {}
-        grad_dict, queue_length, scale_threshold = {}, 10, 5.0
-        # per-parameter norms and queue medians first, ONE host transfer for all the "is it an outlier" decisions
-        # (the reference branches on a GPU scalar per parameter: one synchronisation each)
-        entries, meds = [], []
-        for d in self.params_ref_list:
-            ((name, p),) = d.items()
-            if not (p.requires_grad and p.grad is not None):
-                continue
-            grad = p.grad.reshape(-1).norm(2, -1)
-            grad_dict["grad/" + name] = grad
-            q = self.grad_queue.setdefault(name, [])
-            med = None
-            if len(q) > queue_length:
-                med = torch.stack(q[:-1]).median()
-                grad_dict["grad_med/" + name] = med
-                meds.append((len(entries), grad, med))
-            entries.append((name, p, grad, q, med))
-        outlier = {}
-        if meds:
-            flags = (torch.stack([g for _, g, _ in meds]) > scale_threshold * torch.stack([m for _, _, m in meds])).tolist()
-            outlier = {i: f for (i, _, _), f in zip(meds, flags)}
-        for i, (name, p, grad, q, med) in enumerate(entries):
-            if med is not None:
-                if outlier[i]:
-                    torch.nn.utils.clip_grad_norm_(p, med)
-                else:
-                    q.append(grad)
-                    q.pop(0)
-            else:
-                q.append(grad)
+        flags = self.grad_history.commit(plan, host[2] != 0)
+        grad_dict = {"grad/" + name: g for (name, _), g in zip(named, plan["norms"].unbind())}
+        if plan["med"] is not None:
+            for (name, _), m, has in zip(named, plan["med"].unbind(), plan["has_med"]):
+                if has:
+                    grad_dict["grad_med/" + name] = m
+        if get_local_rank() == 0:
+            for (name, _), f in zip(named, flags):
+                if f:
+                    print("large grad: %.2f, clear %s" % (float(grad_dict["grad/" + name]), name))
         return grad_dict
 
     def clear_grad(self):
@@ -300,7 +316,14 @@ class phys_model(nn.Module):
         return ref_ja, queried_q, queried_qd, torques.reshape(nstep, -1), res_f.reshape(nstep, -1, 6)  # quirk (ii)
 
     def get_foot_height(self, state_body_q):
-        """lowest ground-contact candidate per (env, frame); the reference poses the visual meshes instead"""
+        """lowest ground-contact candidate per (env, frame); the reference poses the visual meshes instead (dp_model.py:574-579).
+        float32 GPU poses: one HIP launch (``pd_foot_height``) and one for the gradient, which reaches the body of the
+        lowest candidate only -- the torch composition's gather over 3 838 candidates has a 3.3 ms index_put backward."""
+        if state_body_q.is_cuda and state_body_q.dtype == torch.float32:
+            return _FootHeightHip.apply(state_body_q, self.c_body_i32, self.c_point, self.c_dist)
+        return self.get_foot_height_torch(state_body_q)
+
+    def get_foot_height_torch(self, state_body_q):
         X = state_body_q[..., self.c_body, :]
         q, p = X[..., 3:], X[..., :3]
         qv, w = q[..., :3], q[..., 3:]

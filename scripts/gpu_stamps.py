@@ -22,6 +22,7 @@ nblk = (bs * segw // 64 + 3) // 4
 dbg = torch.zeros((nblk * 12 + 64) * 16, dtype=torch.int64, device=dev)
 L = hip_backend.lib()
 L.pd_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
+L.pd_debug_set_groups(4)  # the role-by-row mapping below assumes 4 env groups per workgroup
 for it in range(2):
     out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=f2s)
 torch.cuda.synchronize()

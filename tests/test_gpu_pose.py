@@ -1,0 +1,146 @@
+"""GPU tests of the pose-algebra kernels (C ABI pd_pose_op / pd_pose_op_vjp / pd_foot_height)
+against the torch compositions they replace (diffphys_amd.dp_utils.*_torch, written after the reference's
+diffphys/dp_utils.py:22-31,60-84 and diffphys/geom_utils.py:148-203) -- values in float32 and float64, gradients against
+torch autograd of the float64 composition."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _poses(rng, n, special=True):
+    """(n, 7) poses with un-normalised quaternions; with `special`, the first rows are rotations by ~pi about x / y / z and
+    about a diagonal (each of the four matrix->quaternion candidates is the best-conditioned one somewhere) and identity."""
+    q = rng.randn(n, 4)
+    q *= (0.5 + rng.rand(n, 1))  # |q| != 1, like linearly interpolated mocap rows
+    if special:
+        eps = 1e-3
+        q[0] = [1, eps, -eps, eps]; q[1] = [eps, 1, eps, -eps]; q[2] = [-eps, eps, 1, eps]; q[3] = [0.7, 0.7, 0.1, 1e-4]
+        q[4] = [0, 0, 0, 1]; q[5] = [0, 0, 0, -2.0]; q[6] = [0.5, 0.5, 0.5, 0.5]
+    return np.concatenate([rng.randn(n, 3), q], 1)
+
+
+def _deltas(rng, n):
+    d = np.concatenate([rng.randn(n, 3) * 0.1, rng.randn(n, 3) * 0.5], 1)
+    d[0, 3:] = 0.0                      # zero rotation: the series branch, zero subgradient of the norm
+    d[1, 3:] = [3e-7, -2e-7, 1e-7]      # below the 1e-6 switch
+    d[2, 3:] = [np.pi - 1e-3, 0, 0]     # almost a half turn
+    d[3, 3:] = [2.0, -2.0, 1.5]         # more than pi
+    return d
+
+
+def _check(op_hip, op_torch, a64, b64, dev, grad_a=True, grad_b=True, tol=3e-6):
+    a32 = torch.tensor(a64, dtype=torch.float32, device=dev, requires_grad=grad_a)
+    b32 = torch.tensor(b64, dtype=torch.float32, device=dev, requires_grad=grad_b)
+    out = op_hip(a32, b32)
+    # float64 torch composition evaluated at the float32 inputs
+    ad = a32.detach().double().cpu().requires_grad_(grad_a)
+    bd = b32.detach().double().cpu().requires_grad_(grad_b)
+    ref = op_torch(ad, bd)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    err = (out.detach().double().cpu() - ref.detach()).abs().max().item()
+    assert err < tol * max(1.0, ref.detach().abs().max().item()), err
+    # the float32 torch composition on the GPU is no closer to float64 than the kernel is (up to a factor)
+    t32 = op_torch(a32.detach(), b32.detach())
+    err32 = (t32.double().cpu() - ref.detach()).abs().max().item()
+    assert err <= 4 * err32 + 1e-6, (err, err32)
+    g = torch.tensor(np.random.RandomState(5).randn(*ref.shape), dtype=torch.float64)
+    out.backward(g.float().to(dev))
+    ref.backward(g)
+    for x32, xd, need in ((a32, ad, grad_a), (b32, bd, grad_b)):
+        if need:
+            ge = (x32.grad.double().cpu() - xd.grad).abs().max().item()
+            assert ge < 2e-5 * max(1.0, xd.grad.abs().max().item()), ge
+    return err
+
+
+def test_compose_delta_matches_the_torch_composition(dev):
+    from diffphys_amd import dp_utils
+
+    rng = np.random.RandomState(0)
+    n = 4096
+    tq, dl = _poses(rng, n), _deltas(rng, n)
+    _check(dp_utils.compose_delta, dp_utils.compose_delta_torch, tq, dl, dev)
+    # (bs, T, .) operands as phys_model passes them, and no gradient needed for the target
+    _check(dp_utils.compose_delta, dp_utils.compose_delta_torch, tq.reshape(64, 64, 7), dl.reshape(64, 64, 6), dev, grad_a=False)
+
+
+def test_rotate_frame_and_rotate_frame_vel_match_the_torch_compositions(dev):
+    from diffphys_amd import dp_utils
+
+    rng = np.random.RandomState(1)
+    tq = _poses(rng, 64 * 50).reshape(64, 50, 7)
+    qd = rng.randn(64, 50, 6)
+    for gq in ([0.0, -0.3, 0.1, 0.0, 0.0, 0.0, 1.0], [0.2, 0.1, -0.4, 0.3, -0.5, 0.2, 0.9], [0.0, 0.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3]):
+        gq = np.asarray(gq)
+        _check(dp_utils.rotate_frame, dp_utils.rotate_frame_torch, gq, tq, dev)
+        _check(dp_utils.rotate_frame, dp_utils.rotate_frame_torch, gq, tq, dev, grad_b=False)  # as in phys_model: mocap rows need no gradient
+        _check(dp_utils.rotate_frame_vel, dp_utils.rotate_frame_vel_torch, gq, qd, dev)
+        _check(dp_utils.rotate_frame_vel, dp_utils.rotate_frame_vel_torch, gq, qd, dev, grad_b=False)
+
+
+def test_pose_ops_reject_bad_operands(dev):
+    from diffphys_amd import hip_backend
+
+    a = torch.zeros(8, 7, device=dev)
+    with pytest.raises(ValueError):
+        hip_backend.pose_op(hip_backend.POSE_COMPOSE_DELTA, a, torch.zeros(8, 7, device=dev))  # delta must be 6 wide
+    with pytest.raises(ValueError):
+        hip_backend.pose_op(hip_backend.POSE_ROTATE_FRAME, torch.zeros(3, 7, device=dev), a)   # 3 globals against 8 targets
+    with pytest.raises(TypeError):
+        hip_backend.pose_op(hip_backend.POSE_ROTATE_FRAME, a.double(), a)
+    with pytest.raises(ValueError):
+        hip_backend.pose_op(hip_backend.POSE_ROTATE_FRAME, a.cpu(), a)
+    out = hip_backend.pose_op(hip_backend.POSE_ROTATE_VEL, torch.tensor([0, 0, 0, 0, 0, 0, 1.0], device=dev), torch.zeros(0, 6, device=dev))
+    assert out.shape == (0, 6)
+
+
+def test_foot_height_matches_the_torch_gather(dev):
+    """pd_foot_height against phys_model.get_foot_height_torch's formula: same heights, the same arg-min candidate wherever the
+    minimum is not (nearly) tied, and the gradient torch.min routes to that candidate's body."""
+    from diffphys_amd import hip_backend, robots
+
+    tpl = robots.load_template("laikago")
+    c_body = torch.tensor(tpl["contact_body"], dtype=torch.long, device=dev)
+    c_point = torch.tensor(tpl["contact_point"], dtype=torch.float32, device=dev)
+    c_dist = torch.tensor(tpl["contact_dist"], dtype=torch.float32, device=dev)
+    rng = np.random.RandomState(2)
+    nb = int(tpl["nb"])
+    X = np.concatenate([rng.randn(32, 4, nb, 3) * 0.3, rng.randn(32, 4, nb, 4)], -1)
+    X[..., 3:] /= np.linalg.norm(X[..., 3:], axis=-1, keepdims=True)
+    x_hip = torch.tensor(X, dtype=torch.float32, device=dev, requires_grad=True)
+    x_ref = x_hip.detach().clone().requires_grad_(True)
+
+    def torch_height(state_body_q):
+        Xc = state_body_q[..., c_body, :]
+        q, p = Xc[..., 3:], Xc[..., :3]
+        qv, w = q[..., :3], q[..., 3:]
+        pt = c_point.expand(qv.shape)
+        rot = pt * (2 * w * w - 1) + 2 * w * torch.cross(qv, pt, dim=-1) + 2 * qv * (qv * pt).sum(-1, keepdim=True)
+        return (p[..., 1] + rot[..., 1] - c_dist).min(-1)
+
+    h_ref, arg_ref = torch_height(x_ref)
+    from diffphys_amd.phys_model import _FootHeightHip
+    h = _FootHeightHip.apply(x_hip, c_body.int(), c_point, c_dist)
+    assert h.shape == (32, 4) and torch.allclose(h, h_ref, rtol=0, atol=2e-6)
+    _, arg = hip_backend.foot_height(x_hip.detach(), c_body.int(), c_point, c_dist)
+    assert (arg.long() == arg_ref).float().mean().item() > 0.95  # ties / 1-ulp near-ties may pick a neighbour
+    g = torch.tensor(rng.randn(32, 4), dtype=torch.float32, device=dev)
+    h.backward(g)
+    h_ref.backward(g)
+    same = (arg.long() == arg_ref)[..., None, None].expand_as(x_ref.grad)
+    assert torch.allclose(x_hip.grad[same], x_ref.grad[same], rtol=1e-5, atol=1e-6)
+    assert ((x_hip.grad != 0).any(-1).sum(-1) == 1).all()  # exactly one body per pose set receives a gradient
+    # a NaN pose propagates like torch.min
+    bad = x_hip.detach().clone()
+    bad[3, 1, 5, 4] = float("nan")
+    hb, _ = hip_backend.foot_height(bad, c_body.int(), c_point, c_dist)
+    assert torch.isnan(hb[3, 1]) and not torch.isnan(hb).sum().item() > 1

@@ -126,12 +126,12 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(pd_[A-Za-z0-9_]+)\s*\(", hdr)))
-    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and len(names) == 16
+    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and len(names) == 20
     lib = hip_backend.lib()
     for n in names:
         assert hasattr(lib, n), "missing symbol " + n
-    assert lib.pd_abi_version() == 2 == hip_backend.ABI_VERSION
-    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == 2
+    assert lib.pd_abi_version() == 3 == hip_backend.ABI_VERSION
+    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == 3
     lib.pd_rollout_workspace_floats.restype = ctypes.c_size_t
     assert lib.pd_rollout_workspace_floats(None, 4, 10) == 0
 
@@ -148,6 +148,12 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert "null model" in err()
     assert lib.pd_rollout_backward(None, 1, 1, ctypes.c_float(5e-4), *([None] * 9), 2, f2s, *([None] * 13), None) != 0
     assert lib.pd_fk_forward(None, 1, None, None, None, None, None) != 0 and "null model" in err()
+    # pose algebra / foot height: bad op, negative count, null operands are refused before any launch; n = 0 is a no-op
+    assert lib.pd_pose_op(7, 1, None, 0, None, None, None) != 0 and lib.pd_pose_op(0, -1, None, 0, None, None, None) != 0
+    assert lib.pd_pose_op(0, 4, None, 0, None, None, None) != 0 and lib.pd_pose_op(0, 0, None, 0, None, None, None) == 0
+    assert lib.pd_pose_op_vjp(1, 4, None, 1, None, None, None, None, None) != 0 and lib.pd_pose_op_vjp(1, 0, None, 1, None, None, None, None, None) == 0
+    assert lib.pd_foot_height(4, 13, 0, *([None] * 7)) != 0 and lib.pd_foot_height(4, 13, 8, *([None] * 7)) != 0 and lib.pd_foot_height(0, 13, 8, *([None] * 7)) == 0
+    assert lib.pd_foot_height_vjp(4, 13, *([None] * 7)) != 0 and lib.pd_foot_height_vjp(0, 13, *([None] * 7)) == 0
     assert lib.pd_model_bind_joint_X_p(None, None, 0) != 0
     assert lib.pd_model_set_timing(None, 1) != 0
     assert lib.pd_last_kernel_ms(None, 0) < 0

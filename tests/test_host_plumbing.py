@@ -110,3 +110,55 @@ def test_device_side_mocap_query_matches_the_numpy_pipeline():
     for k in ref:
         assert got[k].dtype == torch.float32 and tuple(got[k].shape) == ref[k].shape
         assert np.abs(got[k].numpy() - ref[k].astype(np.float32)).max() <= 1e-6 * max(1.0, np.abs(ref[k]).max()), k
+
+
+def test_batched_gradient_history_matches_the_reference_loop():
+    """grad_guard.GradHistory (one device tensor, one host transfer per iteration) against the reference's per-parameter
+    lists (dp_model.py:965-1000 restated as a loop): same histories, same outlier decisions, same clipped gradients --
+    with outliers injected, with a parameter that has no gradient in some iterations, and with one that appears late."""
+    from diffphys_amd.grad_guard import GradHistory
+
+    torch.manual_seed(0)
+    shapes = [(3,), (4, 5), (7,), (2, 2, 2), (11,), (6,)]
+    names = ["p%d" % i for i in range(len(shapes))]
+    hist, queues = GradHistory(queue_length=10, scale_threshold=5.0), {}
+    n_out = 0
+    for it in range(60):
+        active = [i for i in range(len(shapes)) if not (i == 2 and it % 7 == 3) and not (i == 5 and it < 9)]
+        grads = [torch.randn(shapes[i]) * (0.5 + 0.1 * i) for i in active]
+        if it in (25, 31, 32, 50):
+            grads[it % len(grads)] *= 40.0  # an outlier
+        ref = [g.clone() for g in grads]
+        # reference loop
+        ref_flags = []
+        for k, i in enumerate(active):
+            g = ref[k]
+            norm = g.reshape(-1).norm(2, -1)
+            q = queues.setdefault(names[i], [])
+            flag = False
+            if len(q) > 10:
+                med = torch.stack(q[:-1]).median()
+                if norm > 5.0 * med:
+                    g.mul_((med / (norm + 1e-6)).clamp(max=1.0))
+                    flag = True
+                else:
+                    q.append(norm); q.pop(0)
+            else:
+                q.append(norm)
+            ref_flags.append(flag)
+        # batched
+        plan = hist.plan([names[i] for i in active], grads)
+        any_out = plan["any_outlier"] is not None and bool(plan["any_outlier"] != 0)
+        flags = hist.commit(plan, any_out)
+        assert flags == ref_flags, it
+        n_out += sum(flags)
+        for a, b in zip(grads, ref):
+            assert torch.allclose(a, b, rtol=1e-6, atol=0)
+        for i in range(len(shapes)):
+            if names[i] in queues:
+                assert np.allclose(hist.history(names[i]), [float(x) for x in queues[names[i]]], rtol=1e-6), (it, i)
+    assert n_out >= 3
+    # plan() alone does not touch the histories (the global-norm guard returns before they are updated)
+    before = hist.Q.clone(), list(hist.fill)
+    hist.plan(names, [torch.randn(s) for s in shapes])
+    assert torch.equal(hist.Q, before[0]) and hist.fill == before[1]
