@@ -12,7 +12,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     Either way every rank builds ITS slice of one global batch (per-env seeded: the slices concatenate to the
     same global batch for any N), envs are independent, and there is no collective on the data path
   * inputs are resident in HBM before the timed region; timed region is bracketed by barrier + synchronize
-  * rank 0 prints ONE JSON line (value = whole-job env-steps/s, max time over ranks)
+  * rank 0 prints ONE JSON line (value = whole-job env-steps/s, max time over ranks); for N > 1 the line also carries
+    "other_scaling": the same measurement in the other mode (so one scaling run holds the strong AND the weak row)
 
 Extra objects on the line:
   roofline     dominant kernel (the adjoint rollout): algorithmic HBM bytes per launch / its average launch
@@ -120,6 +121,7 @@ def main():
     ap.add_argument("--robot", default="laikago")
     ap.add_argument("--segw", type=int, default=0, help="lanes per articulation (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--both", action="store_true", help="also measure the other scaling mode at N = 1 (always done for N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,46 +152,57 @@ def main():
     tpl = robots.load_template(args.robot)
     seqs = ("mi-trot", "mi-spin") if args.robot == "laikago" else ("mi-pace",)
     T = args.T
-    inp, (lo, hi), gbs = rank_inputs(tpl, args.robot, T, world, rank, args.scaling, args.bs, seqs)
-    bs = hi - lo
     dm = hip_backend.DeviceModel(tpl)
     if args.segw:
         dm.set_segment_width(args.segw)
-    t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
-    f2s = inp["frame2step"]
-    fwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass",
-                               "body_inertia", "body_inv_inertia")]
-    bwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "refs", "target_ke", "target_kd", "body_inv_mass",
-                               "body_inertia", "body_inv_inertia")]
-    adj_pos = torch.from_numpy(inp["adj_pos"]).to(dev)
-    adj_vel = torch.from_numpy(inp["adj_vel"]).to(dev)
-    # workspace, frame outputs and gradient buffers live outside the timed loop (the autograd boundary allocates them per
-    # call through torch's caching allocator; the bench times the two launches, not the allocator)
-    bufs = dm.alloc_rollout(bs, T, len(f2s), dev)
-
-    def step():
-        out = dm.rollout_forward(bs, T, inp["dt"], *fwd_args, frame2step=f2s, out=bufs)
-        return dm.rollout_backward(bs, T, inp["dt"], *bwd_args, f2s, out[4], adj_pos, adj_vel, out=bufs)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def setup(scaling):
+        """this rank's slice of the global batch, resident in HBM, and the step closure over it"""
+        inp, (lo, hi), gbs = rank_inputs(tpl, args.robot, T, world, rank, scaling, args.bs, seqs)
+        bs = hi - lo
+        t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
+        f2s = inp["frame2step"]
+        fwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass",
+                                   "body_inertia", "body_inv_inertia")]
+        bwd_args = [t[k] for k in ("q_init", "qd_init", "torques", "refs", "target_ke", "target_kd", "body_inv_mass",
+                                   "body_inertia", "body_inv_inertia")]
+        adj_pos = torch.from_numpy(inp["adj_pos"]).to(dev)
+        adj_vel = torch.from_numpy(inp["adj_vel"]).to(dev)
+        # workspace, frame outputs and gradient buffers live outside the timed loop (the autograd boundary allocates them per
+        # call through torch's caching allocator; the bench times the two launches, not the allocator)
+        bufs = dm.alloc_rollout(bs, T, len(f2s), dev)
+
+        def step():
+            out = dm.rollout_forward(bs, T, inp["dt"], *fwd_args, frame2step=f2s, out=bufs)
+            return dm.rollout_backward(bs, T, inp["dt"], *bwd_args, f2s, out[4], adj_pos, adj_vel, out=bufs)
+
+        return step, bs, gbs
+
+    def timed(step):
+        """W untimed steps, then exactly K steps between barrier + synchronize brackets; MAX over ranks"""
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g = step()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, g
+
+    step, bs, gbs = setup(args.scaling)
+    elapsed, g = timed(step)
     bad = int(torch.isnan(g["q_init"]).sum().item())
 
     # per-kernel device time (HIP events on the launch stream), in an extra pass outside the timed region
@@ -202,6 +215,16 @@ def main():
         kb.append(dm.last_kernel_ms(1))
     dm.set_timing(False)
     fwd_ms, bwd_ms = float(np.mean(kf)), float(np.mean(kb))
+
+    # N > 1: the same measurement in the OTHER scaling mode, reported beside the main one (SURVEY section 8(d) writes C4 as
+    # one 4096-env batch split over the GPUs = strong; the driver's contract quotes weak).  At N = 1 the two coincide.
+    other = None
+    if world > 1 or args.both:
+        o_mode = "strong" if args.scaling == "weak" else "weak"
+        o_step, o_bs, o_gbs = setup(o_mode)
+        o_elapsed, _ = timed(o_step)
+        other = {"scaling": o_mode, "value": o_gbs * T * args.steps / o_elapsed, "unit": "env-steps/s", "ms_per_step": o_elapsed / args.steps * 1e3,
+                 "global_batch": o_gbs, "envs_per_gpu": o_bs}
 
     if rank == 0:
         nb, nqd = int(tpl["nb"]), int(tpl["nqd"])
@@ -276,6 +299,8 @@ def main():
                 "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4)",
             },
         }
+        if other is not None:
+            line["other_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tpl, args.robot, T, seqs)
         print(json.dumps(line))
