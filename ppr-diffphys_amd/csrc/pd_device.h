@@ -483,9 +483,11 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
     P.q_w = qmul(j.q_p, c.q_off);
     const v3 ax[3] = {ax0, P.ax1, P.ax2};
     P.t_raw = V3(0, 0, 0);
+    float Mw[9];
+    rotm(P.q_w, Mw);  // one quaternion rotates the three axes (pd_math.h)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      P.axw[k] = qrot(P.q_w, ax[k]); P.qdk[k] = dot(P.axw[k], j.w_err);
+      P.axw[k] = mat_vec(Mw, ax[k]); P.qdk[k] = dot(P.axw[k], j.w_err);
       const JointLimit L = c.lim[k];
       P.jf[k] = joint_force(P.ang[k], P.qdk[k], tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
       P.t_raw += P.axw[k] * P.jf[k];
@@ -560,6 +562,10 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     float adj_ang[3] = {0.f, 0.f, 0.f};
     v3 adj_ax[3] = {V3(0, 0, 0), V3(0, 0, 0), V3(0, 0, 0)};
     qt adj_q_w = Q4(0, 0, 0, 0);
+    float Mw[9], aW[9];  // rotm(q_w) and its matrix adjoint: axw[k] = Mw ax[k]
+    rotm(P.q_w, Mw);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aW[k] = 0.f;
 #pragma unroll
     for (int k = 2; k >= 0; --k) {
       float adj_jf = dot(adj_t_raw, P.axw[k]);
@@ -570,8 +576,10 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
       joint_force_adj(P.ang[k], P.qdk[k], tgt[k], ke[k], kd[k], L.lo, L.up, L.ke, L.kd, adj_jf, adj_ang[k], adj_qdk, a_tgt[k], a_ke[k],
                       a_kd[k], a_act[k]);
       adj_axw += j.w_err * adj_qdk; adj_w_err += P.axw[k] * adj_qdk;
-      adj_qrot(P.q_w, ax[k], adj_q_w, adj_ax[k], adj_axw);
+      adj_ax[k] += matT_vec(Mw, adj_axw);
+      add_outer(aW, adj_axw, ax[k]);
     }
+    rotm_adj(P.q_w, aW, adj_q_w);
     adj_qmul_a(c.q_off, adj_q_p, adj_q_w);
     qt adj_q10 = Q4(0, 0, 0, 0), adj_q_1 = adj_q10, adj_q_0 = adj_q10;
     adj_qrot_q(P.q10, V3(0, 0, 1), adj_q10, adj_ax[2]);
@@ -598,8 +606,12 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
   if (c.parent >= 0) {
     v3 adj_x_p = adj_r_p - adj_x_err;
     par.p = adj_x_p - adj_r_p;                           // x_p = pp + ..., r_p = x_p - (pp + rc_par)
-    adj_qrot_q(j.qp, c.com_par, par.r, -adj_r_p);
-    adj_qrot_q(j.qp, c.p_pj, par.r, adj_x_p);
+    float aP[9];  // matrix adjoint of rotm(qp): rc_par = rotm(qp) com_par, x_p = pp + rotm(qp) p_pj
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aP[k] = 0.f;
+    add_outer(aP, -adj_r_p, c.com_par);
+    add_outer(aP, adj_x_p, c.p_pj);
+    rotm_adj(j.qp, aP, par.r);
     adj_qmul_a(c.q_pj, par.r, adj_q_p);
     par.w = -adj_w_err; par.v = -adj_v_err;
   }
@@ -667,7 +679,7 @@ PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 
 // Parent quantities are passed explicitly (pp, qp, w_p, v_p, rc_par = rot(qp, com_par); ignored for a joint to the world).
 PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, v3 pp, qt qp, v3 w_p, v3 v_p, v3 rc_par,
                              const RevCache &R, float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par,
-                             float &a_tgt, float &a_act, float &a_ke, float &a_kd) {
+                             float *aR, float &a_tgt, float &a_act, float &a_ke, float &a_kd) {  // aR: matrix adjoint of rotm(s.r), see integrate_adj2
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 r_p = V3(0, 0, 0);
   if (c.parent >= 0) {
@@ -702,27 +714,31 @@ PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const Body
   adj_r_err.x += c.axis.x * adj_da; adj_r_err.y += c.axis.y * adj_da; adj_r_err.z += c.axis.z * adj_da;
   adj_r_err.w += adj_tq.w;
   adj_qrot_q(R.q_p, c.axis, adj_q_p, adj_axis_p);
-  adj_qrot_q(s.r, c.axis, adj_q_c, adj_axis_c);
+  add_outer(aR, adj_axis_c, c.axis);  // axis_c = rotm(s.r) axis
   {  // r_err = conj(q_p) * q_c
     qt adj_cqp = Q4(0, 0, 0, 0);
     adj_qmul(qconj(R.q_p), s.r, adj_cqp, adj_q_c, adj_r_err);
     adj_q_p += qconj(adj_cqp);
   }
-  adj_qrot_q(s.r, c.com, adj_q_c, -adj_r_c);
+  add_outer(aR, -adj_r_c, c.com);     // rc_c = rotm(s.r) com
   own.p += adj_x_err; own.r += adj_q_c; own.w += adj_w_err; own.v += adj_v_err;
   par = adj_zero();
   if (c.parent >= 0) {
     v3 adj_x_p = adj_r_p - adj_x_err;
     par.p = adj_x_p - adj_r_p;
-    adj_qrot_q(qp, c.com_par, par.r, -adj_r_p);
-    adj_qrot_q(qp, c.p_pj, par.r, adj_x_p);
+    float aP[9];  // matrix adjoint of rotm(qp): rc_par = rotm(qp) com_par, x_p = pp + rotm(qp) p_pj
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aP[k] = 0.f;
+    add_outer(aP, -adj_r_p, c.com_par);
+    add_outer(aP, adj_x_p, c.p_pj);
+    rotm_adj(qp, aP, par.r);
     adj_qmul_a(c.q_pj, par.r, adj_q_p);
     par.w = -adj_w_err; par.v = -adj_v_err;
   }
 }
 
 PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const RevCache &R,
-                        float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par, float &a_tgt,
+                        float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par, float *aR, float &a_tgt,
                         float &a_act, float &a_ke, float &a_kd) {
   v3 pp = V3(0, 0, 0), w_p = pp, v_p = pp, rc_par = pp;
   qt qp = Q4(0, 0, 0, 1);
@@ -730,7 +746,7 @@ PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState
     const float *r = rec + c.parent * PD_REC;
     pp = ld3(r); qp = ld4(r + 3); w_p = ld3(r + 7); v_p = ld3(r + 10); rc_par = ld3(r + 13);
   }
-  rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+  rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt, a_act, a_ke, a_kd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -773,17 +789,20 @@ PD_DEV void add_outer(LdsAcc9 M, v3 a, v3 b) {
   for (int k = 0; k < 9; ++k) M.p[k] = t[k];
 }
 template <typename ACC, typename F>
-PD_DEV void integrate_adj2(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m, const float *I,
-                           const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, float &g_inv_m, ACC g_I, ACC g_invI,
-                           F &&wrench_ready) {
+PD_DEV void integrate_adj2(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *Rm, v3 t0, v3 f0, float inv_m,
+                           const float *I, const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, float *aR, float &g_inv_m, ACC g_I,
+                           ACC g_invI, F &&wrench_ready) {
+  // Rm = rotm(s.r): the six rotations by the body's own quaternion are matrix products, and their quaternion adjoints are
+  // accumulated as ONE matrix adjoint in aR (+=), which the caller converts once with rotm_adj(s.r, aR, ...) -- after the
+  // joint adjoint has added its own rotations by s.r where that runs on the same wave (pd_math.h)
   v3 g = V3(m.gx, m.gy, m.gz);
   float nz = inv_m != 0.0f ? 1.0f : 0.0f;
   v3 v1 = s.v + (f0 * inv_m + g * nz) * dt;
-  v3 wb = qrot_inv(s.r, s.w);
+  v3 wb = matT_vec(Rm, s.w);
   v3 Iwb = mat_vec(I, wb);
-  v3 tb = qrot_inv(s.r, t0) - cross(wb, Iwb);
+  v3 tb = matT_vec(Rm, t0) - cross(wb, Iwb);
   v3 u = wb + mat_vec(invI, tb) * dt;
-  v3 w1 = qrot(s.r, u);
+  v3 w1 = mat_vec(Rm, u);
   qt W = Q4(w1.x, w1.y, w1.z, 0.f);
   qt rq = s.r + qmul(W, s.r) * (0.5f * dt);
   qt r1 = qnormalize(rq);
@@ -799,34 +818,32 @@ PD_DEV void integrate_adj2(const PdDevModel &m, const BodyConst &c, const BodySt
   qt adj_W = Q4(0, 0, 0, 0);
   adj_qmul_a(s.r, adj_W, gW);
   adj_w1 += qvec(adj_W);
-  v3 adj_u = V3(0, 0, 0);
-  adj_u += qrot_inv(s.r, adj_w1);
+  const v3 adj_u = matT_vec(Rm, adj_w1);
   v3 adj_wb = adj_u, adj_a = adj_u * dt;
   v3 adj_tb = matT_vec(invI, adj_a);
-  v3 adj_t0 = V3(0, 0, 0);
-  adj_t0 += qrot(s.r, adj_tb);
+  const v3 adj_t0 = mat_vec(Rm, adj_tb);
   adj_v1 += gn.p * dt;
   const v3 adj_f0 = adj_v1 * (inv_m * dt);
   wrench_ready(adj_t0, adj_f0);
   // ---- phase 2
   qt adj_r0 = adj_rq;
   adj_qmul_b(W, adj_r0, gW);
-  adj_qrot_q(s.r, u, adj_r0, adj_w1);
+  add_outer(aR, adj_w1, u);    // w1 = Rm u
   add_outer(g_invI, adj_a, tb);
-  adj_qrot_inv_q(s.r, t0, adj_r0, adj_tb);
+  add_outer(aR, t0, adj_tb);   // Rm^T t0
   v3 adj_Iwb = V3(0, 0, 0);
   adj_cross(wb, Iwb, adj_wb, adj_Iwb, -adj_tb);
   add_outer(g_I, adj_Iwb, wb);
   adj_wb += matT_vec(I, adj_Iwb);
-  v3 adj_w0 = V3(0, 0, 0);
-  adj_qrot_inv(s.r, s.w, adj_r0, adj_w0, adj_wb);
+  const v3 adj_w0 = mat_vec(Rm, adj_wb);
+  add_outer(aR, s.w, adj_wb);  // wb = Rm^T w
   g_inv_m += dot(adj_v1, f0) * dt;
-  adj_qrot_q(s.r, c.com, adj_r0, gn.p);
+  add_outer(aR, gn.p, c.com);  // x_com = p + Rm com
   a.p = gn.p; a.r = adj_r0; a.w = adj_w0; a.v = adj_v1;
 }
 
-PD_DEV void integrate_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 t0, v3 f0, float inv_m,
-                          const float *I, const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, v3 &adj_t0, v3 &adj_f0,
+PD_DEV void integrate_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *Rm, v3 t0, v3 f0, float inv_m,
+                          const float *I, const float *invI, float dt, const BodyAdj &gn, BodyAdj &a, float *aR, v3 &adj_t0, v3 &adj_f0,
                           float &g_inv_m, float *g_I, float *g_invI) {
-  integrate_adj2(m, c, s, t0, f0, inv_m, I, invI, dt, gn, a, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) { adj_t0 = t; adj_f0 = f; });
+  integrate_adj2(m, c, s, Rm, t0, f0, inv_m, I, invI, dt, gn, a, aR, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) { adj_t0 = t; adj_f0 = f; });
 }

@@ -1002,14 +1002,19 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     // unsplit kernels replay the forward hit list inline further down: fetch its length now, far ahead of its use
     int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
     const int log_cnt = (!SPLIT && env_ok) ? lg[0] : 0;
-    const v3 rc = qrot(s.r, c.com);
+    float Rm[9];
+    rotm(s.r, Rm);  // the body's rotation as a matrix: shared by the staging and the adjoint of integrate_bodies
+    const v3 rc = mat_vec(Rm, c.com);
     if (is_body) stage_record(rec, cull, b, s, rc);
     STAMP(0);
     // ---- adjoint of integrate_bodies
     BodyAdj ga = adj_zero();
     v3 adj_t0 = V3(0, 0, 0), adj_f0 = adj_t0;
+    float aR[9];  // matrix adjoint of Rm, summed over integrate_bodies and (revolute, split) the joint; converted after both
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aR[k] = 0.f;
     if (SPLIT && EARLY) {
-      integrate_adj2(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) {
+      integrate_adj2(m, c, s, Rm, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) {
         adj_t0 = t; adj_f0 = f;
         if (is_body) {
           float *o = adjf + b * PD_W6;
@@ -1025,7 +1030,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       STAMP(1);
       pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
     } else {
-    integrate_adj(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
+    integrate_adj(m, c, s, Rm, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
     if (is_body) {
       float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
       stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
@@ -1050,11 +1055,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
       if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
       if (SPLIT)  // revolute only: the state-only half was computed by the contact wave
-        rev_adjoint(m, c, s, rc, rec, rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC), tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt[0],
-                    a_act[0], a_ke[0], a_kd[0]);
+        rev_adjoint(m, c, s, rc, rec, rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC), tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, aR,
+                    a_tgt[0], a_act[0], a_ke[0], a_kd[0]);
       else
         joint_adj<JT>(m, c, s, rc, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
     }
+    rotm_adj(s.r, aR, ga.r);
     if (is_body) {
       adj_store(cslot + b * PD_ADJ, par);
 #pragma unroll
@@ -1394,8 +1400,12 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
           BodyState s;
           s.p = ld3(r); s.r = q_c; s.w = w_c; s.v = ld3(r + 10);
           const v3 rc_c = ld3(r + 13), v_p = ld3(prec + 10), rc_par = ld3(prec + 13);
-          rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke[0], kd[0], gc_t, gc_f, gp_t, gp_f, own, par, a_tgt[0], a_act[0],
+          float aR[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) aR[k] = 0.f;
+          rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke[0], kd[0], gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt[0], a_act[0],
                            a_ke[0], a_kd[0]);
+          rotm_adj(s.r, aR, own.r);
         }
         if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
         STAMP(10);
@@ -1525,7 +1535,9 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w); f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
     fr = n_fr;
     select_step(step);
-    const v3 rc = qrot(s.r, c.com);
+    float Rm[9];
+    rotm(s.r, Rm);  // the body's rotation as a matrix: shared by the staging and the adjoint of integrate_bodies
+    const v3 rc = mat_vec(Rm, c.com);
     if (is_body) stage_record(rec, cull, b, s, rc);
     if (JT != PD_JT_REVOLUTE) pair_signal(sig + 3, a.nsteps - step);  // S
   };
@@ -1545,7 +1557,12 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     // ---- adjoint of integrate_bodies; hand-over A as soon as the wrench adjoint exists
     BodyAdj ga = adj_zero();
     v3 adj_t0 = V3(0, 0, 0), adj_f0 = adj_t0;
-    integrate_adj2(m, c, s, t0, f0, inv_m, I, invI, a.dt, gn, ga, g_inv_m, LdsAcc9{ga_lds}, LdsAcc9{ga_lds + 9}, [&](v3 t, v3 f) {
+    float Rm[9];
+    rotm(s.r, Rm);  // (recomputed rather than carried from stage_step: nine registers across the loop cost more than 22 instructions)
+    float aR[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aR[k] = 0.f;
+    integrate_adj2(m, c, s, Rm, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, LdsAcc9{ga_lds}, LdsAcc9{ga_lds + 9}, [&](v3 t, v3 f) {
       adj_t0 = t; adj_f0 = f;
       if (is_body) {
         float *o = adjf + b * PD_W6;
@@ -1556,6 +1573,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       // (plus the contacts) covers the HBM latency before stage_step consumes it
       load_step(step - 1);
     });
+    rotm_adj(s.r, aR, ga.r);
     if (is_body) {
       float *o = a.g_res_f + (size_t)__builtin_amdgcn_readfirstlane(step) * N * 6;  // adjoint of wp_add
       stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
