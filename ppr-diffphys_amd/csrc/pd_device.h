@@ -374,10 +374,15 @@ struct JointCtx {  // locals shared by the forward and the adjoint
   qt qp, q_p, r_err;
 };
 
+// HP (here and in the adjoint functions below): the caller promises c.parent >= 0 (pd_parented(JT): the host sends a model with
+// a non-FREE joint to the world to the generic instantiation; no robot of the reference has one) -- the `if (parent)` regions
+// then cost no exec-mask code and no moves that merge their results with the values of lanes outside them (-62 instructions
+// per adjoint step)
+template <bool HP = false>
 PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, JointCtx &j) {
   j.pp = V3(0, 0, 0); j.qp = Q4(0, 0, 0, 1); j.x_p = c.p_pj; j.q_p = c.q_pj;
   j.r_p = V3(0, 0, 0); j.w_p = V3(0, 0, 0); j.v_p = V3(0, 0, 0);
-  if (c.parent >= 0) {  // :326-333
+  if (HP || c.parent >= 0) {  // :326-333
     const float *r = rec + c.parent * PD_REC;
     j.pp = ld3(r); j.qp = ld4(r + 3); j.w_p = ld3(r + 7); j.v_p = ld3(r + 10);
     j.x_p = j.pp + qrot(j.qp, c.p_pj);
@@ -461,10 +466,10 @@ struct JointPrep {
   float2 sc0, sc1;  // (sin, cos) of ang[0] / 2 and ang[1] / 2, as q_axis_angle computed them
 };
 
-template <int JT>
+template <int JT, bool HP = false>
 PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
                            const float *act, const float *ke, const float *kd, JointPrep &P) {
-  joint_ctx(c, s, rc_c, rec, P.j);
+  joint_ctx<HP>(c, s, rc_c, rec, P.j);
   const JointCtx &j = P.j;
   const float ake = m.attach_ke, akd = m.attach_kd;
   P.f_raw = j.x_err * ake + j.v_err * akd;
@@ -495,7 +500,7 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
   }
 }
 
-template <int JT>
+template <int JT, bool HP = false>
 PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyState &s, const JointPrep &P, const float *tgt,
                             const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
                             BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
@@ -504,7 +509,7 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
   const v3 f_raw = P.f_raw, f_total = P.f_total;
   v3 adj_t = -gc_t, adj_f = -gc_f, adj_r_c = V3(0, 0, 0), adj_r_p = V3(0, 0, 0);
   adj_cross(j.r_c, f_total, adj_r_c, adj_f, -gc_t);
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     adj_t += gp_t; adj_f += gp_f;
     adj_cross(j.r_p, f_total, adj_r_p, adj_f, gp_t);
   }
@@ -603,7 +608,7 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
   adj_qrot_q(s.r, c.com, adj_q_c, -adj_r_c);  // r_c = x_c - (x_c + rot(q_c, com)); rc_c is a function of q_c
   own.p += adj_x_err; own.r += adj_q_c; own.w += adj_w_err; own.v += adj_v_err;
   par = adj_zero();
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     v3 adj_x_p = adj_r_p - adj_x_err;
     par.p = adj_x_p - adj_r_p;                           // x_p = pp + ..., r_p = x_p - (pp + rc_par)
     float aP[9];  // matrix adjoint of rotm(qp): rc_par = rotm(qp) com_par, x_p = pp + rotm(qp) p_pj
@@ -617,13 +622,13 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
   }
 }
 
-template <int JT>
+template <int JT, bool HP = false>
 PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
                       const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
                       BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
   JointPrep P;
-  joint_adj_prep<JT>(m, c, s, rc_c, rec, tgt, act, ke, kd, P);
-  joint_adj_apply<JT>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+  joint_adj_prep<JT, HP>(m, c, s, rc_c, rec, tgt, act, ke, kd, P);
+  joint_adj_apply<JT, HP>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -651,11 +656,12 @@ PD_DEV RevCache rev_cache_load(const float *d) {
 }
 
 // pp, qp, w_p: pose and angular velocity of the parent body (ignored for a joint to the world)
+template <bool HP = false>
 PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 w_c, v3 pp, qt qp, v3 w_p, float tgt, float act, float ke,
                             float kd) {
   RevCache R;
   R.x_p = c.p_pj; R.q_p = c.q_pj;
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     R.x_p = pp + qrot(qp, c.p_pj);
     R.q_p = qmul(qp, c.q_pj);
   } else {
@@ -677,12 +683,13 @@ PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 
 }
 
 // Parent quantities are passed explicitly (pp, qp, w_p, v_p, rc_par = rot(qp, com_par); ignored for a joint to the world).
+template <bool HP = false>
 PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, v3 pp, qt qp, v3 w_p, v3 v_p, v3 rc_par,
                              const RevCache &R, float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par,
                              float *aR, float &a_tgt, float &a_act, float &a_ke, float &a_kd) {  // aR: matrix adjoint of rotm(s.r), see integrate_adj2
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 r_p = V3(0, 0, 0);
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     r_p = R.x_p - (pp + rc_par);
   } else {
     pp = V3(0, 0, 0); w_p = pp; v_p = pp; qp = Q4(0, 0, 0, 1);
@@ -692,7 +699,7 @@ PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const Body
   const v3 f_total = x_err * ake + v_err * akd;
   v3 adj_t = -gc_t, adj_f = -gc_f, adj_r_c = V3(0, 0, 0), adj_r_p = V3(0, 0, 0);
   adj_cross(r_c, f_total, adj_r_c, adj_f, -gc_t);
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     adj_t += gp_t; adj_f += gp_f;
     adj_cross(r_p, f_total, adj_r_p, adj_f, gp_t);
   }
@@ -723,7 +730,7 @@ PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const Body
   add_outer(aR, -adj_r_c, c.com);     // rc_c = rotm(s.r) com
   own.p += adj_x_err; own.r += adj_q_c; own.w += adj_w_err; own.v += adj_v_err;
   par = adj_zero();
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     v3 adj_x_p = adj_r_p - adj_x_err;
     par.p = adj_x_p - adj_r_p;
     float aP[9];  // matrix adjoint of rotm(qp): rc_par = rotm(qp) com_par, x_p = pp + rotm(qp) p_pj
@@ -737,16 +744,17 @@ PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const Body
   }
 }
 
+template <bool HP = false>
 PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const RevCache &R,
                         float tgt, float ke, float kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own, BodyAdj &par, float *aR, float &a_tgt,
                         float &a_act, float &a_ke, float &a_kd) {
   v3 pp = V3(0, 0, 0), w_p = pp, v_p = pp, rc_par = pp;
   qt qp = Q4(0, 0, 0, 1);
-  if (c.parent >= 0) {
+  if (HP || c.parent >= 0) {
     const float *r = rec + c.parent * PD_REC;
     pp = ld3(r); qp = ld4(r + 3); w_p = ld3(r + 7); v_p = ld3(r + 10); rc_par = ld3(r + 13);
   }
-  rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt, a_act, a_ke, a_kd);
+  rev_adjoint_core<HP>(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt, a_act, a_ke, a_kd);
 }
 
 // ---------------------------------------------------------------------------------------------

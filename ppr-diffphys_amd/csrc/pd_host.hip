@@ -138,7 +138,11 @@ static int build_device(pd_model *m, int segw) {
       default: return fail("unsupported joint type " + std::to_string(m->jtype[i]) + " (revolute, fixed, free, compound only)");
     }
   }
-  if (jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
+  // the two specialised instantiations (revolute-only, compound-only robots) also assume that every joint which is not FREE
+  // hangs on a body (pd_parented: predicate-free parent access in the adjoint); a joint to the world takes the generic one
+  bool world_joint = false;
+  for (int i = 0; i < nb; ++i) world_joint |= m->jtype[i] != PD_JOINT_FREE && m->jparent[i] < 0;
+  if ((jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) || world_joint) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
   // ---- contact table: grouped by body, kd-ordered inside a body, cut into tiles of <= segw points
   std::vector<float4> pts, tile_lo, tile_hi, mats;
   std::vector<unsigned char> pt_mat;

@@ -881,9 +881,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       PD_WAIT_VMEM();
       // (the hand-over records are double-buffered by step parity: the body wave may still be reading the previous ones)
       if (rev)
-        rev_cache_store(jc + (step & 1) * m.env_lds_jc + b * PD_JC, rev_forward(m, c, Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), V3(pose[1].x, pose[1].y, pose[1].z),
-                                                    V3(pose[4].x, pose[4].y, pose[4].z), Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w),
-                                                    V3(pose[3].x, pose[3].y, pose[3].z), tgt_c, act_c, ke1, kd1));
+      {
+        const qt q_c = Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), qp = Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w);
+        const v3 w_c = V3(pose[1].x, pose[1].y, pose[1].z), pp = V3(pose[4].x, pose[4].y, pose[4].z), w_p = V3(pose[3].x, pose[3].y, pose[3].z);
+        float *dst = jc + (step & 1) * m.env_lds_jc + b * PD_JC;
+        rev_cache_store(dst, rev_forward<pd_parented(JT)>(m, c, q_c, w_c, pp, qp, w_p, tgt_c, act_c, ke1, kd1));
+      }
       STAMP(8);
       // request everything the next iteration needs; nothing loaded here is touched before the next PD_WAIT_VMEM
       float tgt_n, act_n;
@@ -1053,10 +1056,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     for (int k = 0; k < ND; ++k) { a_tgt[k] = 0.f; a_act[k] = 0.f; a_ke[k] = 0.f; a_kd[k] = 0.f; }
     if (is_body && c.type != PD_JOINT_FREE) {
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
-      if (c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
+      if ((SPLIT && pd_parented(JT)) || c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
       if (SPLIT)  // revolute only: the state-only half was computed by the contact wave
-        rev_adjoint(m, c, s, rc, rec, rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC), tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, aR,
-                    a_tgt[0], a_act[0], a_ke[0], a_kd[0]);
+      {
+        const RevCache R = rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC);
+        rev_adjoint<pd_parented(JT)>(m, c, s, rc, rec, R, tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, aR, a_tgt[0], a_act[0], a_ke[0], a_kd[0]);
+      }
       else
         joint_adj<JT>(m, c, s, rc, rec, tgt, act, ke, kd, adj_t0, adj_f0, gp_t, gp_f, ga, par, a_tgt, a_act, a_ke, a_kd);
     }
@@ -1382,7 +1387,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         const qt q_c = Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), qp = Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w);
         const v3 w_c = V3(pose[1].x, pose[1].y, pose[1].z), pp = V3(pose[4].x, pose[4].y, pose[4].z), w_p = V3(pose[3].x, pose[3].y, pose[3].z);
         const float tgt = tgt_n, act = act_n;
-        RevCache R = rev_forward(m, c, q_c, w_c, pp, qp, w_p, tgt, act, ke[0], kd[0]);
+        RevCache R = rev_forward<pd_parented(JT)>(m, c, q_c, w_c, pp, qp, w_p, tgt, act, ke[0], kd[0]);
         STAMP(8);
         load_next(step - 1);  // nothing loaded here is touched before the next PD_WAIT_VMEM
         STAMP(7);
@@ -1403,8 +1408,8 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
           float aR[9];
 #pragma unroll
           for (int k = 0; k < 9; ++k) aR[k] = 0.f;
-          rev_adjoint_core(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke[0], kd[0], gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt[0], a_act[0],
-                           a_ke[0], a_kd[0]);
+          rev_adjoint_core<pd_parented(JT)>(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke[0], kd[0], gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt[0], a_act[0],
+                                            a_ke[0], a_kd[0]);
           rotm_adj(s.r, aR, own.r);
         }
         if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
@@ -1444,7 +1449,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         if (jointed) {
           const float *r = rec + b * PD_REC;
           s.p = ld3(r); s.r = ld4(r + 3); s.w = ld3(r + 7); s.v = ld3(r + 10);
-          joint_adj_prep<JT>(m, c, s, ld3(r + 13), rec, tgt, act, ke, kd, P);
+          joint_adj_prep<JT, pd_parented(JT)>(m, c, s, ld3(r + 13), rec, tgt, act, ke, kd, P);
         }
         STAMP(8);
         pair_wait(sig, a.nsteps - step);  // A: the wrench adjoints of this step are staged
@@ -1457,7 +1462,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
           const v3 gc_t = ld3(adjf + b * PD_W6), gc_f = ld3(adjf + b * PD_W6 + 3);
           v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
           if (has_par) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-          joint_adj_apply<JT>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+          joint_adj_apply<JT, pd_parented(JT)>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
         }
         if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
         STAMP(10);

@@ -400,6 +400,61 @@ def test_generic_joint_kernel_on_toy_robot(dev, oracle_libs, tmp_path):
         assert np.median(per_env) < 5e-2, (k, per_env)
 
 
+@pytest.mark.gpu
+def test_revolute_chain_jointed_to_the_world(dev, oracle_libs):
+    """The specialised kernels (one joint type) assume that every joint which is not FREE hangs on a body; a model with a
+    joint to the WORLD must take the generic instantiation instead (pd_host.hip) and still match the oracle.  The model: one
+    Laikago leg (hip motor, upper, lower leg) hung from a point above the ground by its hip joint -- revolute joints only,
+    no floating base -- with the lower leg dipping into the ground."""
+    from diffphys_amd import hip_backend, robots
+    from oracle.ref_c import RefC
+
+    full = robots.load_template("laikago")
+    keep = [1, 2, 3]
+    tpl = {k: v for k, v in full.items()}
+    for k in ("joint_type", "joint_X_p", "joint_X_c", "joint_axis", "body_com", "body_mass", "body_inertia", "body_names", "shape_materials"):
+        tpl[k] = np.ascontiguousarray(full[k][keep])
+    tpl["joint_parent"] = np.array([-1, 0, 1], np.int32)
+    tpl["joint_q_start"] = np.array([0, 1, 2], np.int32)
+    tpl["joint_qd_start"] = np.array([0, 1, 2], np.int32)
+    tpl["nb"], tpl["nq"], tpl["nqd"] = np.int32(3), np.int32(3), np.int32(3)
+    dof = [6, 7, 8]  # the three joints' dofs in the full robot
+    for k in ("joint_target_ke", "joint_target_kd", "joint_limit_lower", "joint_limit_upper", "joint_limit_ke", "joint_limit_kd"):
+        tpl[k] = np.ascontiguousarray(full[k][dof])
+    tpl["joint_q"] = np.zeros(3, np.float32)
+    X_p = tpl["joint_X_p"].copy()
+    X_p[0, :3] = [0.0, 0.36, 0.0]  # hip joint anchored in the world, 36 cm up: the lower leg reaches the ground
+    tpl["joint_X_p"] = X_p
+    sel = np.isin(full["contact_body"], keep)
+    remap = {1: 0, 2: 1, 3: 2}
+    tpl["contact_body"] = np.array([remap[int(b)] for b in full["contact_body"][sel]], np.int32)
+    for k in ("contact_point", "contact_dist", "contact_material"):
+        tpl[k] = np.ascontiguousarray(full[k][sel])
+    tpl["contact_material"] = np.zeros_like(tpl["contact_material"])
+    nb, nq, nqd = 3, 3, 3
+    bs, T = 11, 40
+    rng = np.random.RandomState(4)
+    mass = np.tile(tpl["body_mass"].astype(np.float64), bs)
+    inertia = np.tile(tpl["body_inertia"].astype(np.float64), (bs, 1, 1))
+    inp = dict(q_init=rng.uniform(-0.5, 0.5, bs * nq), qd_init=rng.randn(bs * nqd) * 0.3, torques=rng.randn(T, bs * nqd) * 0.3,
+               res_f=rng.randn(T, bs * nb, 6) * 0.3, refs=rng.uniform(-0.4, 0.4, (T, bs * nqd)), target_ke=np.full(bs * nqd, 220.0),
+               target_kd=np.full(bs * nqd, 2.0), body_mass=mass, body_inv_mass=1 / mass, body_inertia=inertia,
+               body_inv_inertia=np.linalg.inv(inertia), adj_pos=rng.randn(3, bs * nb, 7) * 1e-3, adj_vel=rng.randn(3, bs * nb, 6) * 1e-3)
+    inp = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inp.items()}
+    inp.update(frame2step=[0, 19, 39], nsteps=T, dt=5e-4)
+    dm = hip_backend.DeviceModel(tpl)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert np.abs(st["grf"]).max() > 1.0, "the leg must touch the ground"
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 2e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 1e-3
+    assert relmax(out["grf"], st["grf"]) < 2e-3 and relmax(out["jaf"], st["jaf"]) < 2e-3
+    for k in GRADS:
+        assert np.isfinite(out["grads"][k]).all(), k
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+
+
 def test_empty_batch_and_graph_capture(dev):
     """Empty inputs return empty outputs; and the launch path neither allocates through HIP nor synchronises, so the whole
     device side of an optimisation iteration -- FK, rollout, fused frame losses, adjoint rollout, FK adjoint -- can be
