@@ -11,7 +11,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     writes it: 512 per GPU at N = 8).
     Either way every rank builds ITS slice of one global batch (per-env seeded: the slices concatenate to the
     same global batch for any N), envs are independent, and there is no collective on the data path
-  * inputs are resident in HBM before the timed region; timed region is bracketed by barrier + synchronize
+  * inputs are resident in HBM before the timed region; timed region is bracketed by barrier + synchronize; after the W
+    warm-up steps the bench keeps stepping, untimed, for 0.25 s (clock ramp of an idle box), then times exactly K steps
   * rank 0 prints ONE JSON line (value = whole-job env-steps/s, max time over ranks); for N > 1 the line also carries
     "other_scaling": the same measurement in the other mode (so one scaling run holds the strong AND the weak row)
 
@@ -187,6 +188,14 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
+        # the first GPU process on a box that has been idle can run its first ~50 ms at a fraction of the clock (measured here:
+        # 2.2 ms per step instead of 0.61 for the first bench process on some boxes, 0.61 for every later one): keep warming,
+        # untimed, until a quarter of a second of work has gone through -- W steps of 0.6 ms do not wake the clocks up
+        t_warm = time.perf_counter()
+        while time.perf_counter() - t_warm < 0.25:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
