@@ -462,6 +462,7 @@ struct JointPrep {
   qt qa, q_pc, q_0, q_1, q10, q_w;
   v3 ax1, ax2, axw[3], t_raw;
   float ang[3], jf[3], qdk[3];
+  float Mw[9];  // rotm(q_w), handed from prep to apply
   v3 c0, c1, c2;  // columns of R(q_pc): quat_decompose and its adjoint share them
   float2 sc0, sc1;  // (sin, cos) of ang[0] / 2 and ang[1] / 2, as q_axis_angle computed them
 };
@@ -488,11 +489,10 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
     P.q_w = qmul(j.q_p, c.q_off);
     const v3 ax[3] = {ax0, P.ax1, P.ax2};
     P.t_raw = V3(0, 0, 0);
-    float Mw[9];
-    rotm(P.q_w, Mw);  // one quaternion rotates the three axes (pd_math.h)
+    rotm(P.q_w, P.Mw);  // one quaternion rotates the three axes (pd_math.h)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      P.axw[k] = mat_vec(Mw, ax[k]); P.qdk[k] = dot(P.axw[k], j.w_err);
+      P.axw[k] = mat_vec(P.Mw, ax[k]); P.qdk[k] = dot(P.axw[k], j.w_err);
       const JointLimit L = c.lim[k];
       P.jf[k] = joint_force(P.ang[k], P.qdk[k], tgt[k], ke[k], kd[k], act[k], L.lo, L.up, L.ke, L.kd);
       P.t_raw += P.axw[k] * P.jf[k];
@@ -567,8 +567,8 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     float adj_ang[3] = {0.f, 0.f, 0.f};
     v3 adj_ax[3] = {V3(0, 0, 0), V3(0, 0, 0), V3(0, 0, 0)};
     qt adj_q_w = Q4(0, 0, 0, 0);
-    float Mw[9], aW[9];  // rotm(q_w) and its matrix adjoint: axw[k] = Mw ax[k]
-    rotm(P.q_w, Mw);
+    const float *Mw = P.Mw;
+    float aW[9];  // matrix adjoint of rotm(q_w): axw[k] = Mw ax[k]
 #pragma unroll
     for (int k = 0; k < 9; ++k) aW[k] = 0.f;
 #pragma unroll
