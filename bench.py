@@ -214,7 +214,11 @@ def main():
     elapsed, g = timed(step)
     bad = int(torch.isnan(g["q_init"]).sum().item())
 
-    # per-kernel device time (HIP events on the launch stream), in an extra pass outside the timed region
+    # per-kernel device time (HIP events on the launch stream around each launch, pd_model_set_timing), in an extra pass outside
+    # the timed region.  The two averages add up to MORE than ms_per_step (0.27 + 0.33 against 0.56 ms on the bench box): in
+    # the timed region the kernels run back to back and the head of one overlaps the draining tail of the other (one
+    # workgroup per CU, contact-heavy envs finish last), which a bracket around a single launch cannot see; rocprofv3's
+    # per-dispatch durations (profiles/) are the same quantity as these and agree with them.
     dm.set_timing(True)
     kf, kb = [], []
     for _ in range(max(5, min(args.steps, 20))):
@@ -305,7 +309,8 @@ def main():
                 "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,
                                "frac_of_achievable": ach_fwd / HBM_ACHIEVABLE_BYTES, "avg_launch_ms": fwd_ms,
                                "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf)},
-                "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4)",
+                "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4); launch "
+                        "durations are per dispatch: back to back the two kernels overlap at their boundaries, so their sum exceeds ms_per_step",
             },
         }
         if other is not None:
