@@ -215,10 +215,10 @@ def main():
     bad = int(torch.isnan(g["q_init"]).sum().item())
 
     # per-kernel device time (HIP events on the launch stream around each launch, pd_model_set_timing), in an extra pass outside
-    # the timed region.  The two averages add up to MORE than ms_per_step (0.27 + 0.33 against 0.56 ms on the bench box): in
-    # the timed region the kernels run back to back and the head of one overlaps the draining tail of the other (one
-    # workgroup per CU, contact-heavy envs finish last), which a bracket around a single launch cannot see; rocprofv3's
-    # per-dispatch durations (profiles/) are the same quantity as these and agree with them.
+    # the timed region.  The two averages add up to MORE than ms_per_step (0.27 + 0.33 against 0.56 ms on the bench box): each
+    # launch here is followed by a host synchronisation, the timed region runs 2 K launches back to back (no idle gaps for the
+    # clocks to sag in, and the adjoint starts on the part of the trajectory the forward wrote last).  rocprofv3's
+    # per-dispatch durations (profiles/) are the same quantity as these and agree with them; `value` is the sustained rate.
     dm.set_timing(True)
     kf, kb = [], []
     for _ in range(max(5, min(args.steps, 20))):
@@ -310,7 +310,7 @@ def main():
                                "frac_of_achievable": ach_fwd / HBM_ACHIEVABLE_BYTES, "avg_launch_ms": fwd_ms,
                                "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf)},
                 "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4); launch "
-                        "durations are per dispatch: back to back the two kernels overlap at their boundaries, so their sum exceeds ms_per_step",
+                        "durations are per synchronised dispatch and add up to more than ms_per_step, which is the back-to-back rate",
             },
         }
         if other is not None:
