@@ -18,8 +18,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 
 Extra objects on the line:
   roofline     dominant kernel (the adjoint rollout): algorithmic HBM bytes per launch / its average launch
-               duration measured live with HIP events on the launch stream (pd_model_set_timing) in an extra
-               un-timed pass; peak = 8 TB/s nominal (frac) and 6.3 TB/s achievable (frac_of_achievable);
+               duration measured live with HIP events on the launch stream (pd_model_set_timing) on back-to-back
+               launches in an extra un-timed pass; peak = 8 TB/s nominal (frac) and 6.3 TB/s achievable (frac_of_achievable);
                traffic = HBM bytes per launch from the PMC counters of the LAST COMMITTED PROFILE (traffic_source
                names it -- counters cannot be read inside this run); secondary = what actually bounds the kernel
                (waves per SIMD, VALU busy, LDS per workgroup) from the same profile + this run's launch geometry
@@ -215,14 +215,15 @@ def main():
     bad = int(torch.isnan(g["q_init"]).sum().item())
 
     # per-kernel device time (HIP events on the launch stream around each launch, pd_model_set_timing), in an extra pass outside
-    # the timed region.  The two averages add up to MORE than ms_per_step (0.27 + 0.33 against 0.56 ms on the bench box): each
-    # launch here is followed by a host synchronisation, the timed region runs 2 K launches back to back (no idle gaps for the
-    # clocks to sag in, and the adjoint starts on the part of the trajectory the forward wrote last).  rocprofv3's
-    # per-dispatch durations (profiles/) are the same quantity as these and agree with them; `value` is the sustained rate.
+    # the timed region: batches of 10 steps enqueued back to back, as the timed region runs them, and the durations of the LAST
+    # forward and adjoint launch of each batch are read (the read synchronises).  Bracketing every launch with a host
+    # synchronisation instead reads 0.27 + 0.33 ms where the back-to-back pair takes 0.56 (clocks sag in the idle gaps);
+    # rocprofv3's per-dispatch durations of this same command (profiles/) are the quantity measured here.
     dm.set_timing(True)
     kf, kb = [], []
-    for _ in range(max(5, min(args.steps, 20))):
-        step()
+    for _ in range(max(4, min(args.steps // 2, 10))):
+        for _ in range(10):
+            step()
         torch.cuda.synchronize()
         kf.append(dm.last_kernel_ms(0))
         kb.append(dm.last_kernel_ms(1))
@@ -310,7 +311,7 @@ def main():
                                "frac_of_achievable": ach_fwd / HBM_ACHIEVABLE_BYTES, "avg_launch_ms": fwd_ms,
                                "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf)},
                 "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4); launch "
-                        "durations are per synchronised dispatch and add up to more than ms_per_step, which is the back-to-back rate",
+                        "durations are per dispatch, measured on launches enqueued back to back like the timed region",
             },
         }
         if other is not None:

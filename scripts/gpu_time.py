@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel device timing of rollout fwd / adjoint for a list of (robot, bs, segw) configs (HIP events)."""
+"""Per-kernel device timing of rollout fwd / adjoint for a list of (robot, bs, segw) configs (HIP events around the last
+launches of back-to-back batches)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ppr-diffphys_amd"))
@@ -25,12 +26,16 @@ for name, bs, segw in cfgs:
     fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
     ba = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
     ap = torch.from_numpy(inp["adj_pos"]).to(dev); av = torch.from_numpy(inp["adj_vel"]).to(dev)
+    # batches of steps enqueued back to back (like bench.py's timed region: no idle gaps for the clocks to sag in), the durations
+    # of the last forward / adjoint launch of each batch are read; the first batches warm the clocks up
     fs, bs_ = [], []
-    for it in range(8):
-        out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=fos)
-        g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, out[4], ap, av)
+    bufs = dm.alloc_rollout(bs, T, len(fos), dev)
+    for it in range(9):
+        for _ in range(10):
+            out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=fos, out=bufs)
+            g = dm.rollout_backward(bs, T, inp["dt"], *ba, fos, out[4], ap, av, out=bufs)
         torch.cuda.synchronize()
-        if it >= 3:
+        if it >= 4:
             fs.append(dm.last_kernel_ms(0)); bs_.append(dm.last_kernel_ms(1))
     f, b = np.median(fs), np.median(bs_)
     nb, nqd = int(tpl["nb"]), int(tpl["nqd"]); C = 2 * nqd + 6 * nb; B = 4 * (26 * nb + 3 * C)
