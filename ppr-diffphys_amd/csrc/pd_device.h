@@ -280,12 +280,24 @@ PD_DEV bool contact_point_fwd(const float *r, float4 P, float4 mat, ContactOut &
 }
 
 // Adjoint: g_t, g_f = adjoint of the body's wrench accumulator; returns the contribution to (p,q,w,v).
+// MAT: the four rotations by the body's quaternion (two forward, two adjoint) through one matrix and one matrix adjoint
+// (pd_math.h: rotm).  Measured: -2.3 % adjoint time where the contacts run inline on the integrate wave (quad 8192), +3 % on the
+// revolute kernel's contact wave (Laikago 4096) -- so the caller chooses.
+template <bool MAT = false>
 PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g_f, BodyAdj &out) {
   v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
   qt q = ld4(r + 3);
-  v3 com = qrot_inv(q, rc);  // body-frame COM back from the staged rc = rot(q, com): no table read on the hit path
-  v3 cpt = V3(P.x, P.y, P.z);
-  v3 cp = (p + qrot(q, cpt)) - V3(0.f, P.w, 0.f);
+  float M[9];
+  v3 cpt = V3(P.x, P.y, P.z), com, cp;
+  if (MAT) {
+    rotm(q, M);
+    com = matT_vec(M, rc);
+    cp = (p + mat_vec(M, cpt)) - V3(0.f, P.w, 0.f);
+    cp.y = (p.y + qrot_y(q, cpt)) - P.w;  // the height decides "touching": exactly the forward pass's arithmetic
+  } else {
+    com = qrot_inv(q, rc);  // body-frame COM back from the staged rc = rot(q, com): no table read on the hit path
+    cp = (p + qrot(q, cpt)) - V3(0.f, P.w, 0.f);
+  }
   float c = cp.y;
   if (c > 0.0f) return false;
   v3 rr = cp - (p + rc);
@@ -323,8 +335,17 @@ PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g
   adj_cross(w, rr, adj_w, adj_r, adj_dpdt);
   v3 adj_cp = V3(adj_r.x, adj_r.y + adj_c, adj_r.z);
   qt adj_q = Q4(0, 0, 0, 0);
-  adj_qrot_q(q, com, adj_q, -adj_r);
-  adj_qrot_q(q, cpt, adj_q, adj_cp);
+  if (MAT) {
+    float aM[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) aM[k] = 0.f;
+    add_outer(aM, -adj_r, com);
+    add_outer(aM, adj_cp, cpt);
+    rotm_adj(q, aM, adj_q);
+  } else {
+    adj_qrot_q(q, com, adj_q, -adj_r);
+    adj_qrot_q(q, cpt, adj_q, adj_cp);
+  }
   out.p = adj_cp - adj_r;
   out.r = adj_q;
   out.w = adj_w;

@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {  // ROLES == 2 only
     const int pb = (int)(r - rec) / PD_REC;
     BodyAdj o = adj_zero();
-    contact_point_adj(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    contact_point_adj<true>(r, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
     adj_store(out, o);
   };
   // inertia and inverse inertia are read from LDS where they are used (9 + 9 registers less across the step)

@@ -41,6 +41,12 @@ PD_DEV v3 qrot(qt q, v3 v) {
   v3 u = qvec(q);
   return v * (2.0f * q.w * q.w - 1.0f) + cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
 }
+// y component of qrot(q, v), the same expression: where a branch of the forward pass hangs on it (a contact point's height),
+// code that otherwise rotates by rotm(q) takes the decision from this, bit for bit like the forward pass
+PD_DEV float qrot_y(qt q, v3 v) {
+  v3 u = qvec(q);
+  return v.y * (2.0f * q.w * q.w - 1.0f) + (u.z * v.x - u.x * v.z) * (2.0f * q.w) + u.y * (2.0f * dot(u, v));
+}
 PD_DEV v3 qrot_inv(qt q, v3 v) {
   v3 u = qvec(q);
   return v * (2.0f * q.w * q.w - 1.0f) - cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
