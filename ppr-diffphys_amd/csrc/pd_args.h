@@ -22,7 +22,8 @@ enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD 
 //   adjoint : revolute-only robots the 2-role kernel (body + contact wave); other joint mixes the 2-role k_rollout_bwd3
 //             (integrate + contacts wave, joint wave).  The other variants exist for A/B timing (pd_debug_set_variant).
 constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
-// the specialised instantiations (one joint type) are only launched for models whose non-FREE joints all hang on a body (pd_host.hip)
+// the specialised instantiations (one joint type) are only launched for PLAIN models: non-FREE joints all hang on a body, child
+// joint frames are not rotated (pd_host.hip)
 constexpr bool pd_parented(int jt) { return jt == PD_JT_REVOLUTE || jt == PD_JT_COMPOUND; }
 enum { PD_KV_FWD_SPLIT = 0, PD_KV_FWD_UNSPLIT, PD_KV_BWD_2ROLE, PD_KV_BWD_2ROLE_EARLY, PD_KV_BWD_3ROLE, PD_KV_BWD3_2ROLE, PD_KV_BWD_UNSPLIT, PD_KV_FK };
 struct PdLaunchCfg {

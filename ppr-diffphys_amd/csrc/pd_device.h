@@ -395,10 +395,12 @@ struct JointCtx {  // locals shared by the forward and the adjoint
   qt qp, q_p, r_err;
 };
 
-// HP (here and in the adjoint functions below): the caller promises c.parent >= 0 (pd_parented(JT): the host sends a model with
-// a non-FREE joint to the world to the generic instantiation; no robot of the reference has one) -- the `if (parent)` regions
-// then cost no exec-mask code and no moves that merge their results with the values of lanes outside them (-62 instructions
-// per adjoint step)
+// HP (here and in the adjoint functions below): the caller promises a PLAIN model (pd_parented(JT)): every joint that is not FREE
+// hangs on a body (c.parent >= 0) and every child joint frame (joint_X_c) has the identity rotation -- true of every robot of the
+// reference (Warp's URDF importer only makes such models); the host sends anything else to the generic instantiation.  The
+// `if (parent)` regions then cost no exec-mask code and no moves that merge their results with the values of lanes outside them
+// (-62 instructions per adjoint step), and the compound joint's six quaternion products with q_off drop out of the adjoint
+// (x * identity is x exactly; -5 % adjoint time for human / quad).  The forward pass keeps its products: its arithmetic is frozen.
 template <bool HP = false>
 PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, JointCtx &j) {
   j.pp = V3(0, 0, 0); j.qp = Q4(0, 0, 0, 1); j.x_p = c.p_pj; j.q_p = c.q_pj;
@@ -497,9 +499,9 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
   P.f_raw = j.x_err * ake + j.v_err * akd;
   P.f_total = ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) ? clamp3(P.f_raw, 1.0e4f) : P.f_raw;
   if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
-    P.qa = qmul(qconj(c.q_off), qconj(j.q_p));
+    P.qa = HP ? qconj(j.q_p) : qmul(qconj(c.q_off), qconj(j.q_p));  // (HP: identity child frames, see joint_ctx)
     const qt qb = qmul(P.qa, s.r);
-    P.q_pc = qmul(qb, c.q_off);
+    P.q_pc = HP ? qb : qmul(qb, c.q_off);
     quat_decompose(P.q_pc, P.ang, P.c0, P.c1, P.c2);
     const v3 ax0 = V3(1, 0, 0);
     P.q_0 = q_axis_angle_sc(ax0, P.ang[0], P.sc0);
@@ -507,7 +509,7 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
     P.q_1 = q_axis_angle_sc(P.ax1, P.ang[1], P.sc1);
     P.q10 = qmul(P.q_1, P.q_0);
     P.ax2 = qrot(P.q10, V3(0, 0, 1));
-    P.q_w = qmul(j.q_p, c.q_off);
+    P.q_w = HP ? j.q_p : qmul(j.q_p, c.q_off);
     const v3 ax[3] = {ax0, P.ax1, P.ax2};
     P.t_raw = V3(0, 0, 0);
     rotm(P.q_w, P.Mw);  // one quaternion rotates the three axes (pd_math.h)
@@ -606,7 +608,7 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
       add_outer(aW, adj_axw, ax[k]);
     }
     rotm_adj(P.q_w, aW, adj_q_w);
-    adj_qmul_a(c.q_off, adj_q_p, adj_q_w);
+    if (HP) adj_q_p += adj_q_w; else adj_qmul_a(c.q_off, adj_q_p, adj_q_w);
     qt adj_q10 = Q4(0, 0, 0, 0), adj_q_1 = adj_q10, adj_q_0 = adj_q10;
     adj_qrot_q(P.q10, V3(0, 0, 1), adj_q10, adj_ax[2]);
     adj_qmul(P.q_1, P.q_0, adj_q_1, adj_q_0, adj_q10);
@@ -616,9 +618,9 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     qt adj_q_pc = Q4(0, 0, 0, 0);
     quat_decompose_adj(P.q_pc, P.c0, P.c1, P.c2, adj_ang, adj_q_pc);
     qt adj_qb = Q4(0, 0, 0, 0), adj_qa = adj_qb, adj_cqp = adj_qb;
-    adj_qmul_a(c.q_off, adj_qb, adj_q_pc);
+    if (HP) adj_qb += adj_q_pc; else adj_qmul_a(c.q_off, adj_qb, adj_q_pc);
     adj_qmul(P.qa, s.r, adj_qa, adj_q_c, adj_qb);
-    adj_qmul_b(qconj(c.q_off), adj_cqp, adj_qa);
+    if (HP) adj_cqp += adj_qa; else adj_qmul_b(qconj(c.q_off), adj_cqp, adj_qa);
     adj_q_p += qconj(adj_cqp);
   }
   if (!((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND)) {  // r_err = conj(q_p) * q_c  (a COMPOUND joint does not use r_err:

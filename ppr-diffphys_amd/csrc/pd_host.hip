@@ -139,10 +139,15 @@ static int build_device(pd_model *m, int segw) {
     }
   }
   // the two specialised instantiations (revolute-only, compound-only robots) also assume that every joint which is not FREE
-  // hangs on a body (pd_parented: predicate-free parent access in the adjoint); a joint to the world takes the generic one
-  bool world_joint = false;
-  for (int i = 0; i < nb; ++i) world_joint |= m->jtype[i] != PD_JOINT_FREE && m->jparent[i] < 0;
-  if ((jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) || world_joint) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
+  // hangs on a body and that every child joint frame has the identity rotation (pd_parented: a PLAIN model, see
+  // pd_device.h joint_ctx); anything else takes the generic one
+  bool world_joint = false, turned_child_frame = false;
+  for (int i = 0; i < nb; ++i) {
+    world_joint |= m->jtype[i] != PD_JOINT_FREE && m->jparent[i] < 0;
+    const float *qc = &m->X_c[i * 7 + 3];
+    turned_child_frame |= !(qc[0] == 0.f && qc[1] == 0.f && qc[2] == 0.f && qc[3] == 1.f);
+  }
+  if ((jt != PD_JT_REVOLUTE && jt != PD_JT_COMPOUND) || world_joint || turned_child_frame) jt = PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED;
   // ---- contact table: grouped by body, kd-ordered inside a body, cut into tiles of <= segw points
   std::vector<float4> pts, tile_lo, tile_hi, mats;
   std::vector<unsigned char> pt_mat;

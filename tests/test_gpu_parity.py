@@ -455,6 +455,37 @@ def test_revolute_chain_jointed_to_the_world(dev, oracle_libs):
         assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
 
 
+@pytest.mark.gpu
+def test_rotated_child_joint_frame_takes_the_generic_kernel(dev, oracle_libs):
+    """The single-joint-type kernels also assume identity child joint frames (joint_X_c rotations; every robot of the reference
+    has them) and drop the compound joint's products with that frame from the adjoint.  A model with a ROTATED child frame must
+    take the generic instantiation (pd_host.hip) and match the oracle: the human with two of its child frames turned."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    name = "human"
+    tpl = dict(robots.load_template(name))
+    X_c = np.array(tpl["joint_X_c"], np.float32).copy()
+    for body, (ax, ang) in ((4, ((1.0, 0.0, 0.0), 0.3)), (11, ((0.0, 0.6, 0.8), -0.5))):
+        X_c[body, 3:6] = np.asarray(ax, np.float32) * np.sin(ang / 2)
+        X_c[body, 6] = np.cos(ang / 2)
+    tpl["joint_X_c"] = X_c
+    inp = synth.make_inputs(tpl, name, bs=6, nsteps=20, seed=3, steps_per_frame=7, penetration=0.003)
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, inp["nsteps"], inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    # the same model with identity frames gives different numbers (the turned frames matter) ...
+    plain = gpu_rollout(hip_backend.DeviceModel(robots.load_template(name)), inp, dev)
+    assert relmax(plain["jaf"], out["jaf"]) > 1e-3
+    # ... and the generic kernel agrees with the oracle
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 5e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 2e-3
+    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 5e-3
+    for k in GRADS:
+        assert np.isfinite(out["grads"][k]).all(), k
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+
+
 def test_empty_batch_and_graph_capture(dev):
     """Empty inputs return empty outputs; and the launch path neither allocates through HIP nor synchronises, so the whole
     device side of an optimisation iteration -- FK, rollout, fused frame losses, adjoint rollout, FK adjoint -- can be
