@@ -504,11 +504,22 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
     P.q_pc = HP ? qb : qmul(qb, c.q_off);
     quat_decompose(P.q_pc, P.ang, P.c0, P.c1, P.c2);
     const v3 ax0 = V3(1, 0, 0);
-    P.q_0 = q_axis_angle_sc(ax0, P.ang[0], P.sc0);
-    P.ax1 = qrot(P.q_0, V3(0, 1, 0));
+    // the axis chain of integrator_euler.py:418-427 with its structure spelled out -- q_0 = (s0, 0, 0, c0) turns about x, so
+    // ax1 = rot(q_0, e_y), q_1 = (ax1 s1, c1) and q_1 q_0 have zero components, and ax2 = rot(q_1 q_0, e_z) is a matrix column.
+    // The same terms as the generic qrot / qmul minus the products with exact zeros (which the compiler may not drop without
+    // fast-math): same values, ~45 instructions less here and ~70 less in the adjoint below
+    float s0, c0;
+    sincos_half_pi(P.ang[0] * 0.5f, s0, c0);
+    P.sc0 = make_float2(s0, c0);
+    P.q_0 = Q4(s0, 0.f, 0.f, c0);
+    P.ax1 = V3(0.f, 2.0f * c0 * c0 - 1.0f, s0 * (2.0f * c0));
     P.q_1 = q_axis_angle_sc(P.ax1, P.ang[1], P.sc1);
-    P.q10 = qmul(P.q_1, P.q_0);
-    P.ax2 = qrot(P.q10, V3(0, 0, 1));
+    P.q_1.x = 0.f;
+    P.q10 = Q4(P.q_1.w * s0, c0 * P.q_1.y + P.q_1.z * s0, c0 * P.q_1.z - P.q_1.y * s0, P.q_1.w * c0);
+    {
+      const qt q = P.q10;
+      P.ax2 = V3(q.y * (2.0f * q.w) + q.x * (2.0f * q.z), q.y * (2.0f * q.z) - q.x * (2.0f * q.w), (2.0f * q.w * q.w - 1.0f) + q.z * (2.0f * q.z));
+    }
     P.q_w = HP ? j.q_p : qmul(j.q_p, c.q_off);
     const v3 ax[3] = {ax0, P.ax1, P.ax2};
     P.t_raw = V3(0, 0, 0);
@@ -609,12 +620,22 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     }
     rotm_adj(P.q_w, aW, adj_q_w);
     if (HP) adj_q_p += adj_q_w; else adj_qmul_a(c.q_off, adj_q_p, adj_q_w);
-    qt adj_q10 = Q4(0, 0, 0, 0), adj_q_1 = adj_q10, adj_q_0 = adj_q10;
-    adj_qrot_q(P.q10, V3(0, 0, 1), adj_q10, adj_ax[2]);
-    adj_qmul(P.q_1, P.q_0, adj_q_1, adj_q_0, adj_q10);
+    // adjoint of the axis chain, with the zero components of q_0, q_1 taken out like in joint_adj_prep
+    const float s0 = P.sc0.x, c0 = P.sc0.y;
+    qt G;  // adjoint of q10 = q_1 q_0 through ax2 = rot(q10, e_z)
+    {
+      const qt q = P.q10;
+      const v3 g = adj_ax[2];
+      G = Q4(g.x * (2.0f * q.z) - g.y * (2.0f * q.w), g.x * (2.0f * q.w) + g.y * (2.0f * q.z),
+             g.x * (2.0f * q.x) + g.y * (2.0f * q.y) + g.z * (4.0f * q.z), g.x * (2.0f * q.y) - g.y * (2.0f * q.x) + g.z * (4.0f * q.w));
+    }
+    const qt adj_q_1 = Q4(c0 * G.x - s0 * G.w, c0 * G.y - s0 * G.z, c0 * G.z + s0 * G.y, c0 * G.w + s0 * G.x);  // G conj(q_0)
+    float adj_q0x = P.q_1.w * G.x - P.q_1.y * G.z + P.q_1.z * G.y;  // conj(q_1) G: only x and w reach the angle
+    float adj_q0w = P.q_1.w * G.w + P.q_1.y * G.y + P.q_1.z * G.z;
     adj_q_axis_angle_sc(ax[1], P.sc1.x, P.sc1.y, adj_ax[1], adj_ang[1], adj_q_1);
-    adj_qrot_q(P.q_0, V3(0, 1, 0), adj_q_0, adj_ax[1]);
-    adj_q_axis_angle_ang_sc(ax[0], P.sc0.x, P.sc0.y, adj_ang[0], adj_q_0);
+    adj_q0x += adj_ax[1].z * (2.0f * c0);                                  // ax1 = (0, 2 c0^2 - 1, 2 c0 s0)
+    adj_q0w += adj_ax[1].y * (4.0f * c0) + adj_ax[1].z * (2.0f * s0);
+    adj_ang[0] += 0.5f * (c0 * adj_q0x - s0 * adj_q0w);                    // q_0 = (sin, 0, 0, cos)(ang[0] / 2)
     qt adj_q_pc = Q4(0, 0, 0, 0);
     quat_decompose_adj(P.q_pc, P.c0, P.c1, P.c2, adj_ang, adj_q_pc);
     qt adj_qb = Q4(0, 0, 0, 0), adj_qa = adj_qb, adj_cqp = adj_qb;
