@@ -380,14 +380,23 @@ PD_DEV void quat_decompose(qt q, float *ang) {
   v3 c0, c1, c2;
   quat_decompose(q, ang, c0, c1, c2);
 }
+// The adjoint's recomputation of the same: the rotated basis is the three columns of rotm(q) -- qrot's terms without the
+// products with the basis vectors' zeros (which the compiler may not drop without fast-math): 22 instructions instead of 3 x 23.
+PD_DEV void quat_decompose_cols(qt q, float *ang, v3 &c0, v3 &c1, v3 &c2) {
+  const float s = 2.0f * q.w * q.w - 1.0f, tw = 2.0f * q.w, tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
+  c0 = V3(s + q.x * tx, q.z * tw + q.y * tx, q.z * tx - q.y * tw);
+  c1 = V3(q.x * ty - q.z * tw, s + q.y * ty, q.x * tw + q.z * ty);
+  c2 = V3(q.y * tw + q.x * tz, q.y * tz - q.x * tw, s + q.z * tz);
+  ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
+}
 PD_DEV void quat_decompose_adj(qt q, v3 c0, v3 c1, v3 c2, const float *g, qt &adj_q) {  // c* = the rotated basis of the forward pass
-  v3 ex = V3(1, 0, 0), ey = V3(0, 1, 0), ez = V3(0, 0, 1);
-  v3 a0 = V3(0, 0, 0), a1 = a0, a2 = a0;
   float gphi = -g[0], gth = -g[1], gpsi = -g[2];
-  { float y = c2.y, x = c2.z, d = x * x + y * y; a2.y += gphi * x / d; a2.z += -gphi * y / d; }
-  { float s = -c2.x; a2.x += -gth * inv_sqrt_1mx2(s); }
-  { float y = c1.x, x = c0.x, d = x * x + y * y; a1.x += gpsi * x / d; a0.x += -gpsi * y / d; }
-  adj_qrot_q(q, ex, adj_q, a0); adj_qrot_q(q, ey, adj_q, a1); adj_qrot_q(q, ez, adj_q, a2);
+  // matrix adjoint of rotm(q): only five of its entries are touched (c0.x, c1.x, c2.xyz)
+  float A[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  { float y = c2.y, x = c2.z, d = x * x + y * y; A[5] = gphi * x / d; A[8] = -gphi * y / d; }
+  { float s = -c2.x; A[2] = -gth * inv_sqrt_1mx2(s); }
+  { float y = c1.x, x = c0.x, d = x * x + y * y; A[1] = gpsi * x / d; A[0] = -gpsi * y / d; }
+  rotm_adj(q, A, adj_q);
 }
 
 struct JointCtx {  // locals shared by the forward and the adjoint
@@ -502,7 +511,7 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
     P.qa = HP ? qconj(j.q_p) : qmul(qconj(c.q_off), qconj(j.q_p));  // (HP: identity child frames, see joint_ctx)
     const qt qb = qmul(P.qa, s.r);
     P.q_pc = HP ? qb : qmul(qb, c.q_off);
-    quat_decompose(P.q_pc, P.ang, P.c0, P.c1, P.c2);
+    quat_decompose_cols(P.q_pc, P.ang, P.c0, P.c1, P.c2);
     const v3 ax0 = V3(1, 0, 0);
     // the axis chain of integrator_euler.py:418-427 with its structure spelled out -- q_0 = (s0, 0, 0, c0) turns about x, so
     // ax1 = rot(q_0, e_y), q_1 = (ax1 s1, c1) and q_1 q_0 have zero components, and ax2 = rot(q_1 q_0, e_z) is a matrix column.
