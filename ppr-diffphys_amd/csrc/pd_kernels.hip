@@ -695,7 +695,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     STAMP(1);
     // ---- eval_body_joints (runs while the contact wave sweeps)
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
-    if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT>(m, c, s, rc, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
+    if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT, JT == PD_JT_COMPOUND>(m, c, s, rc, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
     if (is_body) {
       float *pc = pcon + b * PD_W6;
       pc[0] = wp_t.x; pc[1] = wp_t.y; pc[2] = wp_t.z; pc[3] = wp_f.x; pc[4] = wp_f.y; pc[5] = wp_f.z;
