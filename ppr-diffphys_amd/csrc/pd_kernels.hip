@@ -53,7 +53,7 @@ PD_DEV void stg2(float *ubase, unsigned boff, float2 v) { *(float2 *)((char *)ub
 
 // Saved trajectory (workspace): per step PD_TRAJ_G planes of float4, [step][plane][bs*nb]; consecutive lanes touch consecutive
 // 16-byte words, and a step costs 5 vector-memory instructions per lane instead of 19 (their issue rate, not the bytes,
-// is what the rollout loops feel).  Planes:  0: q   1: (w, v.x)   2: (p, v.y)   3: (v.z, t)   4: (f, 0)
+// is what the rollout loops feel).  Planes:  0: q   1: (w, v.x)   2: (p, v.y)   3: (v.z, t)   4: (f, clamp mask)
 // where (t, f) is the total body wrench of the step.  The adjoint's contact wave needs planes 0-1 of a body and 0-2 of its parent.
 #define PD_TRAJ_G 5
 
@@ -647,6 +647,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   BodyState o_s = s;
   v3 o_ft = V3(0, 0, 0), o_ff = o_ft, o_gt = o_ft, o_gf = o_ft;
   int o_fr = -1;
+  unsigned o_mask = 0u, clamp_mask = 0u;  // which velocity components the step's integration clamped (stored for the adjoint)
   auto spill = [&](int step) {  // writes what the o_* registers hold for `step`
     if (!is_body) return;
     float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     stg4(tj + (size_t)4 * N, boff * 4u, make_float4(o_s.w.x, o_s.w.y, o_s.w.z, o_s.v.x));
     stg4(tj + (size_t)8 * N, boff * 4u, make_float4(o_s.p.x, o_s.p.y, o_s.p.z, o_s.v.y));
     stg4(tj + (size_t)12 * N, boff * 4u, make_float4(o_s.v.z, o_ft.x, o_ft.y, o_ft.z));
-    stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, 0.f));
+    stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
     if (o_fr >= 0) {  // frame gather (dp_model.py:1231-1248)
       float *o = a.wp_pos + ((size_t)o_fr * N + idx) * 7;
       o[0] = o_s.p.x; o[1] = o_s.p.y; o[2] = o_s.p.z; o[3] = o_s.r.x; o[4] = o_s.r.y; o[5] = o_s.r.z; o[6] = o_s.r.w;
@@ -727,7 +728,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       // against right after hand-over A, and against after the vmcnt wait: -2 % / -0.5 % forward time at 4096 envs)
       if (step > 0) spill(step - 1);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
-    } else WAVE_SYNC();
+    } else {
+      if (step > 0) spill(step - 1);  // (one step late here too: the record carries the clamp mask of the step's integration)
+      WAVE_SYNC();
+    }
     if (is_body) {
       float *f = facc + b * PD_W6;
       ft += V3(f[0], f[1], f[2]); ff += V3(f[3], f[4], f[5]);
@@ -738,11 +742,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     ft += jt; ff += jf;
     // the state and the total wrench of this step go to the trajectory for the adjoint, frames to the outputs
     o_s = s; o_ft = ft; o_ff = ff; o_gt = grf_t; o_gf = grf_f; o_fr = fr;
-    if (!SPLIT) spill(step);
     STAMP(3);
     // ---- integrate_bodies
     float sink_rate;
-    s = integrate_fwd(m, c, s, rc, ft, ff, inv_m, I, invI, a.dt, rc, sink_rate);
+    s = integrate_fwd(m, c, s, rc, ft, ff, inv_m, I, invI, a.dt, rc, sink_rate, clamp_mask);
+    o_mask = clamp_mask;
     STAMP(4);
     if (SPLIT) {  // did every body stay inside the margin the contact wave speculated with?  (NaN counts as "no")
       sunk += sink_rate * a.dt;
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }
-  if (SPLIT && a.nsteps > 0) spill(a.nsteps - 1);
+  if (a.nsteps > 0) spill(a.nsteps - 1);
   {  // a frame may name the state after the last step (state_steps[nsteps], dp_model.py:396,1241-1246); no force
      // snapshot exists for it (the reference appends grf / jaf for step in steps_idx only, :1225-1228): zero rows
     const int fr_last = ld_uniform(a.frame_of_step, a.nsteps);
@@ -1000,6 +1004,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
     s.p = V3(n_s[2].x, n_s[2].y, n_s[2].z); s.v = V3(n_s[1].w, n_s[2].w, n_s[3].x);
     v3 t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w), f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
+    const unsigned clamp_mask = __float_as_uint(n_s[4].w);  // which of (w, v) the forward pass clamped in this step
     float tgt[ND], act[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 #pragma unroll
     for (int k = 0; k < 9; ++k) aR[k] = 0.f;
     if (SPLIT && EARLY) {
-      integrate_adj2(m, c, s, Rm, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) {
+      integrate_adj2(m, c, s, Rm, clamp_mask, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, g_I, g_invI, [&](v3 t, v3 f) {
         adj_t0 = t; adj_f0 = f;
         if (is_body) {
           float *o = adjf + b * PD_W6;
@@ -1036,7 +1041,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       STAMP(1);
       pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
     } else {
-    integrate_adj(m, c, s, Rm, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
+    integrate_adj(m, c, s, Rm, clamp_mask, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
     if (is_body) {
       float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
       stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
@@ -1526,6 +1531,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
   v3 t0 = V3(0, 0, 0), f0 = t0;
+  unsigned clamp_mask = 0u;  // which of (w, v) the forward pass clamped in the step (stored beside its wrench)
   float4 n_s[PD_TRAJ_G];
   int n_fr = -1, fr = -1;  // frame seeded into state step + 1 (or -1), fetched with the state
   auto load_step = [&](int step) {
@@ -1540,7 +1546,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     PD_WAIT_VMEM();
     s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
     s.p = V3(n_s[2].x, n_s[2].y, n_s[2].z); s.v = V3(n_s[1].w, n_s[2].w, n_s[3].x);
-    t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w); f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z);
+    t0 = V3(n_s[3].y, n_s[3].z, n_s[3].w); f0 = V3(n_s[4].x, n_s[4].y, n_s[4].z); clamp_mask = __float_as_uint(n_s[4].w);
     fr = n_fr;
     select_step(step);
     float Rm[9];
@@ -1570,7 +1576,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     float aR[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) aR[k] = 0.f;
-    integrate_adj2(m, c, s, Rm, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, LdsAcc9{ga_lds}, LdsAcc9{ga_lds + 9}, [&](v3 t, v3 f) {
+    integrate_adj2(m, c, s, Rm, clamp_mask, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, LdsAcc9{ga_lds}, LdsAcc9{ga_lds + 9}, [&](v3 t, v3 f) {
       adj_t0 = t; adj_f0 = f;
       if (is_body) {
         float *o = adjf + b * PD_W6;
