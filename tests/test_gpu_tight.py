@@ -78,6 +78,38 @@ def test_short_horizon_tight(name, T, dev, oracle_libs):
         check("grad " + k, out["grads"][k].reshape(ref.shape), g32[k], ref, cap_g, 1e-5)
 
 
+@pytest.mark.parametrize("name", ["laikago", "human"])
+def test_velocity_clamps_take_the_forward_decision(name, dev, oracle_libs):
+    """Rollouts that sit on the +-10 velocity clamps (integrator_euler.py:78-88): the forward kernel records which components
+    it clamped and the adjoint blocks exactly those (a recomputed w1 can land on the other side of the clamp by an ulp).
+    High above the ground (no contact boundaries in play), initial twists of +-12..30 so that most of the root's and some
+    of the links' components clamp in every step: gradients must match the float64 oracle as tightly as the unclamped
+    short-horizon test, and a clamped component must pass NO gradient to the initial twist."""
+    from diffphys_amd import hip_backend, robots
+
+    tpl = robots.load_template(name)
+    bs, T = 32, 3
+    inp = tight_inputs(tpl, name, bs, T, seed=23)
+    nq, nqd, nb = int(tpl["nq"]), int(tpl["nqd"]), int(tpl["nb"])
+    rng = np.random.RandomState(8)
+    q = inp["q_init"].reshape(bs, nq).copy(); q[:, 1] += 2.0   # two metres up: nothing touches the ground
+    qd = inp["qd_init"].reshape(bs, nqd).copy()
+    qd[:, :6] = rng.uniform(12.0, 30.0, (bs, 6)) * np.sign(rng.randn(bs, 6))  # root twist far beyond the clamps
+    qd[::2, 3:6] = rng.uniform(-8.0, 8.0, (bs // 2, 3))                        # ... every other env: linear part inside them
+    inp["q_init"], inp["qd_init"] = np.ascontiguousarray(q.reshape(-1), np.float32), np.ascontiguousarray(qd.reshape(-1), np.float32)
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    s64, g64 = _oracle(tpl, inp, np.float64)
+    s32, g32 = _oracle(tpl, inp, np.float32)
+    assert np.allclose(np.asarray(s64["grf"])[0], inp["res_f"][0], atol=1e-6), "no contacts in this test: grf is the residual wrench alone"
+    vel_T = np.asarray(s64["wp_vel"]).reshape(2, bs, nb, 6)[1]
+    assert (np.abs(np.abs(vel_T) - 10.0) < 1e-12).mean() > 0.1, "a good share of the final twists must sit on the clamps"
+    cap_p, cap_v, cap_w, cap_g = CAPS[name]
+    for k in GRAD_LEAD:
+        ref = g64[k]
+        e_gpu, e_c = relmax(out["grads"][k].reshape(ref.shape), ref), relmax(g32[k], ref)
+        assert np.isfinite(e_gpu) and e_gpu <= cap_g and e_gpu <= max(4 * e_c, 1e-5), (k, e_gpu, e_c)
+
+
 def _config_inputs(cfg):
     from diffphys_amd import robots, synth
 
