@@ -366,10 +366,14 @@ PD_DEV void write_hit_log(int *log, const int *hits, int log_n, bool env_ok, int
 template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
                            const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, bool env_ok, int seg,
-                           int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS) {
+                           int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS, bool have_pre = false, int pre_e = 0) {
   if (replay_cnt >= 0) {  // wave-uniform: every env of this wave has a usable log entry
     const int nh_r = replay_cnt;
-    for (int j = l; j < nh_r; j += SEGW) hits[j] = log[1 + j];
+    if (have_pre) {  // the caller fetched this lane's entry ahead of time (a list has at most PD_HITLOG - 1 <= SEGW entries then)
+      if (l < nh_r) hits[l] = pre_e;
+    } else {
+      for (int j = l; j < nh_r; j += SEGW) hits[j] = log[1 + j];
+    }
     int *rs = list, *re = list + m.nb;  // run bounds per body (the tile list is not used in a replay)
     if (l < m.nb) { rs[l] = 0; re[l] = 0; }
     WAVE_SYNC();
@@ -1555,6 +1559,17 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     if (is_body) stage_record(rec, cull, b, s, rc);
     if (JT != PD_JT_REVOLUTE) pair_signal(sig + 3, a.nsteps - step);  // S
   };
+  // (ROLES == 2) the forward hit list of a step is replayed inline: its length and this lane's entry are fetched a step ahead
+  // (with the state), so that the replay does not open with a load at its point of use
+  const bool pre_ok = ROLES == 2 && SEGW >= PD_HITLOG - 1;  // one entry per lane covers every list the log can hold
+  const int lq = l < PD_HITLOG - 1 ? l : PD_HITLOG - 2;
+  const unsigned boff_lg = (unsigned)ec * (PD_HITLOG * 4u);
+  int cnt_c = 0, e_c = 0, cnt_n = 0, e_n = 0;
+  auto load_log = [&](int step, int &cnt, int &e) {
+    const int *lgp = a.hitlog + (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * a.bs * PD_HITLOG;
+    cnt = __float_as_int(ldg((const float *)lgp, boff_lg)); e = __float_as_int(ldg((const float *)lgp + 1, boff_lg + (unsigned)lq * 4u));
+  };
+  if (pre_ok && a.nsteps > 0) load_log(a.nsteps - 1, cnt_c, e_c);
   if (a.nsteps > 0) { load_step(a.nsteps - 1); stage_step(a.nsteps - 1); }
   STAMP_DECL;
   for (int step = a.nsteps - 1; step >= 0; --step) {
@@ -1566,7 +1581,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     }
     // (ROLES == 2) the forward hit list of this step is replayed inline further down: fetch its length now, far ahead
     int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
-    const int log_cnt = (ROLES == 2 && env_ok) ? lg[0] : 0;
+    const int log_cnt = (ROLES == 2 && env_ok) ? (pre_ok ? cnt_c : lg[0]) : 0;
     STAMP(0);
     // ---- adjoint of integrate_bodies; hand-over A as soon as the wrench adjoint exists
     BodyAdj ga = adj_zero();
@@ -1586,6 +1601,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       // the stored state of the NEXT iteration is requested here: its 20 registers are free during phase 1, and phase 2
       // (plus the contacts) covers the HBM latency before stage_step consumes it
       load_step(step - 1);
+      if (pre_ok) load_log(step - 1, cnt_n, e_n);
     });
     rotm_adj(s.r, aR, ga.r);
     if (is_body) {
@@ -1600,7 +1616,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       int log_n_unused;
       sweep_contacts<SEGW, PD_ADJ, PD_ADJ, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot,
                                                  cacc, is_body, env_ok, seg, l, replay ? lg : nullptr, replay ? log_cnt : PD_NO_REPLAY,
-                                                 log_n_unused, contact_hit STAMP_PASS);
+                                                 log_n_unused, contact_hit STAMP_PASS, pre_ok, e_c);
       WAVE_SYNC();
       STAMP(5);
     }
@@ -1636,6 +1652,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       for (int k = 0; k < PD_ADJ; ++k) d[k] = 0.f;
     }
     gn = ga;
+    cnt_c = cnt_n; e_c = e_n;
     STAMP(4);
   }
   select_step(0);
