@@ -648,33 +648,31 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       n_rf[2 * k] = v.x; n_rf[2 * k + 1] = v.y;
     }
   };
-  BodyState o_s = s;
-  v3 o_ft = V3(0, 0, 0), o_ff = o_ft, o_gt = o_ft, o_gf = o_ft;
-  int o_fr = -1;
+  // The trajectory record of a step is written in two parts, both where this wave is about to wait for the contact wave:
+  // the state (planes 0-2, frame pose / twist) straight from the live registers of the step itself, the total wrench and
+  // the clamp mask of the step's integration (planes 3-4) one step late from eight copies -- instead of one late record
+  // from copies of everything (26 moves per step on this wave's chain)
+  float o_vz = 0.f;
+  v3 o_ft = V3(0, 0, 0), o_ff = o_ft;
   unsigned o_mask = 0u, clamp_mask = 0u;  // which velocity components the step's integration clamped (stored for the adjoint)
-  auto spill = [&](int step) {  // writes what the o_* registers hold for `step`
+  auto spill_state = [&](int step, const BodyState &cs, int cfr) {
     if (!is_body) return;
     float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
-    stg4(tj, boff * 4u, make_float4(o_s.r.x, o_s.r.y, o_s.r.z, o_s.r.w));
-    stg4(tj + (size_t)4 * N, boff * 4u, make_float4(o_s.w.x, o_s.w.y, o_s.w.z, o_s.v.x));
-    stg4(tj + (size_t)8 * N, boff * 4u, make_float4(o_s.p.x, o_s.p.y, o_s.p.z, o_s.v.y));
-    stg4(tj + (size_t)12 * N, boff * 4u, make_float4(o_s.v.z, o_ft.x, o_ft.y, o_ft.z));
-    stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
-    if (o_fr >= 0) {  // frame gather (dp_model.py:1231-1248)
-      float *o = a.wp_pos + ((size_t)o_fr * N + idx) * 7;
-      o[0] = o_s.p.x; o[1] = o_s.p.y; o[2] = o_s.p.z; o[3] = o_s.r.x; o[4] = o_s.r.y; o[5] = o_s.r.z; o[6] = o_s.r.w;
-      o = a.wp_vel + ((size_t)o_fr * N + idx) * 6;
-      o[0] = o_s.w.x; o[1] = o_s.w.y; o[2] = o_s.w.z; o[3] = o_s.v.x; o[4] = o_s.v.y; o[5] = o_s.v.z;
-      if (a.grf) {
-        o = a.grf + ((size_t)o_fr * N + idx) * 6;
-        o[0] = o_gt.x; o[1] = o_gt.y; o[2] = o_gt.z; o[3] = o_gf.x; o[4] = o_gf.y; o[5] = o_gf.z;
-      }
-      if (a.jaf) {
-        o = a.jaf + ((size_t)o_fr * N + idx) * 6;
-        o[0] = o_ft.x - o_gt.x; o[1] = o_ft.y - o_gt.y; o[2] = o_ft.z - o_gt.z;
-        o[3] = o_ff.x - o_gf.x; o[4] = o_ff.y - o_gf.y; o[5] = o_ff.z - o_gf.z;
-      }
+    stg4(tj, boff * 4u, make_float4(cs.r.x, cs.r.y, cs.r.z, cs.r.w));
+    stg4(tj + (size_t)4 * N, boff * 4u, make_float4(cs.w.x, cs.w.y, cs.w.z, cs.v.x));
+    stg4(tj + (size_t)8 * N, boff * 4u, make_float4(cs.p.x, cs.p.y, cs.p.z, cs.v.y));
+    if (cfr >= 0) {  // frame gather (dp_model.py:1231-1248)
+      float *o = a.wp_pos + ((size_t)cfr * N + idx) * 7;
+      o[0] = cs.p.x; o[1] = cs.p.y; o[2] = cs.p.z; o[3] = cs.r.x; o[4] = cs.r.y; o[5] = cs.r.z; o[6] = cs.r.w;
+      o = a.wp_vel + ((size_t)cfr * N + idx) * 6;
+      o[0] = cs.w.x; o[1] = cs.w.y; o[2] = cs.w.z; o[3] = cs.v.x; o[4] = cs.v.y; o[5] = cs.v.z;
     }
+  };
+  auto spill_wrench = [&](int step) {  // what the o_* registers hold for `step`
+    if (!is_body) return;
+    float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
+    stg4(tj + (size_t)12 * N, boff * 4u, make_float4(o_vz, o_ft.x, o_ft.y, o_ft.z));
+    stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
   };
   if (a.nsteps > 0) load_controls(0);
   STAMP_DECL;
@@ -730,10 +728,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (SPLIT) {
       // the previous step's trajectory record and frame outputs are issued where this wave is about to wait anyway (measured
       // against right after hand-over A, and against after the vmcnt wait: -2 % / -0.5 % forward time at 4096 envs)
-      if (step > 0) spill(step - 1);
+      spill_state(step, s, fr);
+      if (step > 0) spill_wrench(step - 1);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
     } else {
-      if (step > 0) spill(step - 1);  // (one step late here too: the record carries the clamp mask of the step's integration)
+      spill_state(step, s, fr);
+      if (step > 0) spill_wrench(step - 1);
       WAVE_SYNC();
     }
     if (is_body) {
@@ -744,8 +744,18 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     const v3 grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
     ft += jt; ff += jf;
-    // the state and the total wrench of this step go to the trajectory for the adjoint, frames to the outputs
-    o_s = s; o_ft = ft; o_ff = ff; o_gt = grf_t; o_gf = grf_f; o_fr = fr;
+    if (fr >= 0 && is_body) {  // force snapshots of a frame step (4 of 100 steps): written here, no copies carried for them
+      if (a.grf) {
+        float *o = a.grf + ((size_t)fr * N + idx) * 6;
+        o[0] = grf_t.x; o[1] = grf_t.y; o[2] = grf_t.z; o[3] = grf_f.x; o[4] = grf_f.y; o[5] = grf_f.z;
+      }
+      if (a.jaf) {
+        float *o = a.jaf + ((size_t)fr * N + idx) * 6;
+        o[0] = ft.x - grf_t.x; o[1] = ft.y - grf_t.y; o[2] = ft.z - grf_t.z;
+        o[3] = ff.x - grf_f.x; o[4] = ff.y - grf_f.y; o[5] = ff.z - grf_f.z;
+      }
+    }
+    o_vz = s.v.z; o_ft = ft; o_ff = ff;  // the total wrench goes to the trajectory with the clamp mask, one step late
     STAMP(3);
     // ---- integrate_bodies
     float sink_rate;
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }
-  if (a.nsteps > 0) spill(a.nsteps - 1);
+  if (a.nsteps > 0) spill_wrench(a.nsteps - 1);
   {  // a frame may name the state after the last step (state_steps[nsteps], dp_model.py:396,1241-1246); no force
      // snapshot exists for it (the reference appends grf / jaf for step in steps_idx only, :1225-1228): zero rows
     const int fr_last = ld_uniform(a.frame_of_step, a.nsteps);
