@@ -16,6 +16,7 @@ enum { PD_JT_REVOLUTE = 1, PD_JT_COMPOUND = 2, PD_JT_FIXED = 4 };  // template m
 
 // LDS strides are odd so that lanes (= bodies) hit distinct banks with 4-byte accesses.
 #define PD_REC 17  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16]
+#define PD_RECF 25 // the forward rollout's record: the same + R[16:25] = rotm(q), row-major (children and contact candidates rotate by it)
 #define PD_ADJ 13  // floats of a body-state adjoint: p q w v
 #define PD_W6 7    // stride of a 6-float wrench slot
 
@@ -39,7 +40,8 @@ struct PdDevModel {
   int list_cap;                                            // ints reserved for the tile list (>= ntiles and >= 2*nb)
   int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
-  int env_lds_floats;                                     // per-env LDS scratch
+  int env_lds_floats;                                     // per-env LDS scratch (adjoint kernels)
+  int env_lds_fwd;                                        // per-env LDS scratch of the forward rollout kernel
   int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (2-role wave-specialised adjoint only)
   int env_lds_bwd3;                                       // per-env LDS scratch of the 3-role adjoint kernel (k_rollout_bwd3)
@@ -87,6 +89,8 @@ struct BodyConst {
   int tile_first, tile_count;
   int small_e[4];  // this lane's entries of the small-body tile list (chunk u: entry u*SEGW + lane)
   int child[4];    // first four children (-1 = none); the rest, if any, are walked from `children`
+  int pidx;        // parent, or 0 for a body without one (a valid record index for unguarded reads)
+  v3 axis_pj;      // rot(q_pj, axis): the joint axis in the parent body's frame
 };
 
 // env: the articulation this lane works for (only read when a per-env joint_X_p is bound: dp_interface.py:465 of the reference)
@@ -98,6 +102,8 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b, int env) {
   const float *xp = m.X_p_env ? m.X_p_env + ((size_t)(env % m.xp_envs) * m.nb + b) * 7 : m.X_p + b * 7;
   c.p_pj = ld3(xp); c.q_pj = ld4(xp + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
+  c.pidx = c.parent >= 0 ? c.parent : 0;
+  c.axis_pj = qrot(c.q_pj, c.axis);
   c.sphere = m.body_sphere[b];
   c.reach = c.sphere.w >= 0.0f ? length(V3(c.sphere.x, c.sphere.y, c.sphere.z) - c.com) + c.sphere.w : 0.0f;
 #pragma unroll
@@ -121,16 +127,26 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b, int env) {
 
 // Returns the cull vector (p_y, Ry): Ry = second row of R(q), so the world height of a body-frame point x is
 // p_y + Ry . x.  It is also stored 16-byte aligned in cull[b] so the sweeps fetch it with one ds_read_b128.
-PD_DEV float4 stage_record(float *rec, float4 *cull, int b, const BodyState &s, v3 rc) {
+// Rm = rotm(s.r): its row 1 (pd_math.h rot_row1, pinned roundings) is what the exact contact test computes heights from, in the
+// forward pass and in the adjoint alike.
+PD_DEV float4 stage_record(float *rec, float4 *cull, int b, const BodyState &s, v3 rc, const float *Rm) {
   float *r = rec + b * PD_REC;
-  // row 1 of the rotation matrix of a unit quaternion (9 flops instead of a full rotation); the cull tests that
-  // consume it carry explicit safety margins, the exact contact test does not use it
-  v3 Ry = V3(2.0f * (s.r.x * s.r.y + s.r.z * s.r.w), 1.0f - 2.0f * (s.r.x * s.r.x + s.r.z * s.r.z),
-             2.0f * (s.r.y * s.r.z - s.r.x * s.r.w));
   r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
   r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
   r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
-  float4 cv = make_float4(s.p.y, Ry.x, Ry.y, Ry.z);
+  float4 cv = make_float4(s.p.y, Rm[3], Rm[4], Rm[5]);
+  cull[b] = cv;
+  return cv;
+}
+// The forward rollout's record (PD_RECF floats): the same plus the rotation matrix.
+PD_DEV float4 stage_record_f(float *rec, float4 *cull, int b, const BodyState &s, v3 rc, const float *Rm) {
+  float *r = rec + b * PD_RECF;
+  r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
+  r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
+  r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r[16 + k] = Rm[k];
+  float4 cv = make_float4(s.p.y, Rm[3], Rm[4], Rm[5]);
   cull[b] = cv;
   return cv;
 }
@@ -171,12 +187,12 @@ PD_DEV void fk_joint_local(const BodyConst &c, const float *jq, const float *jqd
   }
 }
 
-template <int JT>
+template <int JT, int RS = PD_REC>
 PD_DEV BodyState fk_joint(const BodyConst &c, const float *jq, const float *jqd, const float *rec) {
   v3 p_wp = V3(0, 0, 0), w_wp = V3(0, 0, 0), v_wp = V3(0, 0, 0);
   qt q_wp = Q4(0, 0, 0, 1);
   if (c.parent >= 0) {
-    const float *r = rec + c.parent * PD_REC;
+    const float *r = rec + c.parent * RS;
     p_wp = ld3(r); q_wp = ld4(r + 3); w_wp = ld3(r + 7); v_wp = ld3(r + 10);
   }
   FkLocals L;
@@ -258,12 +274,14 @@ PD_DEV BodyAdj fk_joint_adj(const BodyConst &c, const float *jq, const float *jq
 // Returns false when the point is above ground (the kernel's early return, :132-133).
 struct ContactOut { v3 t, f; };
 
-PD_DEV bool contact_point_fwd(const float *r, float4 P, float4 mat, ContactOut &o) {
-  v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
-  qt q = ld4(r + 3);
-  v3 cp = (p + qrot(q, V3(P.x, P.y, P.z))) - V3(0.f, P.w, 0.f);
-  float c = cp.y;
-  if (c > 0.0f) return false;
+// r = the body's forward record (PD_RECF: rotation matrix at r[16]), cv = its cull vector (p_y, row 1 of that matrix).
+// Branch-free, so that the compiler can schedule it into the joint pass of the same wave: everything is computed, the return
+// value says whether the point touches (c <= 0 or NaN -- the reference continues past `if c > 0: return` for a NaN too).
+PD_DEV bool contact_point_fwd(const float *r, float4 cv, float4 P, float4 mat, ContactOut &o) {
+  const v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
+  const float *R = r + 16;
+  const float c = contact_height(cv, P);
+  const v3 cp = V3(p.x + (R[0] * P.x + R[1] * P.y + R[2] * P.z), c, p.z + (R[6] * P.x + R[7] * P.y + R[8] * P.z));
   v3 rr = cp - (p + rc);
   v3 dpdt = v + cross(w, rr);
   float ke = mat.x, kd = mat.y, kf = mat.z, mu = mat.w;
@@ -276,15 +294,16 @@ PD_DEV bool contact_point_fwd(const float *r, float4 P, float4 mat, ContactOut &
   v3 f = clamp3(V3(ft.x, (fn + fd) + ft.y, ft.z), 500.0f);
   o.f = f;
   o.t = cross(rr, f);
-  return true;
+  return !(c > 0.0f);
 }
 
 // Adjoint: g_t, g_f = adjoint of the body's wrench accumulator; returns the contribution to (p,q,w,v).
 // MAT: the four rotations by the body's quaternion (two forward, two adjoint) through one matrix and one matrix adjoint
 // (pd_math.h: rotm).  Measured: -2.3 % adjoint time where the contacts run inline on the integrate wave (quad 8192), +3 % on the
 // revolute kernel's contact wave (Laikago 4096) -- so the caller chooses.
+// cv = the body's cull vector as staged (p_y, row 1 of rotm(q)): the height, and with it "touching", is the forward pass's bit for bit.
 template <bool MAT = false>
-PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g_f, BodyAdj &out) {
+PD_DEV bool contact_point_adj(const float *r, float4 cv, float4 P, float4 mat, v3 g_t, v3 g_f, BodyAdj &out) {
   v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
   qt q = ld4(r + 3);
   float M[9];
@@ -293,11 +312,11 @@ PD_DEV bool contact_point_adj(const float *r, float4 P, float4 mat, v3 g_t, v3 g
     rotm(q, M);
     com = matT_vec(M, rc);
     cp = (p + mat_vec(M, cpt)) - V3(0.f, P.w, 0.f);
-    cp.y = (p.y + qrot_y(q, cpt)) - P.w;  // the height decides "touching": exactly the forward pass's arithmetic
   } else {
     com = qrot_inv(q, rc);  // body-frame COM back from the staged rc = rot(q, com): no table read on the hit path
     cp = (p + qrot(q, cpt)) - V3(0.f, P.w, 0.f);
   }
+  cp.y = contact_height(cv, P);  // the height decides "touching": exactly the forward pass's arithmetic
   float c = cp.y;
   if (c > 0.0f) return false;
   v3 rr = cp - (p + rc);
@@ -410,14 +429,15 @@ struct JointCtx {  // locals shared by the forward and the adjoint
 // `if (parent)` regions then cost no exec-mask code and no moves that merge their results with the values of lanes outside them
 // (-62 instructions per adjoint step), and the compound joint's six quaternion products with q_off drop out of the adjoint
 // (x * identity is x exactly; -5 % adjoint time for human / quad).  The forward pass keeps its products: its arithmetic is frozen.
-template <bool HP = false>
+template <bool HP = false, int RS = PD_REC>
 PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, JointCtx &j) {
   j.pp = V3(0, 0, 0); j.qp = Q4(0, 0, 0, 1); j.x_p = c.p_pj; j.q_p = c.q_pj;
   j.r_p = V3(0, 0, 0); j.w_p = V3(0, 0, 0); j.v_p = V3(0, 0, 0);
   if (HP || c.parent >= 0) {  // :326-333
-    const float *r = rec + c.parent * PD_REC;
+    const float *r = rec + (HP ? c.pidx : c.parent) * RS;
     j.pp = ld3(r); j.qp = ld4(r + 3); j.w_p = ld3(r + 7); j.v_p = ld3(r + 10);
-    j.x_p = j.pp + qrot(j.qp, c.p_pj);
+    // forward record: the parent staged rotm(qp) beside its pose (9 products instead of a 23-instruction quaternion rotation)
+    j.x_p = j.pp + (RS == PD_RECF ? mat_vec(r + 16, c.p_pj) : qrot(j.qp, c.p_pj));
     j.q_p = qmul(j.qp, c.q_pj);
     j.r_p = j.x_p - (j.pp + ld3(r + 13));
   }
@@ -432,11 +452,14 @@ PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const flo
 // with the identity child frame, the rotated basis as matrix columns, the axis chain with its zero components taken out, one
 // matrix for the three axis rotations: the same terms minus products with exact zeros, ~200 instructions less per joint.
 // Only the compound-only instantiation sets it: the revolute forward pass (Laikago) stays bit for bit what round 1 shipped.
-template <int JT, bool PLAINC = false>
-PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
+// Rm = rotm(s.r) of this body (the integration made it for the staging); rec = forward records (PD_RECF).  HP: plain model
+// (joint_ctx) -- the call may then run for EVERY lane, unguarded: a lane without a joint (the FREE root, idle lanes) computes
+// on the record of body c.pidx = 0 and the caller drops its result.
+template <int JT, bool PLAINC = false, bool HP = PLAINC>
+PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *Rm, const float *rec, const float *tgt,
                       const float *act, const float *ke, const float *kd, v3 &wp_t, v3 &wp_f, v3 &wc_t, v3 &wc_f) {
   JointCtx j;
-  joint_ctx<PLAINC>(c, s, rc_c, rec, j);
+  joint_ctx<HP, PD_RECF>(c, s, rc_c, rec, j);
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {  // :385-390
@@ -444,8 +467,10 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     f_total += j.x_err * ake + j.v_err * akd;
     t_total += qrot(j.q_p, ang_err) * ake + j.w_err * (akd * ads);
   }
-  if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {  // :392-409
-    v3 axis_p = qrot(j.q_p, c.axis), axis_c = qrot(s.r, c.axis);
+  if ((JT & PD_JT_REVOLUTE) && (HP || c.type == PD_JOINT_REVOLUTE)) {  // :392-409
+    // rot(q_p, axis) = rotm(qp) (rotm(q_pj) axis): the inner product is a per-body constant (c.axis_pj)
+    const float *Rp = rec + (HP ? c.pidx : (c.parent >= 0 ? c.parent : 0)) * PD_RECF + 16;
+    v3 axis_p = (HP || c.parent >= 0) ? mat_vec(Rp, c.axis_pj) : c.axis_pj, axis_c = mat_vec(Rm, c.axis);
     v3 a = c.axis * dot(qvec(j.r_err), c.axis);
     qt twist = qnormalize(Q4(a.x, a.y, a.z, j.r_err.w));
     float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
@@ -849,16 +874,18 @@ PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState
 // the adjoint takes the clamp's pass / block decision from it -- recomputing w1 there through rotm(q) instead of qrot can land
 // on the other side of +-10 by an ulp, and a rollout that sits on the clamps (a robot dropped into the ground) then differentiates
 // a different function (found by the randomised sweep: one env of 3 200 off by 6 % in every gradient).
-PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc, v3 t0, v3 f0, float inv_m,
-                               const float *I, const float *invI, float dt, v3 &rc_out, float &sink_rate, unsigned &clamp_mask) {
+PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *Rm, v3 rc, v3 t0, v3 f0, float inv_m,
+                               const float *I, const float *invI, float dt, float *R1, v3 &rc_out, float &sink_rate, unsigned &clamp_mask) {
+  // Rm = rotm(s.r) (pd_math.h): the four rotations by the body's quaternion are matrix products, exactly as the adjoint
+  // recomputes them (integrate_adj2); R1 = rotm of the new quaternion, for the staging, the joints and the next step
   v3 g = V3(m.gx, m.gy, m.gz);
   float nz = inv_m != 0.0f ? 1.0f : 0.0f;
   v3 x_com = s.p + rc;                                          // :61
   v3 v1 = s.v + (f0 * inv_m + g * nz) * dt;                     // :64
   v3 x1 = x_com + v1 * dt;                                      // :65
-  v3 wb = qrot_inv(s.r, s.w);                                   // :68
-  v3 tb = qrot_inv(s.r, t0) - cross(wb, mat_vec(I, wb));        // :69
-  v3 w1 = qrot(s.r, wb + mat_vec(invI, tb) * dt);               // :71
+  v3 wb = matT_vec(Rm, s.w);                                    // :68
+  v3 tb = matT_vec(Rm, t0) - cross(wb, mat_vec(I, wb));         // :69
+  v3 w1 = mat_vec(Rm, wb + mat_vec(invI, tb) * dt);             // :71
   qt r1 = qnormalize(s.r + qmul(Q4(w1.x, w1.y, w1.z, 0.f), s.r) * (0.5f * dt));  // :72
   sink_rate = fabsf(v1.y) + (fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z)) * c.reach;
   w1 = w1 * (1.0f - 0.1f * dt);                                 // :75
@@ -867,7 +894,8 @@ PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const Bo
   clamp_mask = (clamp_pass(w1.x, -10.0f, 10.0f) == 0.0f ? 1u : 0u) | (clamp_pass(w1.y, -10.0f, 10.0f) == 0.0f ? 2u : 0u) |
                (clamp_pass(w1.z, -10.0f, 10.0f) == 0.0f ? 4u : 0u) | (clamp_pass(v1.x, -10.0f, 10.0f) == 0.0f ? 8u : 0u) |
                (clamp_pass(v1.y, -10.0f, 10.0f) == 0.0f ? 16u : 0u) | (clamp_pass(v1.z, -10.0f, 10.0f) == 0.0f ? 32u : 0u);
-  rc_out = qrot(r1, c.com);
+  rotm(r1, R1);
+  rc_out = mat_vec(R1, c.com);
   o.r = r1; o.p = x1 - rc_out;                                  // :90
   return o;
 }

@@ -150,11 +150,28 @@ PD_DEV void adj_q_axis_angle_ang(v3 axis, float ang, float &adj_ang, qt g) {
 // map of the formula above, (2w^2 - 1) I + 2w [u]x + 2 u u^T, not a normalised rotation.  Where one quaternion rotates
 // several vectors in a step, 22 instructions for the matrix + 9 per vector replace 23 per vector, and in the adjoint
 // 9 (outer product into adj_M) + 9 (transposed product) per vector + one rotm_adj replace ~70 per vector.
+// Row 1 of rotm(q) -- the world-up row: the height of a body-frame point x is p_y + row1 . x -- with its roundings PINNED
+// (no contraction beyond the explicit fma): the forward pass decides "this contact point touches" on a height computed from
+// this row, and the adjoint, which recomputes it from the stored quaternion in another kernel, must land on the same side.
+PD_DEV void rot_row1(qt q, float &a, float &b, float &c) {
+#pragma clang fp contract(off)
+  const float s = __builtin_fmaf(2.0f * q.w, q.w, -1.0f), tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
+  const float wz = tz * q.w, wx = tx * q.w;
+  a = __builtin_fmaf(tx, q.y, wz);
+  b = __builtin_fmaf(ty, q.y, s);
+  c = __builtin_fmaf(ty, q.z, -wx);
+}
+// Height above ground of contact candidate P = (x, y, z, dist) of a body with cull vector cv = (p_y, row 1 of rotm(q)):
+// integrator_euler.py:118-121 with n = +y.  Pinned like rot_row1: every kernel gets the same bits from the same (cv, P).
+PD_DEV float contact_height(float4 cv, float4 P) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(cv.w, P.z, __builtin_fmaf(cv.z, P.y, __builtin_fmaf(cv.y, P.x, cv.x))) - P.w;
+}
 PD_DEV void rotm(qt q, float *M) {
   const float s = 2.0f * q.w * q.w - 1.0f, tx = 2.0f * q.x, ty = 2.0f * q.y, tz = 2.0f * q.z;
   const float xy = tx * q.y, xz = tx * q.z, yz = ty * q.z, wx = tx * q.w, wy = ty * q.w, wz = tz * q.w;
   M[0] = s + tx * q.x; M[1] = xy - wz; M[2] = xz + wy;
-  M[3] = xy + wz; M[4] = s + ty * q.y; M[5] = yz - wx;
+  rot_row1(q, M[3], M[4], M[5]);
   M[6] = xz - wy; M[7] = yz + wx; M[8] = s + tz * q.z;
 }
 // adj_q += d<A, rotm(q)>/dq for the accumulated matrix adjoint A

@@ -13,6 +13,8 @@ cfgs = [("laikago", 4096, 16), ("laikago", 4096, 32), ("laikago", 4096, 64), ("l
 variant = int(os.environ.get("PD_VARIANT", "0"))
 hip_backend.lib().pd_debug_set_variant(variant)
 hip_backend.lib().pd_debug_set_groups(int(os.environ.get("PD_GROUPS", "0")))  # env groups per workgroup, 0 = automatic
+if "PD_FUSE" in os.environ and hasattr(hip_backend.lib(), "pd_debug_set_fuse"):
+    hip_backend.lib().pd_debug_set_fuse(int(os.environ["PD_FUSE"]))  # forward contact evaluation on the body wave: 1 / 0, default automatic
 if len(sys.argv) > 1:
     cfgs = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:]]
 dev = torch.device("cuda:0")

@@ -1,0 +1,47 @@
+// Microbenchmark: ISSUE cost in shader cycles (s_memtime) of v_fma_f32 vs v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for ONE wave's
+// stream, 1 and 2 waves per SIMD, 8 independent chains per lane.  Cycles, not wall time: the clock ramps and sags.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ void k(float *out, unsigned long long *cyc, int iters) {
+  f2 a[8];
+  for (int i = 0; i < 8; ++i) a[i] = f2{(float)threadIdx.x + i, (float)threadIdx.x - i};
+  const f2 m = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (MODE == 1) a[j] = __builtin_elementwise_fma(a[j], m, c);
+        else if (MODE == 2) a[j] = a[j] * m;
+        else if (MODE == 3) a[j] = a[j] + c;
+        else a[j].x = __builtin_fmaf(a[j].x, 1.0001f, 0.5f);
+      }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  f2 s = {0, 0};
+  for (int i = 0; i < 8; ++i) s += a[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int MODE>
+void run(float *d, unsigned long long *c, int wps) {
+  const int iters = 20000;
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, d, c, iters);
+  (void)hipDeviceSynchronize();
+  unsigned long long h[256];
+  (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
+  double avg = 0;
+  for (int i = 0; i < 256; ++i) avg += (double)h[i];
+  const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"};
+  printf("%-13s waves/SIMD %d : %.2f shader cycles per instruction per wave\n", names[MODE], wps, avg / 256.0 / ((double)iters * 64));
+}
+int main() {
+  float *d; unsigned long long *c;
+  (void)hipMalloc(&d, 1 << 22); (void)hipMalloc(&c, 256 * 8);
+  for (int wps : {1, 2, 4}) { run<0>(d, c, wps); run<1>(d, c, wps); run<2>(d, c, wps); run<3>(d, c, wps); }
+  return 0;
+}
