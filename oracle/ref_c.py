@@ -60,6 +60,11 @@ class RefC:
         Appendix A.1 recalls Warp.  Process-wide switch of this precision's library: reset it after use."""
         self.lib.ref_set_acos_policy(1 if unguarded else 0)
 
+    def set_state_rounding(self, on):
+        """1 / True: rollout_forward rounds every stored state to fp32; 2: to an adjacent fp32 number (ref_set_state_rounding in diffphys_ref.c).  Process-wide switch
+        of this precision's library: reset it after use."""
+        self.lib.ref_set_state_rounding(int(on))
+
     def num_threads(self):
         return int(self.lib.ref_num_threads())
 
@@ -107,6 +112,32 @@ class RefC:
             self._p(g["torques"]), self._p(g["res_f"]), self._p(g["refs"]), self._p(g["target_ke"]), self._p(g["target_kd"]),
             self._p(g["body_inv_mass"]), self._p(g["body_inertia"]), self._p(g["body_inv_inertia"]))
         return g
+
+    def singularity_probe(self, st):
+        """[nsteps, bs, 4] for a trajectory returned by rollout_forward: min |contact height|, min distance of a pre-clamp
+        velocity component from +-10, min |a - b| of the Coulomb switch over touching points, min 1 - |twist.w| over revolute
+        joints (see ref_singularity_probe in diffphys_ref.c)."""
+        a, bs, nsteps = st["_inputs"], st["_bs"], st["_nsteps"]
+        out = np.zeros((nsteps, bs, 4), dtype=self.dtype)
+        self.lib.ref_singularity_probe(self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self.real(st["_dt"]), self._p(st["states_q"]),
+                                       self._p(st["states_qd"]), self._p(st["states_f"]), self._p(a["body_inv_mass"]),
+                                       self._p(a["body_inertia"]), self._p(a["body_inv_inertia"]), self._p(out))
+        return out
+
+    def branch_log(self, st, inp=None):
+        """Discrete decisions per (step, env, body) of a trajectory: touching contact candidates, how many of them slide on the
+        kf |vt| friction branch, velocity clamp mask (see ref_branch_log in diffphys_ref.c).  st: what rollout_forward returned,
+        or any dict with states_q / states_qd / states_f (e.g. a trajectory the GPU kernel saved) plus `inp` for the inputs."""
+        a = st["_inputs"] if "_inputs" in st else {k: self._c(inp[k]) for k in ("body_inv_mass", "body_inertia", "body_inv_inertia")}
+        sq, sd, sf = self._c(st["states_q"]), self._c(st["states_qd"]), self._c(st["states_f"])
+        nsteps = sf.shape[0]
+        bs = sf.shape[1] // self.nb
+        dt = st["_dt"] if "_dt" in st else inp["dt"]
+        out = [np.zeros((nsteps, bs, self.nb), dtype=np.int32) for _ in range(3)]
+        self.lib.ref_branch_log(self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self.real(dt), self._p(sq), self._p(sd), self._p(sf),
+                                self._p(a["body_inv_mass"]), self._p(a["body_inertia"]), self._p(a["body_inv_inertia"]),
+                                self._p(out[0]), self._p(out[1]), self._p(out[2]))
+        return dict(touch=out[0], slide=out[1], clamp=out[2])
 
     def fk_forward(self, joint_q, joint_qd):
         """joint_q [n,nq], joint_qd [n,nqd] -> body_q [n,nb,7], body_qd [n,nb,6]"""

@@ -115,6 +115,12 @@ static inline qt q_axis_angle(v3 axis, real ang) {
  * gradients (scrubbed to 0 by remove_nan at the boundary) for an env whose joint passes through angle 0 in fp32. */
 static int g_acos_unguarded = 0;
 void ref_set_acos_policy(int unguarded) { g_acos_unguarded = unguarded; }
+/* Conditioning probe (tests): with this on, ref_rollout_forward rounds every state it stores to fp32 (value kept in `real`).  In
+ * the float64 build that is the LEAST any fp32 implementation does to a rollout -- one rounding per state component and step,
+ * exact arithmetic otherwise -- so how far the gradients of an env move under it measures how ill-conditioned the env is.
+ * 2 = the same with each value moved to an adjacent fp32 number (alternating sides): a second sample of the same perturbation. */
+static int g_round_states = 0;
+void ref_set_state_rounding(int on) { g_round_states = on; }
 int ref_get_acos_policy(void) { return g_acos_unguarded; }
 static inline real inv_sqrt_1mx2(real x) {
   real d = R_SQRT((real)1 - x * x);
@@ -818,6 +824,135 @@ static void integrate_adj(const RefTemplate *t, const real *body_q, const real *
  *   inv_mass [bs*nb], inertia / inv_inertia [bs*nb][9].
  * Stored trajectory: states_q [T+1][bs*nb][7], states_qd [T+1][bs*nb][6], states_f [T][bs*nb][6].
  * Outputs at frames: wp_pos [F][bs*nb][7], wp_vel [F][bs*nb][6], grf / jaf [F][bs*nb][6]. */
+/* ------------------------------------------------------------------- singularity probe (test diagnostics)
+ * Where the step function is not differentiable, an fp32 evaluation one ulp away may differentiate the other branch: the
+ * gradient then jumps by a stiffness (ke = 1e4 N/m for a contact) while every value stays within rounding.  For each
+ * (step, env) of a stored trajectory this reports how close the step sits to such a set:
+ *   out[0]  min over contact candidates of |c|, the height whose sign decides "touching" (integrator_euler.py:130-133), metres
+ *   out[1]  min over bodies and components of | |x| - 10 | for the velocities BEFORE the clamp of :78-88 (w1 after damping, v1)
+ *   out[2]  min over TOUCHING candidates of |kf |vt| - mu (fn + fd) ... | i.e. |a_ - b_| of the Coulomb switch (:160-165), newtons
+ *   out[3]  min over revolute joints of 1 - |twist.w|: the acos / its guarded adjoint at joint angle 0 (:398-400)
+ * layout out[(step * bs + env) * 4 + k].  tests/test_gpu_tight.py uses it to EXPLAIN every env whose fp32 gradient is off. */
+void ref_singularity_probe(const RefTemplate *t, int bs, int nsteps, real dt, const real *states_q, const real *states_qd,
+                           const real *states_f, const real *inv_mass, const real *inertia, const real *inv_inertia, real *out) {
+  const int nb = t->nb;
+  const size_t SQ = (size_t)bs * nb * 7, SD = (size_t)bs * nb * 6;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < bs; ++e) {
+    size_t oq = (size_t)e * nb * 7, od = (size_t)e * nb * 6;
+    for (int s = 0; s < nsteps; ++s) {
+      const real *bq = states_q + s * SQ + oq, *bqd = states_qd + s * SD + od, *bf = states_f + s * SD + od;
+      real c_min = (real)1e30, cl_min = (real)1e30, fr_min = (real)1e30, ac_min = (real)1e30;
+      for (int k = 0; k < t->nc; ++k) {
+        int b = t->c_body[k];
+        v3 p = ld3(bq + b * 7); qt q = ld4(bq + b * 7 + 3);
+        v3 w = ld3(bqd + b * 6), v = ld3(bqd + b * 6 + 3);
+        v3 cp = vadd(p, qrot(q, ld3(t->c_point + k * 3)));
+        real c = cp.y - t->c_dist[k];
+        real ac = c < 0 ? -c : c;
+        if (ac < c_min) c_min = ac;
+        if (c > (real)0) continue;
+        v3 r = vsub(V(cp.x, c, cp.z), vadd(p, qrot(q, ld3(t->com + b * 3))));
+        v3 dpdt = vadd(v, vcross(w, r));
+        const real *mat = t->materials + t->c_mat[k] * 4;
+        real vn = dpdt.y;
+        v3 vt = V(dpdt.x, 0, dpdt.z);
+        real fn = c * mat[0], fd = (vn < (real)0 ? vn : (real)0) * mat[1] * (c < (real)0 ? (real)1 : (real)0);
+        real d = mat[2] * vlen(vt) - ((real)0 - mat[3] * (fn + fd));
+        if (d < 0) d = -d;
+        if (d < fr_min) fr_min = d;
+      }
+      for (int i = 0; i < nb; ++i) {
+        v3 x0 = ld3(bq + i * 7); qt r0 = ld4(bq + i * 7 + 3);
+        v3 w0 = ld3(bqd + i * 6), v0 = ld3(bqd + i * 6 + 3);
+        v3 t0 = ld3(bf + i * 6), f0 = ld3(bf + i * 6 + 3);
+        v3 g = ld3(t->gravity);
+        real im = inv_mass[(size_t)e * nb + i]; real nz = im != (real)0 ? (real)1 : (real)0;
+        (void)x0;
+        v3 v1 = vadd(v0, vscale(vadd(vscale(f0, im), vscale(g, nz)), dt));
+        v3 wb = qrot_inv(r0, w0);
+        v3 Iwb; mat_vec(inertia + ((size_t)e * nb + i) * 9, wb, &Iwb);
+        v3 tb = vsub(qrot_inv(r0, t0), vcross(wb, Iwb));
+        v3 a; mat_vec(inv_inertia + ((size_t)e * nb + i) * 9, tb, &a);
+        v3 w1 = vscale(qrot(r0, vadd(wb, vscale(a, dt))), (real)1 - (real)0.1 * dt);
+        real comps[6] = {w1.x, w1.y, w1.z, v1.x, v1.y, v1.z};
+        for (int k = 0; k < 6; ++k) {
+          real d = (comps[k] < 0 ? -comps[k] : comps[k]) - (real)10;
+          if (d < 0) d = -d;
+          if (d < cl_min) cl_min = d;
+        }
+        if (t->joint_type[i] == JOINT_REVOLUTE) {
+          int par = t->joint_parent[i];
+          qt q_p = ld4(t->X_p + i * 7 + 3);
+          if (par >= 0) q_p = qmul(ld4(bq + par * 7 + 3), q_p);
+          qt r_err = qmul(qconj(q_p), r0);
+          v3 ax = ld3(t->axis + i * 3);
+          v3 av = vscale(ax, vdot(qv(r_err), ax));
+          qt tw = qnormalize(Q(av.x, av.y, av.z, r_err.w));
+          real d = (real)1 - (tw.w < 0 ? -tw.w : tw.w);
+          if (d < ac_min) ac_min = d;
+        }
+      }
+      real *o = out + ((size_t)s * bs + e) * 4;
+      o[0] = c_min; o[1] = cl_min; o[2] = fr_min; o[3] = ac_min;
+    }
+  }
+}
+
+/* Branch log (test diagnostics): the discrete decisions of each step of a stored trajectory, per (step, env, body):
+ *   touch[..]  number of the body's contact candidates with c <= 0 (integrator_euler.py:130-133)
+ *   slide[..]  number of those whose friction is the kf |vt| branch of the min (:160-165)
+ *   clamp[..]  6-bit mask of the velocity components that :78-88 clamps (w.x w.y w.z v.x v.y v.z), recomputed from
+ *              (state, body_f) of the step
+ * Two evaluations of a rollout that agree on all of these differentiate the same smooth function. */
+void ref_branch_log(const RefTemplate *t, int bs, int nsteps, real dt, const real *states_q, const real *states_qd,
+                    const real *states_f, const real *inv_mass, const real *inertia, const real *inv_inertia, int *touch, int *slide,
+                    int *clamp) {
+  const int nb = t->nb;
+  const size_t SQ = (size_t)bs * nb * 7, SD = (size_t)bs * nb * 6;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < bs; ++e) {
+    size_t oq = (size_t)e * nb * 7, od = (size_t)e * nb * 6;
+    for (int s = 0; s < nsteps; ++s) {
+      const real *bq = states_q + s * SQ + oq, *bqd = states_qd + s * SD + od, *bf = states_f + s * SD + od;
+      int *to = touch + ((size_t)s * bs + e) * nb, *so = slide + ((size_t)s * bs + e) * nb, *co = clamp + ((size_t)s * bs + e) * nb;
+      for (int i = 0; i < nb; ++i) { to[i] = 0; so[i] = 0; co[i] = 0; }
+      for (int k = 0; k < t->nc; ++k) {
+        int b = t->c_body[k];
+        v3 p = ld3(bq + b * 7); qt q = ld4(bq + b * 7 + 3);
+        v3 w = ld3(bqd + b * 6), v = ld3(bqd + b * 6 + 3);
+        v3 cp = vadd(p, qrot(q, ld3(t->c_point + k * 3)));
+        real c = cp.y - t->c_dist[k];
+        if (c > (real)0) continue;
+        to[b]++;
+        v3 r = vsub(V(cp.x, c, cp.z), vadd(p, qrot(q, ld3(t->com + b * 3))));
+        v3 dpdt = vadd(v, vcross(w, r));
+        const real *mat = t->materials + t->c_mat[k] * 4;
+        real vn = dpdt.y;
+        v3 vt = V(dpdt.x, 0, dpdt.z);
+        real fn = c * mat[0], fd = (vn < (real)0 ? vn : (real)0) * mat[1] * (c < (real)0 ? (real)1 : (real)0);
+        if (mat[2] * vlen(vt) < (real)0 - mat[3] * (fn + fd)) so[b]++;
+      }
+      for (int i = 0; i < nb; ++i) {
+        qt r0 = ld4(bq + i * 7 + 3);
+        v3 w0 = ld3(bqd + i * 6), v0 = ld3(bqd + i * 6 + 3);
+        v3 t0 = ld3(bf + i * 6), f0 = ld3(bf + i * 6 + 3);
+        v3 g = ld3(t->gravity);
+        real im = inv_mass[(size_t)e * nb + i]; real nz = im != (real)0 ? (real)1 : (real)0;
+        v3 v1 = vadd(v0, vscale(vadd(vscale(f0, im), vscale(g, nz)), dt));
+        v3 wb = qrot_inv(r0, w0);
+        v3 Iwb; mat_vec(inertia + ((size_t)e * nb + i) * 9, wb, &Iwb);
+        v3 tb = vsub(qrot_inv(r0, t0), vcross(wb, Iwb));
+        v3 a; mat_vec(inv_inertia + ((size_t)e * nb + i) * 9, tb, &a);
+        v3 w1 = vscale(qrot(r0, vadd(wb, vscale(a, dt))), (real)1 - (real)0.1 * dt);
+        real comps[6] = {w1.x, w1.y, w1.z, v1.x, v1.y, v1.z};
+        for (int k = 0; k < 6; ++k)
+          if (comps[k] < (real)-10 || comps[k] > (real)10) co[i] |= 1 << k;
+      }
+    }
+  }
+}
+
 void ref_rollout_forward(const RefTemplate *t, int bs, int nsteps, real dt, const real *q_init, const real *qd_init,
                          const real *torques, const real *res_f, const real *refs, const real *target_ke,
                          const real *target_kd, const real *inv_mass, const real *inertia, const real *inv_inertia,
@@ -847,6 +982,12 @@ void ref_rollout_forward(const RefTemplate *t, int bs, int nsteps, real dt, cons
         for (int k = 0; k < nb * 6; ++k) jaf[fr * SD + od + k] = bf[k] - grf[fr * SD + od + k];
       integrate_fwd(t, bq, bqd, bf, inv_mass + (size_t)e * nb, inertia + (size_t)e * nb * 9, inv_inertia + (size_t)e * nb * 9,
                     dt, states_q + (s + 1) * SQ + oq, states_qd + (s + 1) * SD + od);
+      if (g_round_states) {
+        real *nq_ = states_q + (s + 1) * SQ + oq, *nd_ = states_qd + (s + 1) * SD + od;
+        /* mode 1: round to nearest; mode 2: the fp32 neighbour on alternating sides of that (a second sample of the same size) */
+        for (int k = 0; k < nb * 7; ++k) { float f = (float)nq_[k]; nq_[k] = (real)(g_round_states == 2 ? nextafterf(f, (k & 1) ? -INFINITY : INFINITY) : f); }
+        for (int k = 0; k < nb * 6; ++k) { float f = (float)nd_[k]; nd_[k] = (real)(g_round_states == 2 ? nextafterf(f, (k & 1) ? INFINITY : -INFINITY) : f); }
+      }
     }
     /* a frame may name state_steps[nsteps] (dp_model.py:396 allocates it, :1241-1246 would read it); no force snapshot
      * exists for that state (:1225-1228), the caller's zero-initialised grf / jaf rows stay zero */

@@ -13,7 +13,6 @@
 // Forward sweeps log their hit list (count + up to PD_HITLOG-1 entries) so that the adjoint replays it instead of
 // repeating the three cull levels; count -1 = did not fit, the adjoint then culls again for that wave.
 #define PD_HITLOG 32
-#define PD_HIT_CAP_TILES_HOST 8  // = PD_HIT_CAP_TILES of pd_kernels.hip: candidate-list capacity in units of the segment width
 
 enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
 
@@ -66,7 +65,6 @@ struct RolloutArgs {
   float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
   int *hitlog;              // workspace tail: per (step, env) the compacted contact hit list of the forward sweep
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
-  int fuse;                 // forward: the body wave evaluates the contact candidates itself (its helper shares its SIMD)
   int variant;              // A/B experiments (pd_debug_set_variant, not in the public header): which adjoint kernel a revolute robot runs
 };
 

@@ -16,7 +16,6 @@ enum { PD_JT_REVOLUTE = 1, PD_JT_COMPOUND = 2, PD_JT_FIXED = 4 };  // template m
 
 // LDS strides are odd so that lanes (= bodies) hit distinct banks with 4-byte accesses.
 #define PD_REC 17  // floats per staged body record: p[0:3] q[3:7] w[7:10] v[10:13] rc[13:16]
-#define PD_RECF 25 // the forward rollout's record: the same + R[16:25] = rotm(q), row-major (children and contact candidates rotate by it)
 #define PD_ADJ 13  // floats of a body-state adjoint: p q w v
 #define PD_W6 7    // stride of a 6-float wrench slot
 
@@ -40,8 +39,7 @@ struct PdDevModel {
   int list_cap;                                            // ints reserved for the tile list (>= ntiles and >= 2*nb)
   int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
-  int env_lds_floats;                                     // per-env LDS scratch (adjoint kernels)
-  int env_lds_fwd;                                        // per-env LDS scratch of the forward rollout kernel
+  int env_lds_floats;                                     // per-env LDS scratch
   int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (2-role wave-specialised adjoint only)
   int env_lds_bwd3;                                       // per-env LDS scratch of the 3-role adjoint kernel (k_rollout_bwd3)
@@ -90,7 +88,7 @@ struct BodyConst {
   int small_e[4];  // this lane's entries of the small-body tile list (chunk u: entry u*SEGW + lane)
   int child[4];    // first four children (-1 = none); the rest, if any, are walked from `children`
   int pidx;        // parent, or 0 for a body without one (a valid record index for unguarded reads)
-  v3 axis_pj;      // rot(q_pj, axis): the joint axis in the parent body's frame
+  float alen;      // |axis| (1 for every URDF-imported joint)
 };
 
 // env: the articulation this lane works for (only read when a per-env joint_X_p is bound: dp_interface.py:465 of the reference)
@@ -103,7 +101,7 @@ PD_DEV BodyConst load_body_const(const PdDevModel &m, int b, int env) {
   c.p_pj = ld3(xp); c.q_pj = ld4(xp + 3); c.q_off = ld4(m.X_c + b * 7 + 3);
   c.com_par = c.parent >= 0 ? ld3(m.com + c.parent * 3) : V3(0, 0, 0);
   c.pidx = c.parent >= 0 ? c.parent : 0;
-  c.axis_pj = qrot(c.q_pj, c.axis);
+  c.alen = length(c.axis);
   c.sphere = m.body_sphere[b];
   c.reach = c.sphere.w >= 0.0f ? length(V3(c.sphere.x, c.sphere.y, c.sphere.z) - c.com) + c.sphere.w : 0.0f;
 #pragma unroll
@@ -134,18 +132,6 @@ PD_DEV float4 stage_record(float *rec, float4 *cull, int b, const BodyState &s, 
   r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
   r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
   r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
-  float4 cv = make_float4(s.p.y, Rm[3], Rm[4], Rm[5]);
-  cull[b] = cv;
-  return cv;
-}
-// The forward rollout's record (PD_RECF floats): the same plus the rotation matrix.
-PD_DEV float4 stage_record_f(float *rec, float4 *cull, int b, const BodyState &s, v3 rc, const float *Rm) {
-  float *r = rec + b * PD_RECF;
-  r[0] = s.p.x; r[1] = s.p.y; r[2] = s.p.z; r[3] = s.r.x; r[4] = s.r.y; r[5] = s.r.z; r[6] = s.r.w;
-  r[7] = s.w.x; r[8] = s.w.y; r[9] = s.w.z; r[10] = s.v.x; r[11] = s.v.y; r[12] = s.v.z;
-  r[13] = rc.x; r[14] = rc.y; r[15] = rc.z;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) r[16 + k] = Rm[k];
   float4 cv = make_float4(s.p.y, Rm[3], Rm[4], Rm[5]);
   cull[b] = cv;
   return cv;
@@ -187,12 +173,12 @@ PD_DEV void fk_joint_local(const BodyConst &c, const float *jq, const float *jqd
   }
 }
 
-template <int JT, int RS = PD_REC>
+template <int JT>
 PD_DEV BodyState fk_joint(const BodyConst &c, const float *jq, const float *jqd, const float *rec) {
   v3 p_wp = V3(0, 0, 0), w_wp = V3(0, 0, 0), v_wp = V3(0, 0, 0);
   qt q_wp = Q4(0, 0, 0, 1);
   if (c.parent >= 0) {
-    const float *r = rec + c.parent * RS;
+    const float *r = rec + c.parent * PD_REC;
     p_wp = ld3(r); q_wp = ld4(r + 3); w_wp = ld3(r + 7); v_wp = ld3(r + 10);
   }
   FkLocals L;
@@ -274,14 +260,16 @@ PD_DEV BodyAdj fk_joint_adj(const BodyConst &c, const float *jq, const float *jq
 // Returns false when the point is above ground (the kernel's early return, :132-133).
 struct ContactOut { v3 t, f; };
 
-// r = the body's forward record (PD_RECF: rotation matrix at r[16]), cv = its cull vector (p_y, row 1 of that matrix).
-// Branch-free, so that the compiler can schedule it into the joint pass of the same wave: everything is computed, the return
-// value says whether the point touches (c <= 0 or NaN -- the reference continues past `if c > 0: return` for a NaN too).
+// r = the body's staged record, cv = its cull vector (p_y, row 1 of rotm(q)): the height -- and with it "touching" -- comes from
+// contact_height (pinned roundings, the adjoint recomputes the same bits), x and z from the reference's quaternion rotation.
+// Returns whether the point touches (c <= 0 or NaN: the reference continues past `if c > 0: return` for a NaN too); o is
+// computed either way.
 PD_DEV bool contact_point_fwd(const float *r, float4 cv, float4 P, float4 mat, ContactOut &o) {
   const v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
-  const float *R = r + 16;
+  const qt q = ld4(r + 3);
   const float c = contact_height(cv, P);
-  const v3 cp = V3(p.x + (R[0] * P.x + R[1] * P.y + R[2] * P.z), c, p.z + (R[6] * P.x + R[7] * P.y + R[8] * P.z));
+  const v3 rp = qrot(q, V3(P.x, P.y, P.z));
+  const v3 cp = V3(p.x + rp.x, c, p.z + rp.z);
   v3 rr = cp - (p + rc);
   v3 dpdt = v + cross(w, rr);
   float ke = mat.x, kd = mat.y, kf = mat.z, mu = mat.w;
@@ -429,15 +417,14 @@ struct JointCtx {  // locals shared by the forward and the adjoint
 // `if (parent)` regions then cost no exec-mask code and no moves that merge their results with the values of lanes outside them
 // (-62 instructions per adjoint step), and the compound joint's six quaternion products with q_off drop out of the adjoint
 // (x * identity is x exactly; -5 % adjoint time for human / quad).  The forward pass keeps its products: its arithmetic is frozen.
-template <bool HP = false, int RS = PD_REC>
+template <bool HP = false>
 PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, JointCtx &j) {
   j.pp = V3(0, 0, 0); j.qp = Q4(0, 0, 0, 1); j.x_p = c.p_pj; j.q_p = c.q_pj;
   j.r_p = V3(0, 0, 0); j.w_p = V3(0, 0, 0); j.v_p = V3(0, 0, 0);
   if (HP || c.parent >= 0) {  // :326-333
-    const float *r = rec + (HP ? c.pidx : c.parent) * RS;
+    const float *r = rec + (HP ? c.pidx : c.parent) * PD_REC;
     j.pp = ld3(r); j.qp = ld4(r + 3); j.w_p = ld3(r + 7); j.v_p = ld3(r + 10);
-    // forward record: the parent staged rotm(qp) beside its pose (9 products instead of a 23-instruction quaternion rotation)
-    j.x_p = j.pp + (RS == PD_RECF ? mat_vec(r + 16, c.p_pj) : qrot(j.qp, c.p_pj));
+    j.x_p = j.pp + qrot(j.qp, c.p_pj);
     j.q_p = qmul(j.qp, c.q_pj);
     j.r_p = j.x_p - (j.pp + ld3(r + 13));
   }
@@ -452,14 +439,14 @@ PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const flo
 // with the identity child frame, the rotated basis as matrix columns, the axis chain with its zero components taken out, one
 // matrix for the three axis rotations: the same terms minus products with exact zeros, ~200 instructions less per joint.
 // Only the compound-only instantiation sets it: the revolute forward pass (Laikago) stays bit for bit what round 1 shipped.
-// Rm = rotm(s.r) of this body (the integration made it for the staging); rec = forward records (PD_RECF).  HP: plain model
-// (joint_ctx) -- the call may then run for EVERY lane, unguarded: a lane without a joint (the FREE root, idle lanes) computes
-// on the record of body c.pidx = 0 and the caller drops its result.
+// Rm = rotm(s.r) of this body (the integration made it for the staging).  HP: plain model (joint_ctx) -- the call may then run
+// for EVERY lane, unguarded: a lane without a joint (the FREE root, idle lanes) computes on the record of body c.pidx = 0 and
+// the caller drops its result.
 template <int JT, bool PLAINC = false, bool HP = PLAINC>
 PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *Rm, const float *rec, const float *tgt,
                       const float *act, const float *ke, const float *kd, v3 &wp_t, v3 &wp_f, v3 &wc_t, v3 &wc_f) {
   JointCtx j;
-  joint_ctx<HP, PD_RECF>(c, s, rc_c, rec, j);
+  joint_ctx<HP>(c, s, rc_c, rec, j);
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {  // :385-390
@@ -468,13 +455,8 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     t_total += qrot(j.q_p, ang_err) * ake + j.w_err * (akd * ads);
   }
   if ((JT & PD_JT_REVOLUTE) && (HP || c.type == PD_JOINT_REVOLUTE)) {  // :392-409
-    // rot(q_p, axis) = rotm(qp) (rotm(q_pj) axis): the inner product is a per-body constant (c.axis_pj)
-    const float *Rp = rec + (HP ? c.pidx : (c.parent >= 0 ? c.parent : 0)) * PD_RECF + 16;
-    v3 axis_p = (HP || c.parent >= 0) ? mat_vec(Rp, c.axis_pj) : c.axis_pj, axis_c = mat_vec(Rm, c.axis);
-    v3 a = c.axis * dot(qvec(j.r_err), c.axis);
-    qt twist = qnormalize(Q4(a.x, a.y, a.z, j.r_err.w));
-    float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
-    float q = acos_c(twist.w) * 2.0f * sgn;
+    v3 axis_p = qrot(j.q_p, c.axis), axis_c = mat_vec(Rm, c.axis);
+    float q = twist_angle(dot(qvec(j.r_err), c.axis), j.r_err.w, c.alen);  // :394-400, see pd_math.h
     float qd = dot(j.w_err, axis_p);
     const JointLimit L = c.lim[0];
     float jf = joint_force(q, qd, tgt[0], ke[0], kd[0], act[0], L.lo, L.up, L.ke, L.kd);
@@ -627,12 +609,8 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
   }
   if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
     v3 axis_p = qrot(j.q_p, c.axis), axis_c = qrot(s.r, c.axis);
-    float da = dot(qvec(j.r_err), c.axis);
-    v3 a = c.axis * da;
-    qt tq = Q4(a.x, a.y, a.z, j.r_err.w);
-    qt twist = qnormalize(tq);
-    float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
-    float q = acos_c(twist.w) * 2.0f * sgn;
+    float dq_dda, dq_dw;
+    float q = twist_angle(dot(qvec(j.r_err), c.axis), j.r_err.w, c.alen, dq_dda, dq_dw);
     float qd = dot(j.w_err, axis_p);
     const JointLimit L = c.lim[0];
     float lo = L.lo, up = L.up, lke = L.ke, lkd = L.kd;
@@ -648,12 +626,9 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     a_tgt[0] = 0.f; a_act[0] = 0.f; a_ke[0] = 0.f; a_kd[0] = 0.f;
     joint_force_adj(q, qd, tgt[0], ke[0], kd[0], lo, up, lke, lkd, adj_jf, adj_q, adj_qd, a_tgt[0], a_ke[0], a_kd[0], a_act[0]);
     adj_w_err += axis_p * adj_qd; adj_axis_p += j.w_err * adj_qd;
-    qt adj_twist = Q4(0, 0, 0, -adj_q * 2.0f * sgn * inv_sqrt_1mx2(twist.w));
-    qt adj_tq = Q4(0, 0, 0, 0);
-    adj_qnormalize(tq, adj_tq, adj_twist);
-    float adj_da = dot(qvec(adj_tq), c.axis);
+    const float adj_da = adj_q * dq_dda;
     adj_r_err.x += c.axis.x * adj_da; adj_r_err.y += c.axis.y * adj_da; adj_r_err.z += c.axis.z * adj_da;
-    adj_r_err.w += adj_tq.w;
+    adj_r_err.w += adj_q * dq_dw;
     adj_qrot_q(j.q_p, c.axis, adj_q_p, adj_axis_p);
     adj_qrot_q(s.r, c.axis, adj_q_c, adj_axis_c);
   }
@@ -744,22 +719,22 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
 // on the stored state and the controls only -- it runs on the otherwise idle contact wave and is handed over through
 // LDS -- and rev_adjoint, on the body wave, is the part that needs the wrench adjoints.  Together they equal the
 // revolute branch of joint_adj.
-#define PD_JC 25  // floats of the hand-over record (odd stride)
+#define PD_JC 23  // floats of the hand-over record (odd stride)
 struct RevCache {
-  qt q_p, r_err, tq;
+  qt q_p, r_err;
   v3 x_p, axis_p, axis_c;
-  float q, qd, jf, dq;  // dq = d q / d twist.w = -2 sgn / sqrt(1 - twist.w^2), guarded
+  float q, qd, jf, dq_dda, dq_dw;  // partial derivatives of the twist angle (pd_math.h twist_angle)
 };
 PD_DEV void rev_cache_store(float *d, const RevCache &R) {
   d[0] = R.q_p.x; d[1] = R.q_p.y; d[2] = R.q_p.z; d[3] = R.q_p.w; d[4] = R.r_err.x; d[5] = R.r_err.y; d[6] = R.r_err.z; d[7] = R.r_err.w;
-  d[8] = R.tq.x; d[9] = R.tq.y; d[10] = R.tq.z; d[11] = R.tq.w; d[12] = R.x_p.x; d[13] = R.x_p.y; d[14] = R.x_p.z;
-  d[15] = R.axis_p.x; d[16] = R.axis_p.y; d[17] = R.axis_p.z; d[18] = R.axis_c.x; d[19] = R.axis_c.y; d[20] = R.axis_c.z;
-  d[21] = R.q; d[22] = R.qd; d[23] = R.jf; d[24] = R.dq;
+  d[8] = R.x_p.x; d[9] = R.x_p.y; d[10] = R.x_p.z;
+  d[11] = R.axis_p.x; d[12] = R.axis_p.y; d[13] = R.axis_p.z; d[14] = R.axis_c.x; d[15] = R.axis_c.y; d[16] = R.axis_c.z;
+  d[17] = R.q; d[18] = R.qd; d[19] = R.jf; d[20] = R.dq_dda; d[21] = R.dq_dw;
 }
 PD_DEV RevCache rev_cache_load(const float *d) {
   RevCache R;
-  R.q_p = ld4(d); R.r_err = ld4(d + 4); R.tq = ld4(d + 8); R.x_p = ld3(d + 12); R.axis_p = ld3(d + 15); R.axis_c = ld3(d + 18);
-  R.q = d[21]; R.qd = d[22]; R.jf = d[23]; R.dq = d[24];
+  R.q_p = ld4(d); R.r_err = ld4(d + 4); R.x_p = ld3(d + 8); R.axis_p = ld3(d + 11); R.axis_c = ld3(d + 14);
+  R.q = d[17]; R.qd = d[18]; R.jf = d[19]; R.dq_dda = d[20]; R.dq_dw = d[21];
   return R;
 }
 
@@ -778,12 +753,7 @@ PD_DEV RevCache rev_forward(const PdDevModel &m, const BodyConst &c, qt q_c, v3 
   R.r_err = qmul(qconj(R.q_p), q_c);
   R.axis_p = qrot(R.q_p, c.axis);
   R.axis_c = qrot(q_c, c.axis);
-  v3 a = c.axis * dot(qvec(R.r_err), c.axis);
-  R.tq = Q4(a.x, a.y, a.z, R.r_err.w);
-  const qt twist = qnormalize(R.tq);
-  const float sgn = dot(c.axis, qvec(twist)) < 0.0f ? -1.0f : 1.0f;
-  R.q = acos_c(twist.w) * 2.0f * sgn;
-  R.dq = -2.0f * sgn * inv_sqrt_1mx2(twist.w);
+  R.q = twist_angle(dot(qvec(R.r_err), c.axis), R.r_err.w, c.alen, R.dq_dda, R.dq_dw);
   R.qd = dot(w_c - w_p, R.axis_p);
   const JointLimit L = c.lim[0];
   R.jf = joint_force(R.q, R.qd, tgt, ke, kd, act, L.lo, L.up, L.ke, L.kd);
@@ -823,11 +793,9 @@ PD_DEV void rev_adjoint_core(const PdDevModel &m, const BodyConst &c, const Body
   const JointLimit L = c.lim[0];
   joint_force_adj(R.q, R.qd, tgt, ke, kd, L.lo, L.up, L.ke, L.kd, adj_jf, adj_q, adj_qd, a_tgt, a_ke, a_kd, a_act);
   adj_w_err += R.axis_p * adj_qd; adj_axis_p += w_err * adj_qd;
-  qt adj_tq = Q4(0, 0, 0, 0);
-  adj_qnormalize(R.tq, adj_tq, Q4(0, 0, 0, adj_q * R.dq));
-  const float adj_da = dot(qvec(adj_tq), c.axis);
+  const float adj_da = adj_q * R.dq_dda;
   adj_r_err.x += c.axis.x * adj_da; adj_r_err.y += c.axis.y * adj_da; adj_r_err.z += c.axis.z * adj_da;
-  adj_r_err.w += adj_tq.w;
+  adj_r_err.w += adj_q * R.dq_dw;
   adj_qrot_q(R.q_p, c.axis, adj_q_p, adj_axis_p);
   add_outer(aR, adj_axis_c, c.axis);  // axis_c = rotm(s.r) axis
   {  // r_err = conj(q_p) * q_c

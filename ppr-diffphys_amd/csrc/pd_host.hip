@@ -225,17 +225,10 @@ static int build_device(pd_model *m, int segw) {
   // lanes (env e, body b) of one wave address base_e + f(b): an env stride of 16 mod 32 floats lets the envs of a wave
   // alternate between the two halves of the 32 LDS banks (2-way, the minimum for 64 lanes) instead of piling onto one
   d.env_lds_floats += (16 - d.env_lds_floats % 32 + 32) % 32;
-  // forward rollout kernel (pd_kernels.hip k_rollout_fwd): cull vectors, records with the rotation matrix, wrench slots, parent
-  // contributions + the zero record, two generations of speculative cull vectors, 8 words, tile list, candidate list
-  {
-    const int spec_off = ((4 + PD_RECF + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;
-    d.env_lds_fwd = ((spec_off + 8 * nb + 8 + d.list_cap + PD_HIT_CAP_TILES_HOST * segw + 3) / 4) * 4;
-    d.env_lds_fwd += (16 - d.env_lds_fwd % 32 + 32) % 32;
-  }
   const int envs_per_block = PD_BWAVES * (64 / segw);
   const size_t lds_tables = (size_t)std::max(nc, 1) * 16 + (size_t)std::max(ntiles, 1) * 32 + (size_t)std::max(m->nmat, 1) * 16 +
                             (size_t)((std::max(ntiles, 1) + 3) & ~3) * 4 + (size_t)((nb + 1) & ~1) * 8 + (size_t)((std::max(nc, 1) + 15) & ~15);
-  const size_t lds_rollout = lds_tables + (size_t)envs_per_block * d.env_lds_fwd * 4;
+  const size_t lds_rollout = lds_tables + (size_t)envs_per_block * d.env_lds_floats * 4;
   {
     int dev_id = 0, cus = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) cus = 0;
@@ -289,7 +282,6 @@ static int build_device(pd_model *m, int segw) {
 
 static int g_variant = 0;  // A/B experiments only (pd_debug_set_variant)
 static int g_groups = 0;   // A/B experiments only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
-static int g_fuse = -1;    // A/B experiments only (pd_debug_set_fuse): forward contact evaluation on the body wave, -1 = automatic
 
 // Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
 static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
@@ -303,8 +295,7 @@ static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
   c.threads = c.roles * c.groups * 64;
   const size_t envs = (size_t)c.groups * epw;
   switch (c.kernel) {
-    case PD_KV_FWD_SPLIT: case PD_KV_FWD_UNSPLIT: c.lds = m->lds_tables + envs * d.env_lds_fwd * 4; break;
-    case PD_KV_BWD_UNSPLIT: c.lds = m->lds_tables + envs * d.env_lds_floats * 4; break;
+    case PD_KV_FWD_SPLIT: case PD_KV_FWD_UNSPLIT: case PD_KV_BWD_UNSPLIT: c.lds = m->lds_tables + envs * d.env_lds_floats * 4; break;
     case PD_KV_BWD_2ROLE: case PD_KV_BWD_2ROLE_EARLY: c.lds = envs * (d.env_lds_floats + 2 * d.env_lds_jc) * 4; break;
     case PD_KV_BWD_3ROLE: c.lds = envs * d.env_lds_bwd3 * 4; break;
     case PD_KV_BWD3_2ROLE: c.lds = m->lds_tables + envs * d.env_lds_bwd3 * 4; break;
@@ -455,12 +446,6 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = fos; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
   a.hitlog = (int *)(ws + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
-  {  // a workgroup's waves are dealt to the 4 SIMDs cyclically: with PD_BWAVES env groups per workgroup a body wave and its helper
-     // share a SIMD, and the body wave then evaluates the contact candidates itself (k_rollout_fwd); with fewer groups the
-     // helper has a SIMD of its own and evaluates them in parallel
-    const PdLaunchCfg c = launch_cfg(m, PD_K_ROLLOUT_FWD, bs);
-    a.fuse = g_fuse >= 0 ? g_fuse : (c.kernel == PD_KV_FWD_SPLIT && c.groups == PD_BWAVES ? 1 : 0);
-  }
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, st);
@@ -530,7 +515,6 @@ void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
 // revolute-only: 0 = shipped default (2-role, hand-over A after integrate_adj), 1 = 2-role with the early hand-over,
 // 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 0 = 2-role k_rollout_bwd3<2>, 9 = the unsplit round-1 kernel.
 void pd_debug_set_variant(int v) { g_variant = v; }
-void pd_debug_set_fuse(int f) { g_fuse = f; }
 void pd_debug_set_groups(int g) { g_groups = g < 0 ? 0 : (g > PD_BWAVES ? PD_BWAVES : g); }
 
 int pd_model_set_timing(pd_model *m, int on) {

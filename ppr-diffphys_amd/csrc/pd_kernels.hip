@@ -142,7 +142,7 @@ PD_DEV int pair_wait(int *flag, int value) {
 #ifndef PD_UNROLL
 #define PD_UNROLL 4          // tiles handled per L3 iteration (their LDS reads are issued back to back)
 #endif
-#define PD_HIT_CAP_TILES PD_HIT_CAP_TILES_HOST   // hit-list capacity in units of SEGW (two L3 iterations)
+#define PD_HIT_CAP_TILES 8   // hit-list capacity in units of SEGW (two L3 iterations)
 
 struct SweepTables {
   const float4 *pts, *tlo, *thi, *mats;
@@ -170,7 +170,7 @@ PD_DEV bool cull_above_box(float4 cv, float4 lo, float4 hi) {
 //
 // ATOMIC = true keeps ds_add_f32 (measured faster for the 6-float forward wrench: 0.358 vs 0.415 ms per rollout;
 // slower for the 13-float adjoint: 0.646 vs 0.617 ms).  Both orders are fixed, so results are reproducible either way.
-template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, int RS, typename F>
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int *hits, float *slot, float *dst, int j0, int nh,
                               int run_start, int run_cnt, int l, int nb, F &&compute) {
   const int j = j0 + l;
@@ -178,7 +178,7 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
     int e = hits[j];  // point | material << 16 | body << 24
     int pt = e & 0xffff, pb = (e >> 24) & 0x3f;
     float out[NV];
-    compute(rec + pb * RS, T.pts[pt], T.mats[(e >> 16) & 0xff], out);
+    compute(rec + pb * PD_REC, T.pts[pt], T.mats[(e >> 16) & 0xff], out);
     if (ATOMIC) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) atomicAdd(dst + pb * DSTRIDE + i, out[i]);
@@ -269,7 +269,7 @@ PD_DEV int sweep_cull(const PdDevModel &m, const SweepTables &T, const BodyConst
 }
 
 // L3 + hit pass over list[0, nlist): exact point test, compaction, on_hit arithmetic.  log_n: see sweep_contacts.
-template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, int RS = PD_REC, typename F>
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_points(const PdDevModel &m, const SweepTables &T, const float *rec, const float4 *cull, const int *list, int nlist,
                          int *hits, float *slot, float *dst, int seg, int l, int &log_n, F &&compute STAMP_ARGS) {
   const SegMask sm = seg_mask<SEGW>(seg);
@@ -280,7 +280,7 @@ PD_DEV void sweep_points(const PdDevModel &m, const SweepTables &T, const float 
   auto flush_all = [&]() {
     WAVE_SYNC();
     for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW)
-      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC, RS>(T, rec, hits, slot, dst, j0, nh, run_start, run_cnt, l, m.nb, compute);
+      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC>(T, rec, hits, slot, dst, j0, nh, run_start, run_cnt, l, m.nb, compute);
     nh = 0; run_cnt = 0;
   };
   for (int k0 = 0; __ballot(k0 < nlist) != 0ull; k0 += PD_UNROLL) {
@@ -363,7 +363,7 @@ PD_DEV void write_hit_log(int *log, const int *hits, int log_n, bool env_ok, int
   if (l == 0) log[0] = log_n;
   for (int j = l; j < log_n; j += SEGW) log[1 + j] = hits[j];
 }
-template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, int RS = PD_REC, typename F>
+template <int SEGW, int NV, int DSTRIDE, bool ATOMIC, typename F>
 PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float *rec,
                            const float4 *cull, int *list, int *hits, float *slot, float *dst, bool is_body, bool env_ok, int seg,
                            int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS, bool have_pre = false, int pre_e = 0) {
@@ -388,13 +388,13 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
     if (l < m.nb) { rstart = rs[l]; rcnt = re[l] - rstart; }
     STAMP(10);
     for (int j0 = 0; __ballot(j0 < nh_r) != 0ull; j0 += SEGW)
-      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC, RS>(T, rec, hits, slot, dst, j0, nh_r, rstart, rcnt, l, m.nb, compute);
+      sweep_flush_batch<SEGW, NV, DSTRIDE, ATOMIC>(T, rec, hits, slot, dst, j0, nh_r, rstart, rcnt, l, m.nb, compute);
     STAMP(11);
     return;
   }
   log_n = 0;  // what the forward caller should log for this env: >= 0 hit count (entries are in hits[]), -1 = did not fit
   const int nlist = sweep_cull<SEGW>(m, T, c, cv, cull, list, is_body, seg, l STAMP_PASS);
-  sweep_points<SEGW, NV, DSTRIDE, ATOMIC, RS>(m, T, rec, cull, list, nlist, hits, slot, dst, seg, l, log_n, compute STAMP_PASS);
+  sweep_points<SEGW, NV, DSTRIDE, ATOMIC>(m, T, rec, cull, list, nlist, hits, slot, dst, seg, l, log_n, compute STAMP_PASS);
 }
 
 // Speculative contact cull (k_rollout_fwd): the height any contact candidate of the body is allowed to lose over the
@@ -437,48 +437,18 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 }
 
 // =============================================================================================
-// Forward rollout.  SPLIT = wave specialisation: a body wave per env group plus a HELPER wave (the old contact wave) on the
-// same SIMD.  Kernels whose body wave needs more than 256 VGPRs run unsplit: 4 waves per workgroup, sweeps inline.
-//
-// Round 3: the body wave evaluates the ground contacts ITSELF.  The helper culls once per epoch of PD_SPEC_K steps (a
-// conservative superset of the points that can touch during the epoch, see sink_margin) and hands the candidates over
-// through LDS; lane j of an env's segment then keeps candidate j (entry, point, material) in registers, and every step
-// runs the reference's contact arithmetic for it in the SAME basic block as the joint pass of lane = body: two independent
-// dependency chains per lane for the scheduler to interleave, no hand-over on the step's critical path (rounds 1-2 handed
-// every step's records to the contact wave and waited for its wrenches: two workgroup-scope round trips per step, and the
-// two waves' dependent-issue stalls added up on the shared SIMD).  The helper still does the exact sweep when asked --
-// step 0, a body that outran its margin, more candidates than lanes -- through the old request / done words.
-enum { PD_CM_REDO = 0, PD_CM_EVAL = 1, PD_CM_FUSED = 2 };  // how this step's contacts are evaluated (wave-uniform)
-#define PD_REQ_CNT 0x00ffffff
-#define PD_REQ_REDO 0x01000000   // exact sweep of the step's state + evaluation, then B
-#define PD_REQ_EVAL 0x02000000   // evaluation of the epoch's candidate list (more candidates than lanes), then B
-#define PD_REQ_EPOCH 0x04000000  // the step's state opens an epoch: cull for it, then C
-#define PD_REQ_DONE 0x08000000
-#define PD_C_HAVE 0x01000000     // the candidates fit the list
-#define PD_C_OWNS 0x02000000     // ... and no env has more of them than the segment has lanes
-#define PD_C_OWNS2 0x04000000    // ... than twice the segment's lanes (the fused body wave takes two candidates per lane)
-// polling for a word whose low 24 bits count; idle = the waiter is off the critical path and sleeps between reads
-template <bool IDLE>
-PD_DEV int word_wait(int *flag, int value) {
-  int v;
-  while (((v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) & PD_REQ_CNT) < value) {
-    if (IDLE) __builtin_amdgcn_s_sleep(1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  return v;
-}
-
+// SPLIT = wave specialisation (8 waves, contact waves beside body waves).  Kernels whose body wave needs more than
+// 256 VGPRs (compound joints) run unsplit: 4 waves per workgroup, one per SIMD, sweeps inline.
 template <int SEGW, int JT, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  constexpr bool HPJ = JT == PD_JT_REVOLUTE;  // plain revolute-only model: the joint pass runs unguarded on every lane
   // env groups (= body waves) per workgroup: chosen by the host per launch (1 .. PD_BWAVES) so that small batches spread
   // over all compute units instead of filling a few
   const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
-  const bool helper_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
+  const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
@@ -488,19 +458,20 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   const int nb = m.nb, N = a.bs * nb;
 
   SweepTables tabs;
-  float *scratch = lds_setup<true>(m, smem, tabs, wave * EPW + seg, m.env_lds_fwd);
+  float *scratch = lds_setup<true>(m, smem, tabs, wave * EPW + seg, m.env_lds_floats);
   float4 *cull = (float4 *)scratch;
   // pcon: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
-  float *rec = scratch + 4 * nb, *facc = rec + nb * PD_RECF, *pcon = facc + nb * PD_W6;
-  // speculative cull vectors of the two latest epochs (by epoch parity), then 8 words: [0] the env's candidate count,
-  // [1..3] of the wave's first env = request / B / C words
-  const int spec_off = ((4 + PD_RECF + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;  // 16-byte aligned like cull
+  float *rec = scratch + 4 * nb, *facc = rec + nb * PD_REC, *pcon = facc + nb * PD_W6;
+  // speculative cull vectors of the two latest states (by step parity) + the env's "speculation failed" flag; they live
+  // in the room the adjoint kernel's wider per-body slots leave in the shared per-env size
+  const int spec_off = ((4 + PD_REC + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;  // 16-byte aligned like cull
   float4 *spec = (float4 *)(scratch + spec_off);
-  int *env_words = (int *)(scratch + spec_off + 8 * nb);
-  int *sig = (int *)(scratch - (size_t)seg * m.env_lds_fwd + spec_off + 8 * nb) + 1;  // [0] request  [1] B  [2] C
-  int *list = env_words + 8, *hits = list + m.list_cap;
+  int *spec_bad = (int *)(scratch + spec_off + 8 * nb);  // 4 words: [0] unused, [1..2] of the wave's first env = pair signals
+  int *sig = (int *)(scratch - (size_t)seg * m.env_lds_floats + spec_off + 8 * nb) + 1;  // pair signals: words 1, 2 after the first env's flag
+  int *list = spec_bad + 4, *hits = list + m.list_cap;
+  float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
   if (SPLIT) {
-    if (lane == 0) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
+    if (lane == 0) { sig[0] = 0; sig[1] = 0; }
     __syncthreads();
   }
 
@@ -509,63 +480,62 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   for (int u = 0; u < 4; ++u) c.small_e[u] = m.small_tiles[u * 64 + (l < 64 ? l : 0)];
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {  // body_f -= (t, f)   (:179)
     ContactOut o;
-    const int pb = (int)(r - rec) / PD_RECF;
-    const bool touching = contact_point_fwd(r, cull[pb], P, mat, o);
+    const bool touching = contact_point_fwd(r, cull[(int)(r - rec) / PD_REC], P, mat, o);
     out[0] = touching ? -o.t.x : 0.f; out[1] = touching ? -o.t.y : 0.f; out[2] = touching ? -o.t.z : 0.f;
     out[3] = touching ? -o.f.x : 0.f; out[4] = touching ? -o.f.y : 0.f; out[5] = touching ? -o.f.z : 0.f;
     return touching;
   };
-  const SegMask sm = seg_mask<SEGW>(seg);
-  if (SPLIT && helper_wave) {
-    // ---- helper wave: sleeps on the request word.  REDO: the exact three-level sweep of the step's state and its evaluation
-    // (ds_add_f32 into the wrench slots), then B.  EVAL: evaluation of the epoch's candidate list out of LDS, then B.  EPOCH:
-    // after those, the speculative cull for the epoch the step's state opens -- with the cull vectors of that state lowered
-    // by margin_b, a bound on how far body b can sink over the epoch that the body wave verifies against the motion it then
-    // integrates (sink_rate) -- then C.  The candidates are a superset, in the same order, of what the exact sweep finds in
-    // any state of the epoch, and the exact test runs on each, so the wrench sums are those of the unspeculated sweep.
+  if (SPLIT && contact_wave) {
+    // ---- contact wave: eval_body_contacts for the partner body wave's envs, between hand-overs A and B of each step.
+    // The cull (L1-L3) is SPECULATED, once per epoch of PD_SPEC_K steps, in the wait for the body wave's integration:
+    // after hand-over B of an epoch's first step s this wave culls with the vectors of state s lowered by margin_b(s), a
+    // guess of how far body b can sink over the epoch.  The body wave checks the guess against the motion it then
+    // integrates (integrate_fwd: sink_rate, summed over the epoch) and raises the env's flag when a body sank further;
+    // a raised flag makes this wave redo the exact sweep.  The candidates are a superset, in the same order, of what
+    // the exact sweep finds in any state of the epoch; contact_hit applies the reference's exact test to each, so the
+    // wrench sums are bit-identical to the unspeculated sweep.
     STAMP_DECL;
-    int nh = 0;  // speculated candidates of my env, hits[0, nh)
-    // hand-over mode (a.fuse == 0: this wave has a SIMD of its own and evaluates every step): when no env of the wave has
-    // more candidates than the segment has lanes, lane j keeps candidate j -- entry, point, material -- in registers
+    const SegMask sm = seg_mask<SEGW>(seg);
+    int nh = 0;         // speculated candidates of my env, hits[0, nh)
+    bool have = false;  // wave-uniform: the candidates are there and nothing overwrote them
+    // When no env of the wave has more candidates than the segment has lanes (the usual case) lane j keeps candidate j --
+    // entry, point, material -- in registers for the whole epoch: the per-step hit pass then starts with the record read.
     bool lane_owns = false;  // wave-uniform
-    int h_e = 0;
-    float4 h_P = make_float4(0.f, 0.f, 0.f, 0.f), h_M = h_P;
-    for (int last = 0;;) {
-      const int rq = a.fuse ? word_wait<true>(sig, last + 1) : word_wait<false>(sig, last + 1);  // hand-over mode: on the critical path every step
-      STAMP(7);
-      if (rq & PD_REQ_DONE) break;
-      last = rq & PD_REQ_CNT;
-      const int step = last - 1;
+    int c_e = 0;
+    float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P;
+    for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
-      if (rq & PD_REQ_REDO) {
-        int log_n = 0;
+      // A: records + cull vectors of this step are staged, wrench accumulators are zero; bit 30: a body of one of my envs
+      // outran its margin
+      const int sigA = pair_wait(sig, step + 1);
+      STAMP(7);
+      const bool redo = !have || (sigA & PD_SIG_FLAG) != 0;  // wave-uniform
+      STAMP_COUNT(13, redo ? 1 : 0);
+      STAMP_COUNT(14, __shfl(nh, 0));
+      int log_n = 0;
+      bool touching = false;  // lane_owns path: does my candidate touch (logged after hand-over B)
+      if (redo) {
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
         if (is_body) cv = cull[b];
         const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, cull, list, is_body, seg, l STAMP_PASS);
-        sweep_points<SEGW, 6, PD_W6, true, PD_RECF>(m, tabs, rec, cull, list, nlist, hits, (float *)hits, facc, seg, l, log_n, contact_hit STAMP_PASS);
-        pair_signal(sig + 1, last);  // B: contact wrenches are complete
-        write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);  // the adjoint's log, off the critical path
-        lane_owns = false;
-        STAMP_COUNT(13, 1);
-      } else if ((rq & PD_REQ_EVAL) && lane_owns) {
-        bool tch = false;
+        sweep_points<SEGW, 6, PD_W6, true>(m, tabs, rec, cull, list, nlist, hits, slot, facc, seg, l, log_n, contact_hit STAMP_PASS);
+        have = false;  // hits[] now holds this step's exact hits
+      } else if (lane_owns) {
+        // evaluate the candidates on the state that now exists: contact_hit applies the reference's exact test
         if (l < nh) {
           float out[6];
-          tch = contact_hit(rec + ((h_e >> 24) & 0x3f) * PD_RECF, h_P, h_M, out);
-          if (tch) {
+          touching = contact_hit(rec + ((c_e >> 24) & 0x3f) * PD_REC, c_P, c_M, out);
+          if (touching) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) atomicAdd(facc + ((h_e >> 24) & 0x3f) * PD_W6 + i, out[i]);
+            for (int i = 0; i < 6; ++i) atomicAdd(facc + ((c_e >> 24) & 0x3f) * PD_W6 + i, out[i]);
           }
         }
-        pair_signal(sig + 1, last);  // B
-        int log_n = 0;
-        const int sl = seg_slot(tch, sm, log_n);
-        if (tch && env_ok && sl < PD_HITLOG - 1) lg[1 + sl] = h_e;
-        if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
-      } else if (rq & PD_REQ_EVAL) {
+        STAMP(11);
+      } else {
         // more candidates than lanes somewhere in the wave: batches out of the LDS list; the ones that touch go to the
         // adjoint's log straight away
-        int log_n = 0;
+        // (per-body sums in registers, seg_run_sum, were measured here too: slower than the 6 ds_add_f32 of the few
+        // candidates that touch -- the chain runs over ALL candidates)
         for (int j0 = 0; __ballot(j0 < nh) != 0ull; j0 += SEGW) {
           const int j = j0 + l;
           bool tch = false;
@@ -573,7 +543,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
           if (j < nh) {
             e = hits[j];
             float out[6];
-            tch = contact_hit(rec + ((e >> 24) & 0x3f) * PD_RECF, tabs.pts[e & 0xffff], tabs.mats[(e >> 16) & 0xff], out);
+            tch = contact_hit(rec + ((e >> 24) & 0x3f) * PD_REC, tabs.pts[e & 0xffff], tabs.mats[(e >> 16) & 0xff], out);
             if (tch) {
 #pragma unroll
               for (int i = 0; i < 6; ++i) atomicAdd(facc + ((e >> 24) & 0x3f) * PD_W6 + i, out[i]);
@@ -583,23 +553,30 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
           if (tch && env_ok && s < PD_HITLOG - 1) lg[1 + s] = e;
         }
         if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
-        pair_signal(sig + 1, last);  // B
+        STAMP(11);
       }
-      STAMP(11);
-      if (rq & PD_REQ_EPOCH) {
+      STAMP(12);
+      pair_signal(sig + 1, step + 1);  // B: contact wrenches are complete
+      // the adjoint's log is written off the critical path
+      if (redo) {
+        write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);
+      } else if (lane_owns) {
+        const int s = seg_slot(touching, sm, log_n);
+        if (touching && env_ok && s < PD_HITLOG - 1) lg[1 + s] = c_e;
+        if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
+      }
+      if (redo) lane_owns = false;
+      if (step % PD_SPEC_K == 0 && step + 1 < a.nsteps) {  // state `step` opened an epoch: cull for the steps it serves
         WAVE_SYNC();  // the log is read out of hits[] before the candidates overwrite it
         const float4 *sp = spec + ((step / PD_SPEC_K) & 1) * nb;
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
         if (is_body) cv = sp[b];
         const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, sp, list, is_body, seg, l STAMP_PASS);
-        const bool have = sweep_l3_spec<SEGW>(tabs, sp, list, nlist, hits, seg, l, nh);
-        const bool owns = have && __ballot(nh > SEGW) == 0ull, owns2 = have && __ballot(nh > 2 * SEGW) == 0ull;
-        if (l == 0) env_words[0] = nh;
-        pair_signal(sig + 2, (step / PD_SPEC_K + 1) | (have ? PD_C_HAVE : 0) | (owns ? PD_C_OWNS : 0) | (owns2 ? PD_C_OWNS2 : 0));  // C
-        lane_owns = owns && !a.fuse;
+        have = sweep_l3_spec<SEGW>(tabs, sp, list, nlist, hits, seg, l, nh);
+        lane_owns = have && __ballot(nh > SEGW) == 0ull;
         if (lane_owns) {
-          h_e = l < nh ? hits[l] : 0;
-          h_P = tabs.pts[h_e & 0xffff]; h_M = tabs.mats[(h_e >> 16) & 0xff];
+          c_e = l < nh ? hits[l] : 0;
+          c_P = tabs.pts[c_e & 0xffff]; c_M = tabs.mats[(c_e >> 16) & 0xff];
         }
         STAMP(10);
       }
@@ -609,7 +586,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   }
   const size_t idx = (size_t)ec * nb + b;  // flat body index (env-major)
   const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
-  const bool jointed = is_body && c.type != PD_JOINT_FREE;
 
   float inv_m = a.inv_mass[idx], I[9], invI[9], ke[ND], kd[ND];
 #pragma unroll
@@ -635,28 +611,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
   BodyState s;
   s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
-  float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};  // rotm(s.r) of the current state
+  float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};  // rotm(s.r) of the current state: integration, staging and the joint's axis share it
   v3 rc = V3(0, 0, 0);  // Rm com of the current state, shared by staging, joints and integration
   float margin = 0.f, sunk = 0.f;  // speculative contact cull: allowed / integrated loss of height since the epoch's state
   for (int d = 0; d <= m.max_depth; ++d) {
     if (is_body && c.depth == d) {
-      s = fk_joint<JT, PD_RECF>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
+      s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
       rotm(s.r, Rm);
       rc = mat_vec(Rm, c.com);
-      float4 cv = stage_record_f(rec, cull, b, s, rc, Rm);
+      float4 cv = stage_record(rec, cull, b, s, rc, Rm);
       margin = sink_margin(c, s, a.dt);
       cv.x -= margin;
       if (SPLIT) spec[b] = cv;  // epoch 0
     }
     WAVE_SYNC();
   }
-  bool spec_failed = false;  // wave-uniform: some body of the wave outran its margin
-  int cmode = PD_CM_REDO;    // wave-uniform: nothing is speculated for step 0
-  bool fetch_pending = false;
-  // lane j's candidates j and SEGW + j of the running epoch (PD_CM_FUSED): packed entry, point, material
-  int c_e = 0, c_e2 = 0, c_nh = 0;
-  float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P, c_P2 = c_P, c_M2 = c_P;
-  bool two = false;  // wave-uniform: some env of the wave has more candidates than lanes
+  bool spec_failed = true;  // wave-uniform: some body of the wave outran its margin (nothing is speculated for step 0)
 
   // Controls are software-prefetched one step ahead: with one wavefront per SIMD there is no other
   // wave to hide the HBM latency of a load issued at its point of use.
@@ -680,9 +650,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       n_rf[2 * k] = v.x; n_rf[2 * k + 1] = v.y;
     }
   };
-  // The trajectory record of a step is written in two parts: the state (planes 0-2, frame pose / twist) straight from the
-  // live registers of the step itself, the total wrench and the clamp mask of the step's integration (planes 3-4) one step
-  // late from eight copies -- instead of one late record from copies of everything (26 moves per step on this wave's chain)
+  // The trajectory record of a step is written in two parts, both where this wave is about to wait for the contact wave:
+  // the state (planes 0-2, frame pose / twist) straight from the live registers of the step itself, the total wrench and
+  // the clamp mask of the step's integration (planes 3-4) one step late from eight copies -- instead of one late record
+  // from copies of everything (26 moves per step on this wave's chain)
   float o_vz = 0.f;
   v3 o_ft = V3(0, 0, 0), o_ff = o_ft;
   unsigned o_mask = 0u, clamp_mask = 0u;  // which velocity components the step's integration clamped (stored for the adjoint)
@@ -708,32 +679,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
   if (a.nsteps > 0) load_controls(0);
   STAMP_DECL;
   for (int step = 0; step < a.nsteps; ++step) {
-    // The records of this step were staged at the end of the previous iteration (or by FK).
-    if (SPLIT) {
-      if (fetch_pending) {  // the candidates of the epoch that the previous step's state opened
-        const int cw = word_wait<false>(sig + 2, (step - 1) / PD_SPEC_K + 1);
-        cmode = (a.fuse && (cw & PD_C_OWNS2)) ? PD_CM_FUSED : ((cw & PD_C_HAVE) ? PD_CM_EVAL : PD_CM_REDO);
-        if (cmode == PD_CM_FUSED) {
-          c_nh = env_words[0];
-          two = !(cw & PD_C_OWNS);
-          c_e = l < c_nh ? hits[l] : 0;
-          c_P = tabs.pts[c_e & 0xffff]; c_M = tabs.mats[(c_e >> 16) & 0xff];
-          if (two) {
-            c_e2 = SEGW + l < c_nh ? hits[SEGW + l] : 0;
-            c_P2 = tabs.pts[c_e2 & 0xffff]; c_M2 = tabs.mats[(c_e2 >> 16) & 0xff];
-          }
-        }
-        fetch_pending = false;
-      }
-      if (spec_failed) cmode = PD_CM_REDO;  // until the next epoch's candidates arrive
-      const bool epoch = step % PD_SPEC_K == 0 && step + 1 < a.nsteps;
-      const int rq = (cmode == PD_CM_REDO ? PD_REQ_REDO : (cmode == PD_CM_EVAL ? PD_REQ_EVAL : 0)) | (epoch ? PD_REQ_EPOCH : 0);
-      if (rq) pair_signal(sig, (step + 1) | rq); else WAVE_SYNC();
-      fetch_pending = epoch;
-      STAMP_COUNT(13, cmode == PD_CM_FUSED ? 1 : 0);
-      STAMP_COUNT(14, cmode == PD_CM_EVAL ? 1 : 0);
-      STAMP_COUNT(15, __shfl(c_nh, 0));
-    }
+    // hand-over A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
+    // contact wave starts sweeping while this wave still unpacks controls and spills the state
+    if (SPLIT) pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: hand this step's records to the contact wave
     STAMP(0);
     PD_WAIT_VMEM();
     float tgt[ND], act[ND];
@@ -745,52 +693,17 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (!SPLIT) {
       WAVE_SYNC();
       int log_n;
-      sweep_contacts<SEGW, 6, PD_W6, true, PD_RECF>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, (float *)hits, facc,
+      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
                                            is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY, log_n, contact_hit STAMP_PASS);
       write_hit_log<SEGW>(a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, hits, log_n, env_ok, l);
     }
     STAMP(1);
-    // ---- eval_body_contacts for this lane's candidates (fused mode), then eval_body_joints for this lane's body
-    bool touching = false, touching2 = false;
-    float cw6[6], cw6b[6];
-    if (SPLIT && cmode == PD_CM_FUSED) {  // wave-uniform
-      touching = contact_hit(rec + ((c_e >> 24) & 0x3f) * PD_RECF, c_P, c_M, cw6) && l < c_nh;
-      if (two) touching2 = contact_hit(rec + ((c_e2 >> 24) & 0x3f) * PD_RECF, c_P2, c_M2, cw6b) && SEGW + l < c_nh;
-    }
+    // ---- eval_body_joints (runs while the contact wave sweeps)
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
-    if (HPJ) {
-      joint_fwd<JT, false, true>(m, c, s, rc, Rm, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
-      wc_t = jointed ? wc_t : V3(0, 0, 0); wc_f = jointed ? wc_f : V3(0, 0, 0);
-    } else if (is_body && c.type != PD_JOINT_FREE) {
-      joint_fwd<JT, JT == PD_JT_COMPOUND>(m, c, s, rc, Rm, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
-    }
+    if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT, JT == PD_JT_COMPOUND>(m, c, s, rc, Rm, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
     if (is_body) {
       float *pc = pcon + b * PD_W6;
       pc[0] = wp_t.x; pc[1] = wp_t.y; pc[2] = wp_t.z; pc[3] = wp_f.x; pc[4] = wp_f.y; pc[5] = wp_f.z;
-    }
-    if (SPLIT) {
-      if (cmode == PD_CM_FUSED) {
-        if (touching) {
-          float *fa = facc + ((c_e >> 24) & 0x3f) * PD_W6;
-#pragma unroll
-          for (int i = 0; i < 6; ++i) atomicAdd(fa + i, cw6[i]);
-        }
-        // the adjoint's log: the candidates that touch, in candidate order
-        int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
-        int log_n = 0;
-        const int sl = seg_slot(touching, sm, log_n);
-        if (touching && env_ok && sl < PD_HITLOG - 1) lg[1 + sl] = c_e;
-        if (two) {  // (a body's candidates are contiguous in the list, so the order of the sums is the list's either way)
-          if (touching2) {
-            float *fa = facc + ((c_e2 >> 24) & 0x3f) * PD_W6;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) atomicAdd(fa + i, cw6b[i]);
-          }
-          const int sl2 = seg_slot(touching2, sm, log_n);
-          if (touching2 && env_ok && sl2 < PD_HITLOG - 1) lg[1 + sl2] = c_e2;
-        }
-        if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
-      }
     }
     STAMP(2);
     WAVE_SYNC();
@@ -814,11 +727,15 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       }
     }
     STAMP(6);
-    spill_state(step, s, fr);
-    if (step > 0) spill_wrench(step - 1);
     if (SPLIT) {
-      if (cmode != PD_CM_FUSED) word_wait<false>(sig + 1, step + 1);  // B: the helper's contact wrenches are complete
+      // the previous step's trajectory record and frame outputs are issued where this wave is about to wait anyway (measured
+      // against right after hand-over A, and against after the vmcnt wait: -2 % / -0.5 % forward time at 4096 envs)
+      spill_state(step, s, fr);
+      if (step > 0) spill_wrench(step - 1);
+      pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
     } else {
+      spill_state(step, s, fr);
+      if (step > 0) spill_wrench(step - 1);
       WAVE_SYNC();
     }
     if (is_body) {
@@ -843,20 +760,23 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     o_vz = s.v.z; o_ft = ft; o_ff = ff;  // the total wrench goes to the trajectory with the clamp mask, one step late
     STAMP(3);
     // ---- integrate_bodies
-    float sink_rate, R1[9];
-    s = integrate_fwd(m, c, s, Rm, rc, ft, ff, inv_m, I, invI, a.dt, R1, rc, sink_rate, clamp_mask);
+    float sink_rate;
+    {
+      float R1[9];
+      s = integrate_fwd(m, c, s, Rm, rc, ft, ff, inv_m, I, invI, a.dt, R1, rc, sink_rate, clamp_mask);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Rm[k] = R1[k];
+      for (int k = 0; k < 9; ++k) Rm[k] = R1[k];
+    }
     o_mask = clamp_mask;
     STAMP(4);
-    if (SPLIT) {  // did every body stay inside the margin the helper speculated with?  (NaN counts as "no")
+    if (SPLIT) {  // did every body stay inside the margin the contact wave speculated with?  (NaN counts as "no")
       sunk += sink_rate * a.dt;
       const bool bad = is_body && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin);
       spec_failed = __ballot(bad) != 0ull;
     }
     WAVE_SYNC();
     if (is_body) {
-      float4 cv = stage_record_f(rec, cull, b, s, rc, Rm);
+      float4 cv = stage_record(rec, cull, b, s, rc, Rm);
       if (SPLIT && (step + 1) % PD_SPEC_K == 0) {  // state step+1 opens a speculation epoch
         margin = sink_margin(c, s, a.dt); sunk = 0.f;
         cv.x -= margin;
@@ -866,7 +786,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     if (!SPLIT) WAVE_SYNC();
     STAMP(5);
   }
-  if (SPLIT) pair_signal(sig, (a.nsteps + 1) | PD_REQ_DONE);
   if (a.nsteps > 0) spill_wrench(a.nsteps - 1);
   {  // a frame may name the state after the last step (state_steps[nsteps], dp_model.py:396,1241-1246); no force
      // snapshot exists for it (the reference appends grf / jaf for step in steps_idx only, :1225-1228): zero rows

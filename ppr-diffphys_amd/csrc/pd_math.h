@@ -80,6 +80,24 @@ PD_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi 
 // 1.0000001f must not turn into NaN.  POLICY, see DESIGN.md section 6.
 PD_DEV float acos_c(float x) { return acosf(clampf(x, -1.0f, 1.0f)); }
 PD_DEV float asin_c(float x) { return asinf(clampf(x, -1.0f, 1.0f)); }
+// Twist angle of a revolute joint (integrator_euler.py:394-400): the reference takes twist = normalize((axis (r.xyz . axis), r.w)) and
+// q = 2 acos(twist.w) sign(axis . twist.xyz).  With y = |axis| |r.xyz . axis| and x = r.w that is q = 2 sign(r.xyz . axis) atan2(y, x)
+// EXACTLY (acos(x / sqrt(x^2 + y^2)) = atan2(y, x) for y >= 0) -- and this is how it is evaluated here: acos near 1 turns one ulp of
+// twist.w into 7e-4 rad of a small joint angle and its derivative -1 / sqrt(1 - w^2) cancels catastrophically, so a literal fp32
+// evaluation (the fp32 C oracle does it) is 1e-3 .. 1 off the float64 value of the SAME function in most 100-step Laikago
+// rollouts; the atan2 form is accurate to an ulp and has no singular point at angle 0.  da = r.xyz . axis, alen = |axis|.
+// dq_dda, dq_dw: the partial derivatives, for the adjoint.  A NAMED DEVIATION in evaluation, not in the function.
+PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq_dw) {
+  const float y = fabsf(da) * alen, sgn = da < 0.0f ? -1.0f : 1.0f;
+  const float d = w * w + y * y, id = d > 0.0f ? 1.0f / d : 0.0f;
+  dq_dda = 2.0f * alen * w * id;
+  dq_dw = -2.0f * sgn * y * id;
+  return 2.0f * sgn * atan2f(y, w);
+}
+PD_DEV float twist_angle(float da, float w, float alen) {
+  const float y = fabsf(da) * alen;
+  return 2.0f * (da < 0.0f ? -1.0f : 1.0f) * atan2f(y, w);
+}
 PD_DEV float clamp_pass(float x, float lo, float hi) { return (x < lo || x > hi) ? 0.0f : 1.0f; }
 PD_DEV v3 clamp3(v3 a, float l) { return V3(clampf(a.x, -l, l), clampf(a.y, -l, l), clampf(a.z, -l, l)); }
 PD_DEV v3 clamp3_pass(v3 a, v3 g, float l) {

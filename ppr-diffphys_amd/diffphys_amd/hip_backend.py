@@ -212,6 +212,20 @@ class DeviceModel:
             p(jaf, "jaf", nframes * bs * nb * 6) if want_forces else None, _stream()))
         return wp_pos, wp_vel, grf, jaf, ws
 
+    def saved_trajectory(self, ws, bs, nsteps):
+        """The trajectory a forward rollout saved for its adjoint, unpacked from the workspace (inspection / tests): states of
+        steps 0 .. nsteps-1 in the reference's layouts -- body_q [T, bs*nb, 7], body_qd [T, bs*nb, 6] (angular first), the total
+        body wrench body_f [T, bs*nb, 6] (torque first) -- and the 6-bit mask of the velocity components each step's
+        integration clamped [T, bs*nb] (csrc/pd_kernels.hip: PD_TRAJ_G planes of float4)."""
+        N = bs * self.nb
+        pl = ws[: nsteps * 20 * N].view(nsteps, 5, N, 4)
+        q, wv, pv, vt, fm = pl[:, 0], pl[:, 1], pl[:, 2], pl[:, 3], pl[:, 4]
+        body_q = torch.cat([pv[..., :3], q], dim=-1)
+        body_qd = torch.cat([wv[..., :3], wv[..., 3:4], pv[..., 3:4], vt[..., 0:1]], dim=-1)
+        body_f = torch.cat([vt[..., 1:4], fm[..., :3]], dim=-1)
+        mask = fm[..., 3].contiguous().view(torch.int32)
+        return body_q, body_qd, body_f, mask
+
     def rollout_backward(self, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, body_inv_mass,
                          body_inertia, body_inv_inertia, frame2step, ws, adj_pos, adj_vel, out=None):
         nb, nq, nqd = self.nb, self.nq, self.nqd

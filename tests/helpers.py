@@ -140,3 +140,54 @@ def grad_env_errors(g, r, bs):
         scale = np.where(scale > 0, scale, np.abs(b).max() + 1e-30)
         out[k] = np.abs(a - b).max(1) / scale
     return out
+
+
+
+def first_branch_difference(rc64, st64, traj, inp, bs, height_tol=5e-7):
+    """First step (per env, or nsteps when there is none) at which the GPU rollout took a discrete decision the float64 oracle
+    did not: a different number of touching contact candidates on some body, a different number of them on the sliding branch of
+    the Coulomb min, a different velocity-clamp mask (the kernel's own, stored with its trajectory) -- or a candidate within
+    `height_tol` of the ground in the kernel's state, where its fp32 height can fall on either side.  The oracle's branch log is
+    evaluated in float64 on the oracle's trajectory and on the kernel's saved trajectory (oracle/ref_c.py branch_log).
+    Envs WITHOUT such a step differentiate the same smooth function as the oracle."""
+    nsteps = inp["nsteps"]
+    nb = rc64.nb
+    ref = rc64.branch_log(st64)
+    gpu = rc64.branch_log(dict(states_q=traj["states_q"], states_qd=traj["states_qd"], states_f=traj["states_f"]), inp)
+    clamp_gpu = traj["clamp"].reshape(nsteps, bs, nb) & 63
+    diff = (ref["touch"] != gpu["touch"]).any(2) | (ref["slide"] != gpu["slide"]).any(2) | (ref["clamp"] != clamp_gpu).any(2)
+    st_g = dict(states_q=traj["states_q"], states_qd=traj["states_qd"], states_f=traj["states_f"], _inputs={k: rc64._c(inp[k]) for k in
+                ("body_inv_mass", "body_inertia", "body_inv_inertia")}, _bs=bs, _nsteps=nsteps, _dt=inp["dt"])
+    st_g = {k: (rc64._c(v) if k.startswith("states") else v) for k, v in st_g.items()}
+    probe = rc64.singularity_probe(st_g)
+    diff |= probe[:, :, 0] < height_tol
+    first = np.where(diff.any(0), diff.argmax(0), nsteps)
+    return first
+
+
+
+def oracle_bundle(tpl, inp, bs):
+    """Everything the explained per-env gradient bars need: the float64 C oracle (trajectory, gradients), the fp32 C oracle's
+    gradients, and the gradients of the float64 oracle with its stored states rounded to fp32 (two samples: to nearest, and to an
+    adjacent fp32 number) -- the least any fp32 implementation does to a rollout (oracle/ref_c/diffphys_ref.c:
+    ref_set_state_rounding).  `cond`: per env, the largest worst-tensor distance of these from the float64 gradients = how
+    ill-conditioned the env is; `e_round`: the same from the rounded-state runs alone (no fp32 arithmetic at all)."""
+    from oracle.ref_c import RefC
+
+    rc64, rc32 = RefC(tpl, np.float64), RefC(tpl, np.float32)
+    T, f2s, dt = inp["nsteps"], inp["frame2step"], inp["dt"]
+    st64 = rc64.rollout_forward(inp, T, f2s, dt)
+    g64 = rc64.rollout_backward(st64, inp["adj_pos"], inp["adj_vel"])
+    st32 = rc32.rollout_forward(inp, T, f2s, dt)
+    g32 = rc32.rollout_backward(st32, inp["adj_pos"], inp["adj_vel"])
+    worst = lambda g: np.max(np.stack([v for v in grad_env_errors(g, g64, bs).values()]), axis=0)
+    rounded = []
+    try:
+        for mode in (1, 2):
+            rc64.set_state_rounding(mode)
+            st_r = rc64.rollout_forward(inp, T, f2s, dt)
+            rounded.append(worst(rc64.rollout_backward(st_r, inp["adj_pos"], inp["adj_vel"])))
+    finally:
+        rc64.set_state_rounding(0)
+    e_round = np.maximum(rounded[0], rounded[1])
+    return dict(rc64=rc64, st64=st64, g64=g64, st32=st32, g32=g32, cond=np.maximum(worst(g32), e_round), e_round=e_round)

@@ -29,7 +29,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def gpu_rollout(dm, inp, dev, backward=True):
+def gpu_rollout(dm, inp, dev, backward=True, keep_traj=False):
     from diffphys_amd import dp_model
 
     bs = inp["q_init"].size // dm.nq
@@ -41,6 +41,9 @@ def gpu_rollout(dm, inp, dev, backward=True):
     if backward:
         g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], fos, ws, t["adj_pos"], t["adj_vel"])
         out["grads"] = {k: v.cpu().numpy() for k, v in g.items()}
+    if keep_traj:  # the states, total wrenches and clamp masks the kernel saved for its adjoint
+        bq, bqd, bf, mask = dm.saved_trajectory(ws, bs, T)
+        out["traj"] = dict(states_q=bq.cpu().numpy(), states_qd=bqd.cpu().numpy(), states_f=bf.cpu().numpy(), clamp=mask.cpu().numpy())
     return out
 
 
@@ -81,14 +84,22 @@ def test_vs_c_oracle_fresh_seed(name, bs, dev, oracle_libs):
     inp["res_f"] = (rng.randn(*inp["res_f"].shape) * 0.5).astype(np.float32)
     inp["qd_init"] = (rng.randn(*inp["qd_init"].shape) * 0.1).astype(np.float32)
     out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
-    rc = RefC(tpl, np.float32)
+    # the float64 oracle is the authority; the fp32 oracle evaluates the revolute twist angle literally (2 acos(twist.w): one ulp
+    # of twist.w is 7e-4 rad at a small angle), the kernel through atan2 (pd_math.h twist_angle) -- for Laikago the kernel is
+    # the closer of the two to float64, so it is no longer compared with the fp32 oracle's gradients
+    rc = RefC(tpl, np.float64)
     st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
     gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    rc32 = RefC(tpl, np.float32)
+    st32 = rc32.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    g32 = rc32.rollout_backward(st32, inp["adj_pos"], inp["adj_vel"])
     assert np.abs(st["grf"]).max() > 1.0, "contacts must be active in this test"
     assert relmax(out["wp_pos"], st["wp_pos"]) < 5e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 2e-3
     assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 5e-3
     for k in GRADS:
-        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+        e, e32 = relmax(out["grads"][k].reshape(gr[k].shape), gr[k]), relmax(g32[k], gr[k])
+        print("%s %-18s kernel vs float64 %.1e   fp32 oracle vs float64 %.1e" % (name, k, e, e32))
+        assert e < max(2e-2, 2 * e32), k
 
 
 def test_long_rollout_statistics_and_invariants(dev, oracle_libs):
@@ -264,16 +275,17 @@ def test_config_c3_human_1024(dev, oracle_libs):
 
 def test_config_c5_quad_8192_gradcheck(dev, oracle_libs):
     """BASELINE config C5: AI4Animation quadruped (26 bodies, 25 compound joints), contact-rich, 8192 envs.
-    Gradient check of every input against the float64 C oracle.  The config's rtol 1e-4 is met on a short
-    horizon (4 steps); over a full frame interval fp32 round-off through the stiff contact/attachment springs
-    limits agreement to the 2e-2 bar stated at the top of this file (the fp32 C oracle behaves the same)."""
+    Gradient check of every input against the float64 C oracle, per env, relative to each tensor's max.  The config's rtol 1e-4
+    is the median bar at BOTH horizons -- 4 steps and the config's own T = 34 (one frame interval) -- with the per-env 99th
+    percentile at 1e-2 for T = 34 (round 2 had 2e-2 / 1.0 there).  The envs above the median bar are the
+    ones that sit on a contact edge (see test_config_size_gradients_every_tensor_per_env for the explained per-env version)."""
     from diffphys_amd import hip_backend, robots, synth
     from oracle.ref_c import RefC
 
     tpl = robots.load_template("quad")
     bs = 8192
     dm = hip_backend.DeviceModel(tpl)
-    for T, tol in ((4, 1e-4), (34, 2e-2)):
+    for T, tol, p99 in ((4, 1e-4, 5e-3), (34, 1e-4, 1e-2)):
         inp = synth.make_inputs(tpl, "quad", bs=bs, nsteps=T, seed=31, steps_per_frame=3 if T == 4 else 33, penetration=0.004)
         rng = np.random.RandomState(2)
         inp["qd_init"] = (rng.randn(*inp["qd_init"].shape) * 0.1).astype(np.float32)
@@ -287,14 +299,15 @@ def test_config_c5_quad_8192_gradcheck(dev, oracle_libs):
             ref = gr[k]
             if np.abs(ref).max() == 0:
                 continue
-            g = out["grads"][k].reshape(bs, -1).astype(np.float64)
-            r = ref.reshape(bs, -1) if k not in ("torques", "res_f", "refs") else None
-            if r is None:  # [T, bs*n] layouts: compare whole tensor
-                assert relmax(out["grads"][k].reshape(ref.shape), ref) < 50 * tol, (T, k)
-                continue
+            if k in ("torques", "res_f", "refs"):  # [T, bs*n] layouts
+                g = out["grads"][k].reshape(T, bs, -1).astype(np.float64).transpose(1, 0, 2).reshape(bs, -1)
+                r = ref.reshape(T, bs, -1).transpose(1, 0, 2).reshape(bs, -1)
+            else:
+                g, r = out["grads"][k].reshape(bs, -1).astype(np.float64), ref.reshape(bs, -1)
             per_env = np.abs(g - r).max(1) / (np.abs(r).max() + 1e-30)
+            print("C5 T=%d %-18s median %.1e p99 %.1e max %.1e" % (T, k, np.median(per_env), np.percentile(per_env, 99), per_env.max()))
             assert np.median(per_env) < tol, (T, k, float(np.median(per_env)))
-            assert np.percentile(per_env, 99) < 50 * tol, (T, k, float(np.percentile(per_env, 99)))
+            assert np.percentile(per_env, 99) < p99, (T, k, float(np.percentile(per_env, 99)))
 
 
 def test_phys_model_training_iterations(dev):

@@ -121,31 +121,54 @@ def _config_inputs(cfg):
 
 @pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
 def test_config_size_gradients_every_tensor_per_env(cfg, dev, oracle_libs):
-    """BASELINE configs C2 / C3 / C4 at full size (C4 = the headline 4096 x 100 batch): poses with the statistical bar of
-    the module docstring of test_gpu_parity, and EVERY gradient tensor per env against the C oracles."""
+    """BASELINE configs C2 / C3 / C4 at full size (C4 = the headline 4096 x 100 batch): poses with the statistical bar of the
+    module docstring of test_gpu_parity, and EVERY gradient tensor of EVERY env against the float64 C oracle, with each env
+    that is off EXPLAINED rather than counted:
+
+      * conditioning: how far the env's gradients move when the float64 oracle merely stores its states in fp32, and when the
+        whole oracle runs in fp32 (helpers.oracle_bundle) -- the larger of the two is the env's conditioning scale `cond`.  Measured:
+        the kernel's error is 1.3 x the rounded-state oracle's in the median (C2, C4), i.e. at the fp32 storage limit;
+      * branch difference: the first step at which the kernel took a discrete decision the float64 oracle did not -- another number
+        of touching contact candidates on a body, of candidates on the sliding branch of the Coulomb min, another velocity-clamp
+        mask, or a candidate within 5e-7 m of the ground in the kernel's own state (helpers.first_branch_difference).  ke = 1e4
+        N/m makes the gradient jump there while every value stays within rounding.
+    An env is explained when its worst-tensor error is <= max(30 cond, 1e-3) or it has a branch difference; there must be none
+    that is not.  So that the explanation cannot swallow a real adjoint bug: envs WITHOUT a branch difference must be tight
+    (human: every one < 5e-4; Laikago: 99 % < 2e-3 and all < 1e-2 wherever the rounded-state runs alone move the env by < 1e-3), most envs must pass on conditioning alone, and the kernel's
+    median error must stay within 3 x the rounded-state oracle's."""
+    from helpers import first_branch_difference, oracle_bundle
     from diffphys_amd import hip_backend
 
     name, tpl, bs, inp = _config_inputs(cfg)
-    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
-    s64, g64 = _oracle(tpl, inp, np.float64)
-    s32, g32 = _oracle(tpl, inp, np.float32)
-    F = len(inp["frame2step"])
-    e = np.abs(out["wp_pos"].astype(np.float64) - s32["wp_pos"]).reshape(F, bs, -1).max((0, 2))
+    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev, keep_traj=True)
+    ob = oracle_bundle(tpl, inp, bs)
+    F, T = len(inp["frame2step"]), inp["nsteps"]
+    e = np.abs(out["wp_pos"].astype(np.float64) - ob["st32"]["wp_pos"]).reshape(F, bs, -1).max((0, 2))
     assert np.median(e) < 1e-5 and np.percentile(e, 90) < 1e-3, (np.median(e), np.percentile(e, 90))
     assert all(np.isfinite(v).all() for v in out["grads"].values())
-    e_gpu = grad_env_errors(out["grads"], g64, bs)   # GPU fp32 vs float64 oracle
-    e_c32 = grad_env_errors(g32, g64, bs)            # fp32 oracle vs float64 oracle: the conditioning of each env
-    for k in GRAD_LEAD:
-        if name == "human":  # well conditioned: 99 % of the envs below 1e-4, and EVERY env as good as a plain fp32 evaluation
-            assert np.percentile(e_gpu[k], 99) < 1e-4, (k, float(np.percentile(e_gpu[k], 99)))
-            worst = int(np.argmax(e_gpu[k] - np.maximum(10 * e_c32[k], 1e-3)))
-            assert e_gpu[k][worst] <= max(10 * e_c32[k][worst], 1e-3), (k, worst, float(e_gpu[k][worst]), float(e_c32[k][worst]))
-            continue
-        regular = e_c32[k] < 1e-2
-        assert regular.mean() > 0.5, (k, float(regular.mean()))
-        assert np.median(e_gpu[k]) < 2e-2, (k, float(np.median(e_gpu[k])), float(np.median(e_c32[k])))
-        agree = (e_gpu[k][regular] < 5e-2).mean()
-        assert agree >= 0.9, (k, float(agree))
+    e_gpu = grad_env_errors(out["grads"], ob["g64"], bs)   # GPU fp32 vs float64 oracle, per tensor and env
+    worst = np.max(np.stack([e_gpu[k] for k in GRAD_LEAD]), axis=0)
+    cond = ob["cond"]
+    first = first_branch_difference(ob["rc64"], ob["st64"], out["traj"], inp, bs)
+    branch = first < T
+    by_cond = worst <= np.maximum(30 * cond, 1e-3)
+    unexplained = np.nonzero(~by_cond & ~branch)[0]
+    print("%s: %d envs, %d with a branch difference, %d explained by conditioning alone, %d above 1e-3, %d unexplained; median error %.1e (cond %.1e)" % (
+        cfg, bs, branch.sum(), by_cond.sum(), (worst > 1e-3).sum(), len(unexplained), np.median(worst), np.median(cond)))
+    assert len(unexplained) == 0, [(int(i), float(worst[i]), float(cond[i])) for i in unexplained[:8]]
+    assert by_cond.mean() > 0.9, float(by_cond.mean())
+    assert np.median(worst) <= 3 * max(np.median(ob["e_round"]), 1e-5), (float(np.median(worst)), float(np.median(ob["e_round"])))
+    regular = ~branch
+    if name == "human":  # well conditioned: every env that took the oracle's decisions agrees to 5e-4 in every tensor
+        assert regular.mean() > 0.95 and worst[regular].max() < 5e-4, (float(regular.mean()), float(worst[regular].max()))
+        assert np.percentile(worst, 99) < 1e-4, float(np.percentile(worst, 99))
+    else:
+        # conditioning from the rounded-state runs alone (the fp32 oracle's literal acos is noisier than the kernel): measured C2 / C4
+        # 133 / 1 255 such envs, kernel error at most 4e-4 / 5e-3
+        calm = regular & (ob["e_round"] < 1e-3)
+        print("   calm envs: %d, worst %.1e" % (calm.sum(), worst[calm].max() if calm.any() else 0.0))
+        assert calm.sum() > 0.05 * bs, int(calm.sum())
+        assert np.percentile(worst[calm], 99) < 2e-3 and worst[calm].max() < 1e-2, (float(np.percentile(worst[calm], 99)), float(worst[calm].max()))
 
 
 def test_frames_validated_on_the_host_and_final_state_frame(dev, oracle_libs):
@@ -279,20 +302,22 @@ def test_timing_is_per_model_and_launch_info(dev):
 
 
 @pytest.mark.parametrize("name", ["laikago", "human", "quad"])
-def test_against_round1_bits(name, dev):
-    """A/B against frozen libraries ("keep the A/B in a test"): tests/golden/r01_bits_<robot>.npz hold the raw
-    fp32 outputs of the round-1 kernels (scripts/make_r01_bits.py) on the golden inputs and on a 8-env x 100-step batch,
-    r02_bits_{human,quad}.npz the same of the round-2 kernels (scripts/make_bits.py).
+def test_against_frozen_bits(name, dev):
+    """A/B against frozen libraries: tests/golden/<tag>_bits_<robot>.npz hold the raw fp32 outputs of the round-1 kernels (r01,
+    scripts/make_r01_bits.py), of the round-2 kernels (r02, human / quad only) and of this round's (r03, scripts/make_bits.py) on
+    the golden inputs and on an 8-env x 100-step batch.
 
-    * FORWARD outputs must be bit-identical to the frozen reference of the robot: r01 for Laikago (its forward arithmetic has not
-      changed since round 1); r02 for human / quad, whose compound-joint forward pass was restructured in round 2 (the same
-      terms without the products with the exact zeros of identity frames and basis vectors) -- and those must stay within 1e-5
-      of r01 on the golden (34-step) inputs (measured: poses 7e-8 / 9e-8, one ulp; velocities and wrenches 2e-6).
-    * GRADIENTS must be bit-identical to the frozen reference or agree to 1e-5 of each tensor's max on the golden inputs (human /
-      quad against r01, whose trajectory is one ulp away: 1e-4; measured 2.4e-5 for quad's target_kd gradient): the adjoint was
-      restructured across waves (FMA contraction boundaries move) and rotates by matrices where one quaternion rotates several
-      vectors (rotm / rotm_adj: same map, different rounding).  Measured against r01: 2e-6 Laikago, 5e-6 human / quad.
-    The 100-step batch is printed only for gradients: over 100 steps of contact dynamics a last-bit difference grows to ~3e-5.
+    The parity authority is the oracle (test_short_horizon_tight, the config-size tests), not an older build of this library:
+    round 3 moved the forward pass to matrix-form rotations (rotm: the same linear map, other roundings) and pinned the contact
+    height's roundings, so its outputs are ulps away from r01 / r02.  What this test guards:
+      * the NEWEST fixture is a regression pin: forward outputs bit-identical, gradients bit-identical or within 1e-5 of each
+        tensor's max on the golden inputs -- an edit that is meant to keep the arithmetic must keep the bits;
+      * every OLDER fixture bounds the drift: golden (34-step) poses within 1e-5 of the tensor's max, twists / wrenches within
+        1e-4, gradients within 5e-4 (measured r03 vs r01: twists 1e-5 Laikago, 6e-5 quad; gradients 2e-4 quad), and for human /
+        quad the gradients of the 100-step batch within 1e-3 of each tensor's max -- a real adjoint regression on the long
+        rollout fails here, an ulp does not.  (Laikago's 100-step gradients are printed only: they move by 0.2 between r01 and
+        this round -- r01 evaluated the twist angle through acos -- which is what test_config_size_gradients_every_tensor_per_env
+        explains env by env against the float64 oracle.)
     (pytest -s shows the distances.)"""
     import os
 
@@ -300,14 +325,14 @@ def test_against_round1_bits(name, dev):
     from diffphys_amd import hip_backend, robots, synth
 
     refs = {}
-    for tag in ("r01", "r02"):
+    for tag in ("r01", "r02", "r03"):
         path = os.path.join(GOLDEN, "%s_bits_%s.npz" % (tag, name))
         if os.path.exists(path):
             with np.load(path) as z:
                 refs[tag] = {k: z[k] for k in z.files}
-    if "r01" not in refs:
-        pytest.skip("r01 bit fixtures not recorded")
-    frozen = "r02" if "r02" in refs else "r01"  # the reference this robot's forward pass is frozen against
+    if not refs:
+        pytest.skip("no bit fixtures recorded")
+    newest = "r03" if "r03" in refs else None
     tpl = robots.load_template(name)
     dm = hip_backend.DeviceModel(tpl)
     for tag, inp in (("golden", golden_inputs(load_golden(name))),
@@ -321,13 +346,18 @@ def test_against_round1_bits(name, dev):
                 same = np.array_equal(v.reshape(r.shape), r)
                 d = relmax(v.reshape(r.shape), r)
                 print("%s %s vs %s %-22s %s relmax %.2e" % (name, tag, which, k, "bit-identical" if same else "differs", d))
-                if not k.startswith("grad_"):
-                    if which == frozen:
+                grad = k.startswith("grad_")
+                if which == newest:
+                    if not grad:
                         assert same, (tag, which, k, d)
                     elif tag == "golden":
-                        assert d < 1e-5, (tag, which, k, d)
+                        assert same or d < 1e-5, (tag, which, k, d)
+                    else:
+                        assert same or d < 1e-3, (tag, which, k, d)
                 elif tag == "golden":
-                    assert same or d < (1e-5 if which == frozen else 1e-4), (tag, which, k, d)
+                    assert d < (5e-4 if grad else (1e-4 if k != "wp_pos" else 1e-5)), (tag, which, k, d)
+                elif grad and name != "laikago":
+                    assert d < 1e-3, (tag, which, k, d)
 
 
 @pytest.mark.parametrize("name,bs", [("human", 1024), ("quad", 2048)])
