@@ -6,15 +6,19 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   * a "step" = one forward rollout + one adjoint rollout over the rank's batch: bs envs x T sim steps
   * workload (BASELINE.json metric / SURVEY.md section 8(d) config C4): Laikago, mixed mi-trot / mi-spin
     mocap targets, T = 100 sim steps (4 frames, frame2step = 0,33,66,99), dt = 5e-4, fp32.
-    --scaling weak (default): 4096 envs PER GPU, global batch N x 4096.
-    --scaling strong: 4096 envs GLOBAL, rank r rolls out the contiguous slice shard_envs(4096, N, r) (C4 as SURVEY
-    writes it: 512 per GPU at N = 8).
+    --scaling strong (default; the BASELINE metric "batch=4096 at 1/2/4/8 MI355X" = SURVEY C4): 4096 envs GLOBAL, rank r rolls
+    out the contiguous slice shard_envs(4096, N, r) (512 per GPU at N = 8).
+    --scaling weak: 4096 envs PER GPU, global batch N x 4096.
     Either way every rank builds ITS slice of one global batch (per-env seeded: the slices concatenate to the
     same global batch for any N), envs are independent, and there is no collective on the data path
-  * inputs are resident in HBM before the timed region; timed region is bracketed by barrier + synchronize; after the W
-    warm-up steps the bench keeps stepping, untimed, for 0.25 s (clock ramp of an idle box), then times exactly K steps
-  * rank 0 prints ONE JSON line (value = whole-job env-steps/s, max time over ranks); for N > 1 the line also carries
-    "other_scaling": the same measurement in the other mode (so one scaling run holds the strong AND the weak row)
+  * inputs are resident in HBM before the timed region; after the W warm-up steps the bench keeps stepping, untimed, for 0.25 s
+    (clock ramp of an idle box; the line's "warmup_extra_steps" says how many steps that was), then times R = --repeats (10)
+    BLOCKS of exactly K steps, each bracketed by barrier + synchronize, MAX over ranks per block.  value / ms_per_step are the
+    MEDIAN block ("median of >= 10 repeats"); "blocks" carries min / max / all of them
+  * rank 0 prints ONE JSON line (value = whole-job env-steps/s); for N > 1 the line also carries "other_scaling": the same
+    measurement in the other mode (so one scaling run holds the strong AND the weak row)
+  * "boundary": the same workload timed one level up, through the reference's autograd boundary -- ForwardWarp.apply(...) then
+    .backward() on tensors that require grad, workspace / output / gradient allocation included (N = 1 only)
 
 Extra objects on the line:
   roofline     dominant kernel (the adjoint rollout): algorithmic HBM bytes per launch / its average launch
@@ -115,13 +119,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+    ap.add_argument("--repeats", type=int, default=10, help="timed blocks of --steps steps; the median block is reported")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
                     help="weak: --bs envs per GPU; strong: --bs envs in total, sharded across the GPUs")
     ap.add_argument("--bs", type=int, default=GLOBAL_BS, help="envs per GPU (weak) / global batch (strong)")
     ap.add_argument("--T", type=int, default=100, help="sim steps per rollout")
     ap.add_argument("--robot", default="laikago")
     ap.add_argument("--segw", type=int, default=0, help="lanes per articulation (0 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the autograd-boundary measurement")
     ap.add_argument("--both", action="store_true", help="also measure the other scaling mode at N = 1 (always done for N > 1)")
     args = ap.parse_args()
 
@@ -183,8 +189,11 @@ def main():
 
         return step, bs, gbs
 
+    extra_warm = [0]
+
     def timed(step):
-        """W untimed steps, then exactly K steps between barrier + synchronize brackets; MAX over ranks"""
+        """W untimed steps (+ the clock ramp), then R blocks of exactly K steps, each between barrier + synchronize brackets, MAX over
+        ranks per block; returns the per-block times (s) and the last gradients"""
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -192,26 +201,61 @@ def main():
         # 2.2 ms per step instead of 0.61 for the first bench process on some boxes, 0.61 for every later one): keep warming,
         # untimed, until a quarter of a second of work has gone through -- W steps of 0.6 ms do not wake the clocks up
         t_warm = time.perf_counter()
+        extra_warm[0] = 0
         while time.perf_counter() - t_warm < 0.25:
             for _ in range(10):
                 step()
+            extra_warm[0] += 10
             torch.cuda.synchronize()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            g = step()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
+        blocks = []
+        g = None
+        for _ in range(max(1, args.repeats)):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                g = step()
+            torch.cuda.synchronize()
+            barrier()
+            blocks.append(time.perf_counter() - t0)
         if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            tt = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        return elapsed, g
+            blocks = [float(x) for x in tt.tolist()]
+        return blocks, g
+
+    def boundary_step_factory():
+        """the same rank-0 workload through the reference's autograd boundary (diffphys_amd/dp_model.py ForwardWarp): tensors that
+        require grad, workspace / outputs / gradients allocated per call by the op, loss.backward() through autograd"""
+        from diffphys_amd import dp_model
+
+        inp, (lo, hi), _ = rank_inputs(tpl, args.robot, T, world, rank, args.scaling, args.bs, seqs)
+        nenv = hi - lo
+
+        class Host:
+            pass
+
+        h = Host()
+        h.env = robots.env_from_template(args.robot, nenv, device=dev)
+        h.num_envs, h.steps_idx, h.frame2step, h.dt = nenv, range(T), inp["frame2step"], inp["dt"]
+        t = {k: torch.from_numpy(inp[k]).to(dev).requires_grad_(True) for k in synth.INPUT_NAMES}
+        adj_pos = torch.from_numpy(inp["adj_pos"]).to(dev)
+        adj_vel = torch.from_numpy(inp["adj_vel"]).to(dev)
+        args_ = [t[k] for k in synth.INPUT_NAMES]
+
+        def step():
+            for v in args_:
+                v.grad = None
+            pos, vel = dp_model.ForwardWarp.apply(*args_, h)
+            torch.autograd.backward([pos, vel], [adj_pos.view_as(pos), adj_vel.view_as(vel)])
+            return {"q_init": t["q_init"].grad}
+
+        return step
 
     step, bs, gbs = setup(args.scaling)
-    elapsed, g = timed(step)
+    blocks, g = timed(step)
+    elapsed = float(np.median(blocks))  # the median block: ms_per_step x steps = one real K-step block
+    warm_extra = extra_warm[0]
     bad = int(torch.isnan(g["q_init"]).sum().item())
 
     # per-kernel device time (HIP events on the launch stream around each launch, pd_model_set_timing), in an extra pass outside
@@ -236,9 +280,21 @@ def main():
     if world > 1 or args.both:
         o_mode = "strong" if args.scaling == "weak" else "weak"
         o_step, o_bs, o_gbs = setup(o_mode)
-        o_elapsed, _ = timed(o_step)
+        o_blocks, _ = timed(o_step)
+        o_elapsed = float(np.median(o_blocks))
         other = {"scaling": o_mode, "value": o_gbs * T * args.steps / o_elapsed, "unit": "env-steps/s", "ms_per_step": o_elapsed / args.steps * 1e3,
-                 "global_batch": o_gbs, "envs_per_gpu": o_bs}
+                 "global_batch": o_gbs, "envs_per_gpu": o_bs,
+                 "blocks": {"n": len(o_blocks), "min_value": o_gbs * T * args.steps / max(o_blocks), "max_value": o_gbs * T * args.steps / min(o_blocks)}}
+
+    boundary = None
+    if world == 1 and not args.no_boundary:
+        b_blocks, gb = timed(boundary_step_factory())
+        b_elapsed = float(np.median(b_blocks))
+        boundary = {"value": gbs * T * args.steps / b_elapsed, "unit": "env-steps/s", "ms_per_step": b_elapsed / args.steps * 1e3,
+                    "ratio_to_value": elapsed / b_elapsed,
+                    "what": "ForwardWarp.apply + autograd backward on requires_grad tensors: workspace / output / gradient allocation, "
+                            "save_for_backward and the in-kernel remove_nan included; median of %d blocks of %d steps" % (len(b_blocks), args.steps),
+                    "nan_grads": int(torch.isnan(gb["q_init"]).sum().item())}
 
     if rank == 0:
         nb, nqd = int(tpl["nb"]), int(tpl["nqd"])
@@ -275,7 +331,10 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_extra_steps": warm_extra,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "blocks": {"n": len(blocks), "statistic": "median", "min_value": gbs * T * args.steps / max(blocks),
+                       "max_value": gbs * T * args.steps / min(blocks), "ms_per_step_all": [b / args.steps * 1e3 for b in blocks]},
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -294,6 +353,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
+                "limiter": "instruction issue / dependency-chain latency of one wave per SIMD (frac of HBM is what the contract asks for; "
+                           "see secondary: VALU busy, waves per SIMD)",
                 "kernel": "k_rollout_bwd",
                 "achieved": ach_bwd / 1e9,
                 "peak": HBM_PEAK_BYTES / 1e9,
@@ -316,6 +377,8 @@ def main():
         }
         if other is not None:
             line["other_scaling"] = other
+        if boundary is not None:
+            line["boundary"] = boundary
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tpl, args.robot, T, seqs)
         print(json.dumps(line))

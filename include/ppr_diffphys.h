@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 3   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height */
+#define PD_ABI_VERSION 4   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -104,7 +104,10 @@ int pd_rollout_forward(const pd_model *m, int bs, int nsteps, float dt,
                        float *wp_pos_dev, float *wp_vel_dev, float *grf_dev, float *jaf_dev, void *stream);
 
 /* Gradients are OVERWRITTEN (not accumulated).  g_*_dev mirror the input shapes.  body_mass has no
- * direct gradient (integrator_euler.py:43 loads it, nothing uses it), so there is no g_body_mass. */
+ * direct gradient (integrator_euler.py:43 loads it, nothing uses it), so there is no g_body_mass.
+ * Every stored gradient has been through the boundary's remove_nan (diffphys/dp_model.py:1294-1384 with
+ * diffphys/dp_utils.py:43-57, clip=False): NaN -> 0, +-inf kept -- applied by the kernel at its stores (ABI v4; up to v3
+ * the caller had to scrub). */
 int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
                         const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
                         const float *refs_dev, const float *target_ke_dev, const float *target_kd_dev,
@@ -119,6 +122,8 @@ int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
 /* n independent articulations: joint_q [n][nq], joint_qd [n][nqd] -> body_q [n][nb][7], body_qd [n][nb][6] */
 int pd_fk_forward(const pd_model *m, int n, const float *joint_q_dev, const float *joint_qd_dev,
                   float *body_q_dev, float *body_qd_dev, void *stream);
+/* The gradients come out with ForwardKinematics.backward's post-processing (diffphys/dp_model.py:1109-1110, 1122-1123):
+ * NaN -> 0, then values above 1 -> 1 (an upper clamp only) -- applied by the kernel at its stores (ABI v4). */
 int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const float *joint_qd_dev,
                    const float *adj_body_q_dev, const float *adj_body_qd_dev,
                    float *g_joint_q_dev, float *g_joint_qd_dev, void *stream);

@@ -196,9 +196,11 @@ PD_DEV BodyState fk_joint(const BodyConst &c, const float *jq, const float *jqd,
 
 // Adjoint of fk_joint: g = adjoint of this body's (p,q,w,v); writes the joint-coordinate
 // gradients (overwrite) and returns the contribution to the parent's state adjoint.
-template <int JT>
+// POST: post-processing of the stored joint-coordinate gradients (pd_math.h grad_post).
+template <int JT, int POST>
 PD_DEV BodyAdj fk_joint_adj(const BodyConst &c, const float *jq, const float *jqd, const float *rec, const BodyAdj &g,
                             float *gq, float *gqd) {
+  auto P = [](float x) { return grad_post<POST>(x); };
   v3 p_wp = V3(0, 0, 0);
   qt q_wp = Q4(0, 0, 0, 1);
   if (c.parent >= 0) {
@@ -226,17 +228,17 @@ PD_DEV BodyAdj fk_joint_adj(const BodyConst &c, const float *jq, const float *jq
   if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
     float a = 0.f;
     adj_q_axis_angle_ang(c.axis, jq[0], a, adj_q_jc);
-    gq[0] = a;
-    gqd[0] = dot(c.axis, adj_w_jc);
+    gq[0] = P(a);
+    gqd[0] = P(dot(c.axis, adj_w_jc));
   } else if (c.type == PD_JOINT_FREE) {
-    gq[0] = adj_p_jc.x; gq[1] = adj_p_jc.y; gq[2] = adj_p_jc.z;
-    gq[3] = adj_q_jc.x; gq[4] = adj_q_jc.y; gq[5] = adj_q_jc.z; gq[6] = adj_q_jc.w;
-    gqd[0] = adj_w_jc.x; gqd[1] = adj_w_jc.y; gqd[2] = adj_w_jc.z;
-    gqd[3] = adj_v_jc.x; gqd[4] = adj_v_jc.y; gqd[5] = adj_v_jc.z;
+    gq[0] = P(adj_p_jc.x); gq[1] = P(adj_p_jc.y); gq[2] = P(adj_p_jc.z);
+    gq[3] = P(adj_q_jc.x); gq[4] = P(adj_q_jc.y); gq[5] = P(adj_q_jc.z); gq[6] = P(adj_q_jc.w);
+    gqd[0] = P(adj_w_jc.x); gqd[1] = P(adj_w_jc.y); gqd[2] = P(adj_w_jc.z);
+    gqd[3] = P(adj_v_jc.x); gqd[4] = P(adj_v_jc.y); gqd[5] = P(adj_v_jc.z);
   } else if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
     float aq0 = 0.f, aq1 = 0.f, aq2 = 0.f;
     v3 adj_a0 = adj_w_jc * jqd[0], adj_a1 = adj_w_jc * jqd[1], adj_a2 = adj_w_jc * jqd[2];
-    gqd[0] = dot(L.a0, adj_w_jc); gqd[1] = dot(L.a1, adj_w_jc); gqd[2] = dot(L.a2, adj_w_jc);
+    gqd[0] = P(dot(L.a0, adj_w_jc)); gqd[1] = P(dot(L.a1, adj_w_jc)); gqd[2] = P(dot(L.a2, adj_w_jc));
     qt q10 = qmul(L.q1, L.q0);
     qt adj_q2 = Q4(0, 0, 0, 0), adj_q10 = adj_q2, adj_q1 = adj_q2, adj_q0 = adj_q2;
     adj_qmul(L.q2, q10, adj_q2, adj_q10, adj_q_jc);
@@ -250,7 +252,7 @@ PD_DEV BodyAdj fk_joint_adj(const BodyConst &c, const float *jq, const float *jq
     adj_qrot_q(q0o, V3(0, 1, 0), adj_q0o, adj_a1);
     adj_qmul_a(c.q_off, adj_q0, adj_q0o);
     adj_q_axis_angle(L.a0, jq[0], adj_a0, aq0, adj_q0);
-    gq[0] = aq0; gq[1] = aq1; gq[2] = aq2;
+    gq[0] = P(aq0); gq[1] = P(aq1); gq[2] = P(aq2);
   }
   return par;
 }

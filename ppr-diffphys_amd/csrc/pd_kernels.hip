@@ -57,6 +57,11 @@ PD_DEV void stg2(float *ubase, unsigned boff, float2 v) { *(float2 *)((char *)ub
 // where (t, f) is the total body wrench of the step.  The adjoint's contact wave needs planes 0-1 of a body and 0-2 of its parent.
 #define PD_TRAJ_G 5
 
+// Every gradient the rollout adjoint stores goes through remove_nan (NaN -> 0, inf kept): the boundary's post-processing
+// (dp_model.py:1294-1384 of the reference), done here at ONE instruction per stored value (pd_math.h grad_post: v_med3_f32)
+// instead of ten passes over the tensors.
+#define NZ(x) grad_post<1>(x)
+
 template <int SEGW>
 struct Seg {
   static constexpr int EPW = 64 / SEGW;
@@ -1056,27 +1061,28 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       });
       if (is_body) {
         float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
-        stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
-        stg2(o + 4, boff * 6u, make_float2(adj_f0.y, adj_f0.z));
+        stg2(o, boff * 6u, make_float2(NZ(adj_t0.x), NZ(adj_t0.y))); stg2(o + 2, boff * 6u, make_float2(NZ(adj_t0.z), NZ(adj_f0.x)));
+        stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
       }
       STAMP(1);
       pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
     } else {
     integrate_adj(m, c, s, Rm, clamp_mask, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, adj_t0, adj_f0, g_inv_m, g_I, g_invI);
     if (is_body) {
-      float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
-      stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
-      stg2(o + 4, boff * 6u, make_float2(adj_f0.y, adj_f0.z));
       float *f = adjf + b * PD_W6;
       f[0] = adj_t0.x; f[1] = adj_t0.y; f[2] = adj_t0.z; f[3] = adj_f0.x; f[4] = adj_f0.y; f[5] = adj_f0.z;
     }
     STAMP(1);
-    if (SPLIT) {  // A: hand records + wrench adjoints to the contact wave, take its joint hand-over records
-      pair_signal(sig, a.nsteps - step);
-      pair_wait(sig + 1, a.nsteps - step);
-    } else {
-      WAVE_SYNC();
+    // A: hand records + wrench adjoints to the contact wave FIRST -- at 4096 envs it is the later wave of the pair, and whatever
+    // this wave does ahead of the signal delays it: with the remove_nan selects and the g_res_f stores before the signal the
+    // adjoint took 0.324 ms, behind it 0.312 (same-box A/B) -- then the stores, then take its joint hand-over records
+    if (SPLIT) pair_signal(sig, a.nsteps - step);
+    if (is_body) {
+      float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
+      stg2(o, boff * 6u, make_float2(NZ(adj_t0.x), NZ(adj_t0.y))); stg2(o + 2, boff * 6u, make_float2(NZ(adj_t0.z), NZ(adj_f0.x)));
+      stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
     }
+    if (SPLIT) pair_wait(sig + 1, a.nsteps - step); else WAVE_SYNC();
     }
     // ---- adjoint of eval_body_joints (runs while the contact wave sweeps)
     BodyAdj par = adj_zero();
@@ -1099,7 +1105,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       adj_store(cslot + b * PD_ADJ, par);
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
-        if (k < ndof) { stg(a.g_refs + oc + k, boff_qd, a_tgt[k]); stg(a.g_torques + oc + k, boff_qd, a_act[k]); }
+        if (k < ndof) { stg(a.g_refs + oc + k, boff_qd, NZ(a_tgt[k])); stg(a.g_torques + oc + k, boff_qd, NZ(a_act[k])); }
         g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k];
       }
       // the root's six dof columns are zero (a FREE joint reads no dof, integrator_euler.py:382).  Lanes 1..6 write one each
@@ -1176,20 +1182,20 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         int cid = (int)((c.children >> (8 * k)) & 0xffull);
         if (cid != 0xff) adj_add_from(gn, cslot + cid * PD_ADJ);
       }
-      BodyAdj par = fk_joint_adj<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
+      BodyAdj par = fk_joint_adj<JT, 1>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
                                      gn, a.g_q_init + (size_t)ec * m.nq + c.qstart, a.g_qd_init + (size_t)ec * m.nqd + c.qdstart);
       adj_store(cslot + b * PD_ADJ, par);
     }
     WAVE_SYNC();
   }
   if (is_body) {
-    a.g_inv_mass[idx] = g_inv_m;
+    a.g_inv_mass[idx] = NZ(g_inv_m);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { a.g_inertia[idx * 9 + k] = g_I[k]; a.g_inv_inertia[idx * 9 + k] = g_invI[k]; }
+    for (int k = 0; k < 9; ++k) { a.g_inertia[idx * 9 + k] = NZ(g_I[k]); a.g_inv_inertia[idx * 9 + k] = NZ(g_invI[k]); }
     const size_t og = (size_t)ec * m.nqd + c.qdstart;
 #pragma unroll
     for (int k = 0; k < ND; ++k)
-      if (k < ndof) { a.g_ke[og + k] = g_ke[k]; a.g_kd[og + k] = g_kd[k]; }
+      if (k < ndof) { a.g_ke[og + k] = NZ(g_ke[k]); a.g_kd[og + k] = NZ(g_kd[k]); }
     if (c.type == PD_JOINT_FREE) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) { a.g_ke[og + k] = 0.f; a.g_kd[og + k] = 0.f; }
@@ -1382,7 +1388,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       const size_t oc = (size_t)__builtin_amdgcn_readfirstlane(step) * a.bs * m.nqd;
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
-        if (is_body && k < ndof) { stg(a.g_refs + oc + k, boff_qd, a_tgt[k]); stg(a.g_torques + oc + k, boff_qd, a_act[k]); }
+        if (is_body && k < ndof) { stg(a.g_refs + oc + k, boff_qd, NZ(a_tgt[k])); stg(a.g_torques + oc + k, boff_qd, NZ(a_act[k])); }
         g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k];
       }
       if (zero_by_lanes) {
@@ -1504,7 +1510,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       const size_t og = (size_t)ec * m.nqd + c.qdstart;
 #pragma unroll
       for (int k = 0; k < ND; ++k)
-        if (k < ndof) { a.g_ke[og + k] = g_ke[k]; a.g_kd[og + k] = g_kd[k]; }
+        if (k < ndof) { a.g_ke[og + k] = NZ(g_ke[k]); a.g_kd[og + k] = NZ(g_kd[k]); }
       if (c.type == PD_JOINT_FREE) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { a.g_ke[og + k] = 0.f; a.g_kd[og + k] = 0.f; }
@@ -1623,8 +1629,8 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     rotm_adj(s.r, aR, ga.r);
     if (is_body) {
       float *o = a.g_res_f + (size_t)__builtin_amdgcn_readfirstlane(step) * N * 6;  // adjoint of wp_add
-      stg2(o, boff * 6u, make_float2(adj_t0.x, adj_t0.y)); stg2(o + 2, boff * 6u, make_float2(adj_t0.z, adj_f0.x));
-      stg2(o + 4, boff * 6u, make_float2(adj_f0.y, adj_f0.z));
+      stg2(o, boff * 6u, make_float2(NZ(adj_t0.x), NZ(adj_t0.y))); stg2(o + 2, boff * 6u, make_float2(NZ(adj_t0.z), NZ(adj_f0.x)));
+      stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
     }
     STAMP(1);
     if (ROLES == 2) {  // adjoint of eval_body_contacts, while the joint wave works
@@ -1700,16 +1706,16 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         int cid = (int)((c.children >> (8 * k)) & 0xffull);
         if (cid != 0xff) adj_add_from(gn, cslot + cid * PD_ADJ);
       }
-      BodyAdj par = fk_joint_adj<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
+      BodyAdj par = fk_joint_adj<JT, 1>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
                                      gn, a.g_q_init + (size_t)ec * m.nq + c.qstart, a.g_qd_init + (size_t)ec * m.nqd + c.qdstart);
       adj_store(cslot + b * PD_ADJ, par);
     }
     WAVE_SYNC();
   }
   if (is_body) {
-    a.g_inv_mass[idx] = g_inv_m;
+    a.g_inv_mass[idx] = NZ(g_inv_m);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { a.g_inertia[idx * 9 + k] = ga_lds[k]; a.g_inv_inertia[idx * 9 + k] = ga_lds[9 + k]; }
+    for (int k = 0; k < 9; ++k) { a.g_inertia[idx * 9 + k] = NZ(ga_lds[k]); a.g_inv_inertia[idx * 9 + k] = NZ(ga_lds[9 + k]); }
   }
 }
 
@@ -1760,7 +1766,7 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
         int cid = (int)((c.children >> (8 * k)) & 0xffull);
         if (cid != 0xff) adj_add_from(g, cslot + cid * PD_ADJ);
       }
-      BodyAdj par = fk_joint_adj<JT>(c, jq, jqd, rec, g, a.g_joint_q + (size_t)ec * m.nq + c.qstart,
+      BodyAdj par = fk_joint_adj<JT, 2>(c, jq, jqd, rec, g, a.g_joint_q + (size_t)ec * m.nq + c.qstart,
                                      a.g_joint_qd + (size_t)ec * m.nqd + c.qdstart);
       adj_store(cslot + b * PD_ADJ, par);
     }

@@ -87,16 +87,54 @@ PD_DEV float asin_c(float x) { return asinf(clampf(x, -1.0f, 1.0f)); }
 // evaluation (the fp32 C oracle does it) is 1e-3 .. 1 off the float64 value of the SAME function in most 100-step Laikago
 // rollouts; the atan2 form is accurate to an ulp and has no singular point at angle 0.  da = r.xyz . axis, alen = |axis|.
 // dq_dda, dq_dw: the partial derivatives, for the adjoint.  A NAMED DEVIATION in evaluation, not in the function.
+// atan2(y, x) for y >= 0, result in [0, pi]: quotient of the smaller by the larger magnitude, one reduction about tan(pi/8) and
+// the degree-9 odd polynomial of Cephes' atanf on |t| <= tan(pi/8) (relative error 2e-7; about 30 instructions, two v_rcp_f32,
+// where libdevice's atan2f -- signed zeros, infinities, denormals -- is about 60).  atan2(0, 0) = 0; NaN in, NaN out.
+PD_DEV float atan2_pos(float y, float x) {
+  const float ax = fabsf(x), hi = fmaxf(ax, y), lo = fminf(ax, y);
+  float t = hi > 0.0f ? lo * (1.0f / hi) : 0.0f;                      // in [0, 1]
+  const bool red = t > 0.41421356f;                                    // tan(pi/8)
+  const float tr = (t - 1.0f) * (1.0f / (t + 1.0f));                   // atan(t) = pi/4 + atan((t - 1) / (t + 1))
+  t = red ? tr : t;
+  const float z = t * t;
+  float r = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
+  r = red ? r + 0.78539816339f : r;
+  r = y > ax ? 1.57079632679f - r : r;                                 // the quotient was |x| / y
+  r = x < 0.0f ? 3.14159265359f - r : r;
+  return (x != x || y != y) ? x + y : r;
+}
 PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq_dw) {
+#ifdef PD_AB_ACOS  // A/B timing only: the literal form (normalise, acos, guarded derivative)
+  {
+    const float y0 = da * alen, n2 = w * w + y0 * y0, il = 1.0f / sqrtf(n2), tw = w * il, sg = da < 0.0f ? -1.0f : 1.0f;
+    const float q0 = acosf(clampf(tw, -1.0f, 1.0f)) * 2.0f * sg;
+    const float sq = sqrtf(1.0f - tw * tw), dq = sq > 0.0f ? -2.0f * sg / sq : 0.0f;
+    dq_dw = dq * (il - w * w * il * il * il);
+    dq_dda = dq * (-w * y0 * alen * il * il * il);
+    return q0;
+  }
+#endif
   const float y = fabsf(da) * alen, sgn = da < 0.0f ? -1.0f : 1.0f;
   const float d = w * w + y * y, id = d > 0.0f ? 1.0f / d : 0.0f;
   dq_dda = 2.0f * alen * w * id;
   dq_dw = -2.0f * sgn * y * id;
-  return 2.0f * sgn * atan2f(y, w);
+  return 2.0f * sgn * atan2_pos(y, w);
 }
 PD_DEV float twist_angle(float da, float w, float alen) {
   const float y = fabsf(da) * alen;
-  return 2.0f * (da < 0.0f ? -1.0f : 1.0f) * atan2f(y, w);
+  return 2.0f * (da < 0.0f ? -1.0f : 1.0f) * atan2_pos(y, w);
+}
+// Gradient post-processing of the reference's autograd boundaries, applied where a gradient is STORED (one compare + one select
+// per value instead of a pass over the tensor afterwards): POST 1 = remove_nan with clip=False (dp_utils.py:43-57 of the
+// reference: NaN -> 0, inf kept), what ForwardWarp.backward does to every gradient it returns (dp_model.py:1294-1384);
+// POST 2 = ForwardKinematics.backward's (dp_model.py:1109-1110, 1122-1123): NaN -> 0, then values above 1 -> 1.
+// NaN -> 0 in ONE instruction: v_med3_f32(x, 0, x) is the median -- x, also for +-inf -- unless an operand is NaN, in which case
+// the hardware returns min3 with v_min_f32's "the operand that is not a NaN" rule, i.e. 0.
+template <int POST>
+PD_DEV float grad_post(float x) {
+  if (POST >= 1) x = __builtin_amdgcn_fmed3f(x, 0.0f, x);
+  if (POST == 2) x = x > 1.0f ? 1.0f : x;
+  return x;
 }
 PD_DEV float clamp_pass(float x, float lo, float hi) { return (x < lo || x > hi) ? 0.0f : 1.0f; }
 PD_DEV v3 clamp3(v3 a, float l) { return V3(clampf(a.x, -l, l), clampf(a.y, -l, l), clampf(a.z, -l, l)); }

@@ -25,11 +25,6 @@ def convert_ppr_warp(tensor):
     return torch.cat([tensor[..., 3:6], tensor[..., 0:3], tensor[..., 6:]], -1)
 
 
-def _scrub_nan(t):
-    """remove_nan with clip=False (/root/reference/diffphys/dp_utils.py:43-57): NaN -> 0, inf kept."""
-    return torch.where(t.isnan(), torch.zeros_like(t), t)
-
-
 class HostFrames:
     """Env-0 poses of every frame as a list of numpy arrays -- what the reference builds eagerly for visualisation
     (``self.sim_trajs`` dp_model.py:1237-1244, ``body_q_numpy`` :1066-1072) and ``query()`` consumes (:855-860).  Here the
@@ -86,10 +81,8 @@ class ForwardKinematics(torch.autograd.Function):
         aqd = adj_body_qd.to(jq.device, torch.float32).permute(1, 0, 2, 3).contiguous()
         gq, gqd = dm.fk_backward(jq.view(num_frames * bs, -1), jqd.view(num_frames * bs, -1), aq, aqd)
 
-        def post(g, last):  # dp_model.py:1109-1110,1122-1123: NaN -> 0, values > 1 -> 1 (upper clamp only)
-            g = g.view(num_frames, bs, last)
-            g = torch.where(g.isnan(), torch.zeros_like(g), g)
-            g = torch.where(g > 1, torch.ones_like(g), g)
+        def post(g, last):  # the reference's post-processing (dp_model.py:1109-1110,1122-1123: NaN -> 0, values > 1 -> 1, upper
+            g = g.view(num_frames, bs, last)  # clamp only) is applied by the kernel where it stores the gradients (pd_fk_backward)
             return g if ctx.is_cuda else g.cpu()
 
         return post(gq, dm.nq), post(gqd, dm.nqd), None
@@ -134,8 +127,9 @@ class ForwardWarp(torch.autograd.Function):
         g = ctx.dm.rollout_backward(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia,
                                     frame2step, ws, adj_body_qs.to(torch.float32).contiguous(),
                                     adj_body_qd.to(torch.float32).contiguous())
-        s = _scrub_nan
-        return (s(g["q_init"]), s(g["qd_init"]), s(g["torques"]).view_as(torques), s(g["res_f"]).view_as(res_f),
-                s(g["refs"]).view_as(refs), s(g["target_ke"]), s(g["target_kd"]),
-                torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), s(g["body_inv_mass"]),
-                s(g["body_inertia"]).view_as(inertia), s(g["body_inv_inertia"]).view_as(inv_inertia), None)
+        # remove_nan (dp_model.py:1294-1384: NaN -> 0 on every returned gradient, inf kept) is applied by the adjoint kernel where it
+        # stores the gradients (pd_rollout_backward): no pass over the tensors here
+        return (g["q_init"], g["qd_init"], g["torques"].view_as(torques), g["res_f"].view_as(res_f),
+                g["refs"].view_as(refs), g["target_ke"], g["target_kd"],
+                torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), g["body_inv_mass"],
+                g["body_inertia"].view_as(inertia), g["body_inv_inertia"].view_as(inv_inertia), None)

@@ -14,7 +14,7 @@ import torch
 _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
-ABI_VERSION = 3  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+ABI_VERSION = 4  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import INPUT_NAMES, golden_inputs, load_golden, relmax
+from helpers import GRAD_LEAD, INPUT_NAMES, golden_inputs, load_golden, relmax
 
 pytestmark = pytest.mark.gpu
 
@@ -68,7 +68,9 @@ def test_golden_one_frame_interval(name, segw, dev):
     assert relmax(bq.cpu().numpy(), g["fk_body_q"]) < 2e-6 and relmax(bqd.cpu().numpy(), g["fk_body_qd"]) < 2e-6
     gq, gqd = dm.fk_backward(torch.from_numpy(g["fk_joint_q"]).to(dev), torch.from_numpy(g["fk_joint_qd"]).to(dev),
                              torch.from_numpy(g["fk_adj_q"]).to(dev), torch.from_numpy(g["fk_adj_qd"]).to(dev))
-    assert relmax(gq.cpu().numpy(), g["fk_grad_q"]) < 5e-6 and relmax(gqd.cpu().numpy(), g["fk_grad_qd"]) < 5e-6
+    # pd_fk_backward returns the gradients with ForwardKinematics.backward's post-processing (values above 1 -> 1, dp_model.py:1110,1123)
+    assert relmax(gq.cpu().numpy(), np.minimum(g["fk_grad_q"], 1.0)) < 5e-6 and relmax(gqd.cpu().numpy(), np.minimum(g["fk_grad_qd"], 1.0)) < 5e-6
+    assert (g["fk_grad_q"] > 1.0).any(), "the fixture must exercise the clamp"
 
 
 @pytest.mark.parametrize("name,bs", [("laikago", 64), ("human", 33), ("quad", 50)])
@@ -194,6 +196,56 @@ def test_zero_angle_singularity_is_finite(dev):
     inp["refs"][:] = 0.0
     out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
     assert all(np.isfinite(v).all() for v in out["grads"].values())
+
+
+@pytest.mark.parametrize("name", ["laikago", "human"])
+def test_gradient_post_processing_inside_the_kernels(name, dev):
+    """remove_nan is applied where the adjoint STORES (diffphys/dp_model.py:1294-1384 with dp_utils.py:43-57,
+    clip=False): the raw gradients of the C ABI -- no torch pass behind them -- carry exact zeros where a NaN arose and keep inf.
+      * NaN injected through res_f (one body of env 1, step 2): that env's forward state is NaN from there on, its gradients are
+        NaN before the scrub; every gradient of the call must be finite-or-inf and env 1's must be exactly 0 where they were NaN,
+        while the other envs' gradients equal those of the clean rollout bit for bit;
+      * an infinite upstream gradient (adj_vel of one component at the last frame): the gradient of the residual force on that
+        component is +inf and must survive; the NaNs that inf * 0 makes elsewhere are zeros.
+    The FK boundary (NaN -> 0, values above 1 -> 1; dp_model.py:1109-1123) is checked on pd_fk_backward's raw output."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template(name)
+    nb = int(tpl["nb"])
+    bs, T = 5, 6
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=3, steps_per_frame=5, penetration=0.002)
+    dm = hip_backend.DeviceModel(tpl)
+    clean = gpu_rollout(dm, inp, dev)
+    assert all(np.isfinite(v).all() for v in clean["grads"].values())
+    bad = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    bad["res_f"].reshape(T, bs, nb, 6)[2, 1, 3, 4] = np.nan
+    out = gpu_rollout(dm, bad, dev)
+    for k, lead in GRAD_LEAD.items():
+        g, c = out["grads"][k], clean["grads"][k]
+        assert not np.isnan(g).any(), k
+        ge = g.reshape(T, bs, -1) if lead else g.reshape(bs, -1)
+        ce = c.reshape(T, bs, -1) if lead else c.reshape(bs, -1)
+        others = [e for e in range(bs) if e != 1]
+        assert np.array_equal(ge[:, others] if lead else ge[others], ce[:, others] if lead else ce[others]), k
+    # steps 0 .. 2 of env 1 see only NaN adjoints (the state after step 2 is NaN): exact zeros
+    assert np.all(out["grads"]["res_f"].reshape(T, bs, -1)[:3, 1] == 0.0) and np.all(out["grads"]["q_init"].reshape(bs, -1)[1] == 0.0)
+    # an infinite seed survives as inf
+    seeded = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    F = len(inp["frame2step"])
+    assert inp["frame2step"][-1] == T - 1 or inp["frame2step"][-1] == T
+    seeded["adj_vel"].reshape(F, bs, nb, 6)[F - 1, 2, 0, 4] = np.inf   # linear velocity y of the root of env 2
+    out = gpu_rollout(dm, seeded, dev)
+    assert all(not np.isnan(v).any() for v in out["grads"].values())
+    assert np.isinf(out["grads"]["res_f"]).any(), "the infinite gradient was scrubbed"
+    # FK boundary: raw pd_fk_backward output is NaN-free and clamped from above at 1
+    jq = torch.from_numpy(inp["q_init"].reshape(bs, -1)).to(dev)
+    jqd = torch.zeros(bs, int(tpl["nqd"]), device=dev)
+    aq = torch.full((bs, nb, 7), 5.0, device=dev)
+    aq[0, 0, 0] = float("nan")
+    gq, gqd = dm.fk_backward(jq, jqd, aq, torch.full((bs, nb, 6), 5.0, device=dev))
+    gq, gqd = gq.cpu().numpy(), gqd.cpu().numpy()
+    assert not np.isnan(gq).any() and not np.isnan(gqd).any() and gq.max() <= 1.0 and gqd.max() <= 1.0 and gq.max() == 1.0
+    assert gq.min() < -1.0, "only an UPPER clamp: large negative gradients pass"
 
 
 def test_autograd_boundaries(dev, oracle_libs):

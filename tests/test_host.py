@@ -130,8 +130,8 @@ def test_c_abi_exports_every_declared_symbol():
     lib = hip_backend.lib()
     for n in names:
         assert hasattr(lib, n), "missing symbol " + n
-    assert lib.pd_abi_version() == 3 == hip_backend.ABI_VERSION
-    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    assert lib.pd_abi_version() == 4 == hip_backend.ABI_VERSION
+    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == 4
     lib.pd_rollout_workspace_floats.restype = ctypes.c_size_t
     assert lib.pd_rollout_workspace_floats(None, 4, 10) == 0
 
