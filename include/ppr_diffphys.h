@@ -67,6 +67,9 @@ typedef struct pd_model_desc {
 typedef struct pd_model pd_model; /* opaque; owns the device copy of the template */
 
 int pd_abi_version(void);
+/* "<git HEAD at build time>+<first 16 hex digits of the sha256 over the library's sources>" (csrc/Makefile: SRCS, in that order).
+ * A loader that also has the sources (tests, __graft_entry__.smoke) compares the hash: a stale binary cannot pass for the tree's. */
+const char *pd_build_id(void);
 const char *pd_last_error(void);
 
 int pd_model_create(const pd_model_desc *desc, pd_model **out);

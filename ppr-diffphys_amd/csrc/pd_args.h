@@ -20,7 +20,8 @@ enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD 
 //   forward : revolute-only robots always; other joint mixes while a CU holds at most one full workgroup (the latency
 //             regime: human at 1024 envs -32 %), else the unsplit kernel packs twice as many body waves per SIMD
 //   adjoint : revolute-only robots the 2-role kernel (body + contact wave); other joint mixes the 2-role k_rollout_bwd3
-//             (integrate + contacts wave, joint wave).  The other variants exist for A/B timing (pd_debug_set_variant).
+//             (integrate + contacts wave, joint wave).  The rejected variants (3-role, early hand-over, unsplit compound adjoint:
+//             DESIGN.md section 4) are compiled and reachable in -DPD_EXPERIMENT builds only.
 constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
 // the specialised instantiations (one joint type) are only launched for PLAIN models: non-FREE joints all hang on a body, child
 // joint frames are not rotated (pd_host.hip)
@@ -42,8 +43,13 @@ inline int pd_groups_per_wg(int n_groups, int cu_count) {
 inline int pd_kernel_variant(int kind, int jt, int n_groups, int cu_count, int variant) {
   if (kind == PD_K_ROLLOUT_FWD) return (pd_split(jt) || n_groups <= PD_BWAVES * cu_count) ? PD_KV_FWD_SPLIT : PD_KV_FWD_UNSPLIT;
   if (kind == PD_K_ROLLOUT_BWD) {
-    if (pd_split(jt)) return variant == 3 ? PD_KV_BWD_3ROLE : (variant == 1 ? PD_KV_BWD_2ROLE_EARLY : PD_KV_BWD_2ROLE);
-    return variant == 9 ? PD_KV_BWD_UNSPLIT : PD_KV_BWD3_2ROLE;
+#ifdef PD_EXPERIMENT  // rejected variants (pd_debug_set_variant), timing builds only
+    if (pd_split(jt) && variant == 3) return PD_KV_BWD_3ROLE;
+    if (pd_split(jt) && variant == 1) return PD_KV_BWD_2ROLE_EARLY;
+    if (!pd_split(jt) && variant == 9) return PD_KV_BWD_UNSPLIT;
+#endif
+    (void)variant;
+    return pd_split(jt) ? PD_KV_BWD_2ROLE : PD_KV_BWD3_2ROLE;
   }
   return PD_KV_FK;
 }

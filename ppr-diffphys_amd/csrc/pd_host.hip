@@ -280,8 +280,8 @@ static int build_device(pd_model *m, int segw) {
   return 0;
 }
 
-static int g_variant = 0;  // A/B experiments only (pd_debug_set_variant)
-static int g_groups = 0;   // A/B experiments only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
+static int g_variant = 0;  // -DPD_EXPERIMENT builds only (pd_debug_set_variant)
+static int g_groups = 0;   // -DPD_EXPERIMENT / -DPD_STAMPS builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
 
 // Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
 static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
@@ -509,13 +509,22 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *
   return e == hipSuccess ? 0 : hip_fail(e, "fk_backward launch");
 }
 
-// Not part of the public header: buffer for -DPD_STAMPS diagnostic builds ([blocks*waves][16] u64).
+#if defined(PD_STAMPS) || defined(PD_EXPERIMENT)
+// Diagnostic builds only (never in the shipped library, not in the public header).
+// buffer for the in-kernel phase stamps ([blocks*waves][16] u64)
 void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
-// Not part of the public header: selects the adjoint kernel of revolute-only robots for A/B timing (scripts/gpu_time.py):
-// revolute-only: 0 = shipped default (2-role, hand-over A after integrate_adj), 1 = 2-role with the early hand-over,
-// 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 0 = 2-role k_rollout_bwd3<2>, 9 = the unsplit round-1 kernel.
+// adjoint kernel of revolute-only robots for A/B timing (scripts/gpu_time.py): 0 = shipped (2-role, hand-over A after
+// integrate_adj), 1 = 2-role with the early hand-over, 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 9 = the unsplit kernel
 void pd_debug_set_variant(int v) { g_variant = v; }
 void pd_debug_set_groups(int g) { g_groups = g < 0 ? 0 : (g > PD_BWAVES ? PD_BWAVES : g); }
+#endif
+
+// Identity of this build: "<git HEAD or 'unknown'>+<hash of the kernel / host sources>", baked in by the Makefile.  smoke() and the
+// tests compare the source hash with the sources that sit beside the library, so a stale .so cannot pass for the tree's.
+#ifndef PD_BUILD_ID
+#define PD_BUILD_ID "unknown+unknown"
+#endif
+const char *pd_build_id(void) { return PD_BUILD_ID; }
 
 int pd_model_set_timing(pd_model *m, int on) {
   if (!m) return fail("null model");

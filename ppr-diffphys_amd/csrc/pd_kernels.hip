@@ -1801,17 +1801,25 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
       break;
     case PD_K_ROLLOUT_BWD:
       if constexpr (pd_split(JT)) {
-        if (cfg.kernel == PD_KV_BWD_3ROLE)
+#ifdef PD_EXPERIMENT  // rejected variants, kept for A/B timing builds only
+        if (cfg.kernel == PD_KV_BWD_3ROLE) {
           hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 3>), g, t, lds, st, m, *(const RolloutArgs *)args);
-        else if (cfg.kernel == PD_KV_BWD_2ROLE_EARLY)
+          break;
+        }
+        if (cfg.kernel == PD_KV_BWD_2ROLE_EARLY) {
           hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-        else
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          break;
+        }
+#endif
+        hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else {
-        if (cfg.kernel == PD_KV_BWD_UNSPLIT)  // A/B: the unsplit round-1 kernel
+#ifdef PD_EXPERIMENT
+        if (cfg.kernel == PD_KV_BWD_UNSPLIT) {  // the unsplit round-1 kernel
           hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
-        else
-          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          break;
+        }
+#endif
+        hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
       }
       break;
     case PD_K_FK_FWD:
@@ -1832,12 +1840,16 @@ static hipError_t set_lds_jt(int bytes) {
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {
-    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+#ifdef PD_EXPERIMENT
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+#endif
   } else {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+#ifdef PD_EXPERIMENT
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+#endif
   }
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   return hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -32,6 +32,10 @@ class _Desc(ctypes.Structure):
     ]
 
 
+def lib_path():
+    return _LIB_PATH
+
+
 def lib():
     """Loads the HIP library; raises if it has not been built (``__graft_entry__.build()``)."""
     global _lib
@@ -91,6 +95,38 @@ def _dev(t, name, shape_numel=None):
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def build_id():
+    """pd_build_id() of the loaded library: "<git HEAD at build time>+<source hash>"."""
+    L = lib()
+    L.pd_build_id.restype = ctypes.c_char_p
+    return L.pd_build_id().decode()
+
+
+def source_hash():
+    """Hash of the library's sources as they sit in this tree (csrc/Makefile SRCS order; scripts/source_hash.py), or None when the
+    sources are not there (an installed copy without csrc/)."""
+    import hashlib
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "../../include/ppr_diffphys.h"]
+    h = hashlib.sha256()
+    try:
+        for f in srcs:
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def check_build_matches_sources():
+    """Raises when the loaded library was not built from the sources beside it (a stale .so that travelled with the tree)."""
+    want, have = source_hash(), build_id()
+    if want is not None and not have.endswith("+" + want):
+        raise RuntimeError("libpprdiffphys_hip.so is stale: built from sources %s, the tree's hash is %s (run make -C ppr-diffphys_amd/csrc)" % (have, want))
+    return have
 
 
 class DeviceModel:

@@ -47,18 +47,15 @@ def report(lab, who, r, names):
         print("      %-52s %6.1f%%   %8.0f cycles/step" % (n, 100 * r[:, i].mean() / tot, r[:, i].mean() / T))
 
 
-fn = [(0, "top: candidate fetch + request / wave sync"), (1, "vmcnt wait + unpack + control prefetch"),
-      (2, "contact candidate + joint pass, LDS writes, log"), (6, "child gather"),
-      (3, "trajectory stores + (wait B) + facc + frame stores"), (4, "integrate"), (5, "stage record")]
-cn = [(7, "asleep on the request word"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull + publish"), (11, "exact sweep / list evaluation"), (12, "tail")]
-r = rows(f_all, 0)
-report("FWD", "body wave", r, fn)
-print("FWD body wave: fused steps %.1f%%, list-evaluation steps %.1f%%, candidates (env 0 of the wave) %.2f per step" % (
-    100 * r[:, 13].mean() / T, 100 * r[:, 14].mean() / T, r[:, 15].mean() / T))
+fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints fwd + pcon write"), (6, "child gather"),
+      (3, "wait at barrier B + facc + traj_f/frame stores"), (4, "integrate"), (5, "stage record")]
+cn = [(7, "wait at barrier A/A1 (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
+report("FWD", "body wave", rows(f_all, 0), fn)
 if wf >= 8:
     r = rows(f_all, 1)
-    report("FWD", "helper wave", r, cn)
-    print("FWD helper wave: exact sweeps in %.2f%% of wave-steps" % (100 * r[:, 13].mean() / T))
+    report("FWD", "contact wave", r, cn)
+    print("FWD contact wave: exact cull redone in %.2f%% of wave-steps; speculated candidates (env 0 of the wave) %.2f per step" % (
+        100 * r[:, 13].mean() / T, r[:, 14].mean() / T))
 if wb == 12:  # 3-role adjoint
     report("BWD", "integrate wave", rows(b_all, 0), [(0, "top: seeds + unpack + stage"), (1, "integrate adj (phase 1, signal A, phase 2) + g_res_f"),
                                                     (2, "wait J"), (3, "own + child gather"), (4, "wait C + cacc")])

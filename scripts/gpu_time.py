@@ -11,10 +11,11 @@ cfgs = [("laikago", 4096, 16), ("laikago", 4096, 32), ("laikago", 4096, 64), ("l
         ("human", 1024, 32), ("quad", 8192, 32)]
 # PD_VARIANT=n selects an experimental adjoint kernel (pd_debug_set_variant; 0 = shipped default)
 variant = int(os.environ.get("PD_VARIANT", "0"))
-hip_backend.lib().pd_debug_set_variant(variant)
-hip_backend.lib().pd_debug_set_groups(int(os.environ.get("PD_GROUPS", "0")))  # env groups per workgroup, 0 = automatic
-if "PD_FUSE" in os.environ and hasattr(hip_backend.lib(), "pd_debug_set_fuse"):
-    hip_backend.lib().pd_debug_set_fuse(int(os.environ["PD_FUSE"]))  # forward contact evaluation on the body wave: 1 / 0, default automatic
+if hasattr(hip_backend.lib(), "pd_debug_set_variant"):  # `make experiment` builds only (PPR_DIFFPHYS_LIB=..._experiment.so)
+    hip_backend.lib().pd_debug_set_variant(variant)
+    hip_backend.lib().pd_debug_set_groups(int(os.environ.get("PD_GROUPS", "0")))  # env groups per workgroup, 0 = automatic
+elif variant or os.environ.get("PD_GROUPS"):
+    raise SystemExit("PD_VARIANT / PD_GROUPS need the experiment build (make -C ppr-diffphys_amd/csrc experiment)")
 if len(sys.argv) > 1:
     cfgs = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:]]
 dev = torch.device("cuda:0")

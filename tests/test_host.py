@@ -126,10 +126,16 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(pd_[A-Za-z0-9_]+)\s*\(", hdr)))
-    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and len(names) == 20
+    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and "pd_build_id" in names and len(names) == 21
     lib = hip_backend.lib()
     for n in names:
         assert hasattr(lib, n), "missing symbol " + n
+    # ... and nothing else: the A/B variants and debug hooks of earlier rounds live in -DPD_EXPERIMENT / -DPD_STAMPS builds only
+    import subprocess
+    exported = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", hip_backend.lib_path()]).decode().splitlines() if " T pd_" in l}
+    assert exported == set(names), sorted(exported ^ set(names))
+    # the binary was built from the sources beside it (pd_build_id = "<git HEAD>+<source hash>")
+    assert hip_backend.check_build_matches_sources().endswith("+" + hip_backend.source_hash())
     assert lib.pd_abi_version() == 4 == hip_backend.ABI_VERSION
     assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == 4
     lib.pd_rollout_workspace_floats.restype = ctypes.c_size_t
