@@ -219,20 +219,22 @@ class phys_model(nn.Module):
         tests/test_host_plumbing.py compares them), with ONE host transfer per iteration -- the deferred NaN check of the
         loss, the global norm and "is any parameter an outlier" travel together -- instead of one per parameter."""
         named = [(name, p) for d in self.params_ref_list for name, p in d.items() if p.requires_grad and p.grad is not None]
-        pending, self._pending_loss = getattr(self, "_pending_loss", None), None
+        # a 0-dim bool tensor: some forward() since the last check produced a NaN total_loss (accumulated over the accu_steps
+        # forward() calls of one update; never set by eval / no_grad forwards) -- read and cleared here
+        pending, self._pending_nan = getattr(self, "_pending_nan", None), None
         if not named:
-            if pending is not None and bool(pending.isnan()):
+            if pending is not None and bool(pending):
                 raise FloatingPointError("total_loss is NaN")
             return {}
         params_list = [p for _, p in named]
         grad_norm = torch.nn.utils.clip_grad_norm_(params_list, thresh)
         plan = self.grad_history.plan([n for n, _ in named], [p.grad for p in params_list])  # norms AFTER the global clip, like the reference
         zero = grad_norm.new_zeros(())
-        host = torch.stack([pending.isnan().to(grad_norm.dtype) if pending is not None else zero, grad_norm,
+        host = torch.stack([pending.to(grad_norm.dtype) if pending is not None else zero, grad_norm,
                             plan["any_outlier"].to(grad_norm.dtype) if plan["any_outlier"] is not None else zero]).tolist()
         if host[0] != 0:
             raise FloatingPointError("total_loss is NaN")  # deferred from forward(), see there
-        if host[1] > thresh:
+        if not (host[1] <= thresh):  # too large OR not finite (NaN > thresh is False: a NaN norm must not reach the optimiser)
             self.optimizer.zero_grad()
             if get_local_rank() == 0:
                 print("large grad: %.2f, clear gradients" % host[1])
@@ -440,7 +442,13 @@ class phys_model(nn.Module):
         # the reference drops into pdb on a NaN loss right here (dp_model.py:832): one host synchronisation per forward().
         # The check is kept but deferred to update(), which has to talk to the host anyway (gradient-norm guard), so that
         # nothing between forward() and backward() waits for the device
-        self._pending_loss = total_loss.detach()
+        # nothing between forward() and backward() waits for the device.  The flag ACCUMULATES: main.py calls forward() accu_steps
+        # times per update() and sums the losses, a NaN in any of those windows must stop the update, not only one in the last.
+        # Evaluation forwards (no_grad, or the module in eval mode) leave no flag behind for the next training update.
+        if torch.is_grad_enabled() and self.training:
+            nan_now = total_loss.detach().isnan()
+            prev = getattr(self, "_pending_nan", None)
+            self._pending_nan = nan_now if prev is None else (prev | nan_now)
         out["total_loss"] = total_loss
         return out
 
@@ -470,7 +478,44 @@ class phys_model(nn.Module):
 
     @torch.no_grad()
     def query(self, img_size=None):
-        """simulated / target / control-reference body trajectories of env 0 plus forces (no mesh posing)"""
-        return {"sim_traj": np.stack(self.sim_trajs, 0), "target_traj": np.stack(self.target_trajs, 0),
-                "control_ref": np.stack(self.pid_ref, 0), "grf": torch.stack(self.grfs, 0).cpu().numpy(),
-                "jaf": torch.stack(self.jafs, 0).cpu().numpy()}
+        """Env 0 of the last forward(), frame by frame, in the reference's keys (dp_model.py:843-902): the simulated, target and
+        control-reference robots POSED -- the reference hands trimesh objects to its renderer (articulate_robot_rbrt:
+        collision-mesh vertices rotated and translated by each body's pose); here each is the array of those posed vertices
+        [F, n_vertices, 3] (the collision vertices of all bodies in template order = the contact candidates, `vertex_body`
+        says which body each belongs to; triangle indices, colours and force arrows are the renderer's and out of scope) --
+        plus the centre of mass of the target (`com_k`) and simulated (`com`) robot per frame (dp_utils.py:86-90 with the env's
+        template masses, as the reference), `max_w`, the raw body poses (`*_poses` [F, nb, 7]) and the frame forces."""
+        sim = np.stack(list(self.sim_trajs), 0).astype(np.float64)
+        tgt = np.stack(list(self.target_trajs), 0).astype(np.float64)
+        ref = np.stack(list(self.pid_ref), 0).astype(np.float64)
+        pts = np.asarray(self.template["contact_point"], np.float64)
+        cb = np.asarray(self.template["contact_body"], np.int64)
+        part_com = np.asarray(self.template["body_com"], np.float64)
+        part_mass = np.asarray(self.template["body_mass"], np.float64)
+
+        def rotm(q):  # [..., 4] (x, y, z, w), unit -> [..., 3, 3]
+            x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+            return np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1).reshape(q.shape[:-1] + (3, 3))
+
+        def pose_vertices(traj):  # [F, nb, 7] -> [F, nc, 3]
+            qn = traj[..., 3:] / np.linalg.norm(traj[..., 3:], axis=-1, keepdims=True)
+            R, t = rotm(qn), traj[..., :3]
+            return np.einsum("fcij,cj->fci", R[:, cb], pts) + t[:, cb]
+
+        def com_of(traj):  # dp_utils.py:86-90
+            qn = traj[..., 3:] / np.linalg.norm(traj[..., 3:], axis=-1, keepdims=True)
+            body_com = np.einsum("fbij,bj->fbi", rotm(qn), part_com) + traj[..., :3]
+            return (body_com * part_mass[None, :, None]).sum(1) / part_mass.sum()
+
+        data = {"sim_traj": pose_vertices(sim), "target_traj": pose_vertices(tgt), "control_ref": pose_vertices(ref),
+                "vertex_body": cb, "sim_poses": sim, "target_poses": tgt, "control_ref_poses": ref,
+                "com": com_of(sim), "com_k": list(com_of(tgt)), "body_mass": self.body_mass.detach().cpu().numpy(),
+                "grf": torch.stack(self.grfs, 0).cpu().numpy(), "jaf": torch.stack(self.jafs, 0).cpu().numpy()}
+        # max_w (dp_model.py:897-899: 3 x the robot's horizontal extent in its rest pose); the rest pose here is the first target frame
+        rest = data["target_traj"][0] - data["target_traj"][0].mean(0, keepdims=True)
+        data["max_w"] = float(3 * np.abs(rest[:, [0, 2]]).max())
+        if img_size is not None:
+            data["img_size"] = img_size
+        return data

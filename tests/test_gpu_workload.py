@@ -1,0 +1,180 @@
+"""SURVEY section 8 row f3 on the reference's OWN workload: the training window of /root/reference/main.py:86 --
+reinit_envs(10, frames_per_wdw=24): 10 envs x 760 sim steps, 24 frames -- and its evaluation pass (:73-79, 1 env over the whole
+clip: 1 255 steps, 39 frames), for the five sequences of run.sh:10-14, through phys_model on the HIP rollout."""
+import importlib.util
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEQS = ["mi-spin", "mi-trot", "mi-pace", "mi-sidesteps", "mi-turn"]  # run.sh order
+
+
+def _main():
+    spec = importlib.util.spec_from_file_location("pd_main", os.path.join(ROOT, "ppr-diffphys_amd", "main.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _model(seq, logname):
+    from diffphys_amd.dataloader import DataLoader
+    from diffphys_amd.phys_model import phys_model
+
+    opts = _main().get_opts(["--seqname", seq, "--urdf_template", "laikago", "--logroot", "/tmp/pprdp_workload/", "--logname", logname])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = phys_model(opts, DataLoader(opts)).cuda()
+    model.train()
+    return model, opts
+
+
+class _Capture:
+    """records the arguments of the model's rollout launches (the tensors ForwardWarp hands to pd_rollout_forward)"""
+
+    def __init__(self):
+        from diffphys_amd import hip_backend
+
+        self.cls, self.orig, self.calls = hip_backend.DeviceModel, hip_backend.DeviceModel.rollout_forward, []
+
+    def __enter__(self):
+        cap = self
+
+        def wrapped(dm, bs, nsteps, dt, *tensors, **kw):
+            cap.calls.append((bs, nsteps, dt, [t.detach().cpu().numpy().copy() for t in tensors], list(kw["frame2step"])))
+            return cap.orig(dm, bs, nsteps, dt, *tensors, **kw)
+
+        self.cls.rollout_forward = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.cls.rollout_forward = self.orig
+
+
+FWD_NAMES = ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia")
+
+
+def _physical(pos, vel):
+    assert torch.isfinite(pos).all() and torch.isfinite(vel).all()
+    assert float(vel.abs().max()) <= 10.0 + 1e-5                                   # integrate_bodies' clamps (integrator_euler.py:78-88)
+    assert float((pos[..., 3:].norm(dim=-1) - 1.0).abs().max()) < 1e-5            # normalised quaternions (:72)
+
+
+@pytest.mark.parametrize("seq", SEQS)
+def test_reference_training_window_and_eval_pass(seq, dev, oracle_libs):
+    from diffphys_amd import robots
+    from oracle.ref_c import RefC
+
+    model, opts = _model(seq, "w")
+    assert opts["num_envs"] == 10 and opts["frames_per_wdw"] == 24
+    # ---- the training window: 10 envs x 760 steps, 24 frames
+    model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"])
+    NF, SPF = model.total_frames, model.steps_per_fr_interval  # mi-pace: 39 frames of 33 steps (760-step window, 1 255 eval steps);
+    WT = SPF * 23 + 1                                          # mi-sidesteps / mi-turn have longer frames: 83 steps, 1 910-step window
+    assert len(model.steps_idx) == WT and len(model.frame2step) == 24 and ((NF, SPF, WT) == (39, 33, 760) or seq != "mi-pace")
+    fs = torch.arange(10, device=model.device) % (NF - 24)
+    noise0 = torch.zeros(10 * 19, device=model.device)
+    with _Capture() as cap:
+        out = model.forward(frame_start=fs, q_init_noise=noise0)
+    bs, T, dt, tensors, f2s = cap.calls[-1]
+    assert (bs, T, f2s[:3], len(f2s)) == (10, WT, [0, SPF, 2 * SPF], 24)
+    # poses / twists of the first two frames against the float64 C oracle on the SAME launch arguments (34 steps reach frame 1)
+    inp = dict(zip(FWD_NAMES, tensors))
+    inp34 = {k: (v.reshape(T, -1)[:SPF + 1].copy() if k in ("torques", "res_f", "refs") else v) for k, v in inp.items()}
+    tpl = robots.load_template("laikago")
+    rc = RefC(tpl, np.float64)
+    st = rc.rollout_forward(inp34, SPF + 1, [0, SPF], dt)
+    got_pos = np.stack([np.asarray(model.sim_trajs[f]) for f in (0, 1)], 0)            # env 0, frames 0 and 1
+    assert relmax(got_pos, st["wp_pos"].reshape(2, 10, 13, 7)[:, 0]) < 5e-5
+    grf = torch.stack(model.grfs[:2], 0).cpu().numpy()
+    assert relmax(grf, st["grf"]) < 5e-3
+    model.backward(out["total_loss"])
+    gd = model.update()
+    assert len(gd) > 0 and all(torch.isfinite(v) for v in gd.values())
+    # ---- 20 optimisation iterations on the reference's window: the loss goes down, everything stays physical
+    losses, t_iter = [], []
+    for it in range(20):
+        model.set_progress(it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.forward(frame_start=fs)
+        model.backward(out["total_loss"])
+        model.update()
+        torch.cuda.synchronize()
+        t_iter.append(time.perf_counter() - t0)
+        losses.append(float(out["total_loss"].detach()))
+        assert np.isfinite(losses[-1])
+    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
+    print("%s: 10 x %d window," % (seq, WT) + " iteration %.1f ms (median of 20), loss %.4f -> %.4f" % (1e3 * np.median(t_iter), losses[0], losses[-1]))
+    q = model.query()
+    assert q["sim_traj"].shape == (24, 3838, 3) and q["target_traj"].shape == (24, 3838, 3) and q["control_ref"].shape == (24, 3838, 3)
+    assert q["grf"].shape == (24, 130, 6) and len(q["com_k"]) == 24 and np.isfinite(q["sim_traj"]).all() and q["max_w"] > 0
+    assert q["sim_traj"][..., 1].min() > -0.05, "the simulated robot stays on the ground plane"
+    # ---- the evaluation pass: 1 env over the whole clip, 1 255 steps, 39 frames (main.py:73-79 of the reference)
+    model.reinit_envs(1, frames_per_wdw=model.total_frames, is_eval=True)
+    assert len(model.steps_idx) == SPF * (NF - 1) + 1 and len(model.frame2step) == NF
+    with torch.no_grad(), _Capture() as cap:
+        ev = model.forward(frame_start=torch.zeros(1, dtype=torch.long, device=model.device))
+    assert cap.calls[-1][:2] == (1, SPF * (NF - 1) + 1) and len(cap.calls[-1][4]) == NF
+    assert np.isfinite(float(ev["loss_traj"])) and getattr(model, "_pending_nan", None) is None  # an eval forward leaves no NaN flag behind
+    ev_traj = np.stack(list(model.sim_trajs), 0)
+    # (frame 0 is eval_fk of q_init, whose root quaternion the reference leaves un-normalised -- interpolated mocap + init noise,
+    # SURVEY N4 -- every later frame went through integrate_bodies' normalisation)
+    assert ev_traj.shape == (NF, 13, 7) and np.isfinite(ev_traj).all() and np.abs(np.linalg.norm(ev_traj[1:, :, 3:], axis=-1) - 1).max() < 1e-5
+    # ---- checkpoint round trip: a fresh model that loads the checkpoint reproduces the evaluation rollout bit for bit
+    model.save_checkpoint(0)
+    path = "%s/ckpt_phys_latest.pth" % model.save_dir
+    assert os.path.exists(path)
+    fresh, _ = _model(seq, "w")
+    fresh.load_checkpoint(path)
+    fresh.reinit_envs(1, frames_per_wdw=fresh.total_frames, is_eval=True)
+    with torch.no_grad():
+        fresh.forward(frame_start=torch.zeros(1, dtype=torch.long, device=fresh.device), q_init_noise=torch.zeros(19, device=fresh.device))
+        model.forward(frame_start=torch.zeros(1, dtype=torch.long, device=model.device), q_init_noise=torch.zeros(19, device=model.device))
+    assert np.array_equal(np.stack(list(fresh.sim_trajs), 0), np.stack(list(model.sim_trajs), 0))
+
+
+def test_nan_guards_of_the_update(dev):
+    """a NaN total_loss in ANY of the accu_steps forward() calls of one update stops it (the flag accumulates), a
+    non-finite gradient norm takes the rollback path instead of reaching the optimiser, evaluation forwards leave no flag."""
+    model, opts = _model("mi-pace", "nan")
+    model.reinit_envs(4, frames_per_wdw=3)
+    fs = torch.arange(4, device=model.device)
+    model.save_checkpoint(0)
+    model.save_checkpoint(1)  # two rounds cached: the rollback target exists
+    out1 = model.forward(frame_start=fs)
+    model._pending_nan = torch.ones((), dtype=torch.bool, device=model.device)  # as if this first window's loss had been NaN
+    out2 = model.forward(frame_start=fs)                                       # a clean second window must not clear it
+    model.backward(out1["total_loss"] + out2["total_loss"])
+    with pytest.raises(FloatingPointError):
+        model.update()
+    model.optimizer.zero_grad()
+    assert getattr(model, "_pending_nan", None) is None
+    # non-finite gradient norm: parameters untouched by the step, gradients cleared, state rolled back
+    out = model.forward(frame_start=fs)
+    model.backward(out["total_loss"])
+    p = next(p for p in model.parameters() if p.grad is not None)
+    p.grad.view(-1)[0] = float("nan")
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    assert model.update() == {}
+    after = model.state_dict()
+    assert all(torch.equal(before[k], after[k]) or torch.equal(after[k], model.model_cache[0][k].to(after[k].device)) for k in before)
+    assert all(torch.isfinite(v).all() for v in after.values() if v.is_floating_point())
+    with torch.no_grad():
+        model.forward(frame_start=fs)
+    assert getattr(model, "_pending_nan", None) is None
