@@ -101,9 +101,11 @@ static size_t put(std::vector<unsigned char> &buf, const std::vector<T> &v) {
   return off;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a model: keep the running maximum per
-// (segment width, joint mix) so that a second model never lowers what an earlier, larger one needs.
-static int g_lds_attr[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel ON A DEVICE, not of a model: keep the running
+// maximum per (device, segment width, joint mix) so that a second model never lowers what an earlier, larger one needs, and
+// a process that builds models on several GPUs raises the attribute on each of them.
+#define PD_MAX_DEVICES 64
+static int g_lds_attr[PD_MAX_DEVICES][3][3];
 static int jt_slot(int jt) { return jt == PD_JT_REVOLUTE ? 0 : (jt == PD_JT_COMPOUND ? 1 : 2); }
 
 // Builds the device copy for segment width `segw` into temporaries and commits blob / dev / lds_* / segw / jt only when
@@ -249,7 +251,10 @@ static int build_device(pd_model *m, int segw) {
   if (lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   if (lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   const int lds_max = (int)std::max(std::max(lds_rollout, lds_rollout_bwd), lds_fk);
-  int &attr = g_lds_attr[segw == 16 ? 0 : (segw == 32 ? 1 : 2)][jt_slot(jt)];
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0) dev_id = 0;
+  int uncached = 0;  // (a device index beyond the table is simply never cached: the attribute is set on every build)
+  int &attr = dev_id < PD_MAX_DEVICES ? g_lds_attr[dev_id][segw == 16 ? 0 : (segw == 32 ? 1 : 2)][jt_slot(jt)] : uncached;
   if (lds_max > attr) {
     hipError_t ea = segw == 16 ? pd_set_lds_seg16(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32(jt, lds_max) : pd_set_lds_seg64(jt, lds_max));
     if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(LDS)");
@@ -282,6 +287,7 @@ static int build_device(pd_model *m, int segw) {
 
 static int g_variant = 0;  // -DPD_EXPERIMENT builds only (pd_debug_set_variant)
 static int g_groups = 0;   // -DPD_EXPERIMENT / -DPD_STAMPS builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
+static int g_own_joint = -1;  // -DPD_EXPERIMENT builds only (pd_debug_set_own_joint): -1 = automatic
 
 // Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
 static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
@@ -329,7 +335,7 @@ static void timing_end(pd_model *m, int kind, hipStream_t st) {
 
 // Validates frame2step (host) and returns the cached device table frame_of_step[nsteps + 1] (frame index of each state, or
 // -1).  A new (nsteps, frame2step) costs one allocation and one synchronous upload; a repeated one costs a compare.
-static int frame_table(pd_model *m, int nsteps, int nframes, const int *f2s, const int **out) {
+static int frame_table(pd_model *m, int nsteps, int nframes, const int *f2s, const int **out, hipStream_t st) {
   if (nframes < 0) return fail("negative frame count");
   if (nframes > 0 && !f2s) return fail("null frame2step");
   std::vector<int> fos((size_t)nsteps + 1, -1);
@@ -343,10 +349,14 @@ static int frame_table(pd_model *m, int nsteps, int nframes, const int *f2s, con
   }
   for (const auto &e : m->fos)
     if (e.nsteps == nsteps && (int)e.f2s.size() == nframes && std::equal(e.f2s.begin(), e.f2s.end(), f2s)) { *out = e.dev; return 0; }
-  if (m->fos.size() >= 64) {  // bounded cache: drain the device before the old tables go
-    (void)hipDeviceSynchronize();
-    for (auto &e : m->fos) (void)hipFree(e.dev);
-    m->fos.clear();
+  // The tables are a few hundred bytes each and their device pointers may be baked into HIP graphs the caller captured
+  // (the header: "warm up, then capture"), so NONE is freed before pd_model_destroy -- no eviction, no synchronisation that
+  // would also invalidate a capture in progress.  A caller that keeps inventing frame lists is told so instead.
+  if (m->fos.size() >= 4096) return fail("more than 4096 distinct (nsteps, frame2step) tables on one model; destroy and recreate the model");
+  {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return fail("a new (nsteps, frame2step) needs a synchronous upload, which a stream capture in progress forbids: warm up first");
   }
   int *dev = nullptr;
   hipError_t e = hipMalloc((void **)&dev, fos.size() * sizeof(int));
@@ -434,7 +444,7 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
   const int *fos = nullptr;
-  if (frame_table(m, nsteps, nframes, frame2step, &fos)) return 1;
+  if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;
   if (bs == 0) return 0;
   if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia) return fail("null device pointer");
   if (nsteps > 0 && (!torques || !res_f || !refs || !ws)) return fail("null device pointer");
@@ -463,7 +473,7 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
   const int *fos = nullptr;
-  if (frame_table(m, nsteps, nframes, frame2step, &fos)) return 1;
+  if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;
   if (bs == 0) return 0;
   if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia || !g_q_init || !g_qd_init || !g_ke ||
       !g_kd || !g_inv_mass || !g_inertia || !g_inv_inertia)
@@ -479,6 +489,12 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
   a.variant = g_variant;
+  {  // a workgroup's waves are dealt to the 4 SIMDs cyclically: with PD_BWAVES env groups per workgroup a body wave and its
+     // contact wave share a SIMD; the contact wave is then the later one at both hand-overs and hands rev_forward back (k_rollout_bwd)
+    const PdLaunchCfg c = launch_cfg(m, PD_K_ROLLOUT_BWD, bs);
+    a.own_joint = g_own_joint >= 0 ? g_own_joint : 0;  // measured: no gain; kept as an experiment switch
+    (void)c;
+  }
   a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
@@ -516,6 +532,7 @@ void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
 // adjoint kernel of revolute-only robots for A/B timing (scripts/gpu_time.py): 0 = shipped (2-role, hand-over A after
 // integrate_adj), 1 = 2-role with the early hand-over, 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 9 = the unsplit kernel
 void pd_debug_set_variant(int v) { g_variant = v; }
+void pd_debug_set_own_joint(int v) { g_own_joint = v; }
 void pd_debug_set_groups(int g) { g_groups = g < 0 ? 0 : (g > PD_BWAVES ? PD_BWAVES : g); }
 #endif
 

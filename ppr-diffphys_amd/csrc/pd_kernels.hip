@@ -873,7 +873,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     //           summed per body in hit order by a lane-per-component pass
     // A log that did not fit (count -1) or holds more hits than the segment has lanes takes the generic sweep.
     STAMP_DECL;
-    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE;
+    // a.own_joint (the host sets it when this wave shares its SIMD with the body wave, i.e. PD_BWAVES env groups per workgroup):
+    // the body wave recomputes the state-only half of its joint's adjoint itself, from the records it has staged anyway -- at
+    // 4096 envs THIS wave is the later one at both hand-overs (stamps: 6 900 of 7 200 cycles busy per step while the body wave
+    // waits 2 600), so rev_forward, its five pose loads and two control loads per step move over there
+    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE && !a.own_joint;
     const size_t qd_off = (size_t)ec * m.nqd + c.qdstart;
     const float ke1 = rev ? a.target_ke[qd_off] : 0.f, kd1 = rev ? a.target_kd[qd_off] : 0.f;
     const int lq = l < PD_HITLOG - 1 ? l : PD_HITLOG - 2;
@@ -933,7 +937,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       const int nh = fast && env_ok ? cnt_c : 0;
       STAMP(7);
       // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
-      pair_signal(sig + 1, a.nsteps - step);
+      if (!a.own_joint) pair_signal(sig + 1, a.nsteps - step);
       pair_wait(sig, a.nsteps - step);
       STAMP(9);
       if (fast) {
@@ -1082,7 +1086,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       stg2(o, boff * 6u, make_float2(NZ(adj_t0.x), NZ(adj_t0.y))); stg2(o + 2, boff * 6u, make_float2(NZ(adj_t0.z), NZ(adj_f0.x)));
       stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
     }
-    if (SPLIT) pair_wait(sig + 1, a.nsteps - step); else WAVE_SYNC();
+    if (SPLIT) {
+      if (!a.own_joint) pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
+    } else {
+      WAVE_SYNC();
+    }
     }
     // ---- adjoint of eval_body_joints (runs while the contact wave sweeps)
     BodyAdj par = adj_zero();
@@ -1092,9 +1100,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (is_body && c.type != PD_JOINT_FREE) {
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
       if ((SPLIT && pd_parented(JT)) || c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-      if (SPLIT)  // revolute only: the state-only half was computed by the contact wave
+      if (SPLIT)  // revolute only: the state-only half comes from the contact wave, or (own_joint) is recomputed here
       {
-        const RevCache R = rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC);
+        RevCache R;
+        if (a.own_joint) {  // wave-uniform
+          WAVE_SYNC();      // the parent's record was staged by another lane of this wave
+          const float *pr = rec + (pd_parented(JT) || c.parent >= 0 ? c.parent : b) * PD_REC;
+          R = rev_forward<pd_parented(JT)>(m, c, s.r, s.w, ld3(pr), ld4(pr + 3), ld3(pr + 7), tgt[0], act[0], ke[0], kd[0]);
+        } else {
+          R = rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC);
+        }
         rev_adjoint<pd_parented(JT)>(m, c, s, rc, rec, R, tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, aR, a_tgt[0], a_act[0], a_ke[0], a_kd[0]);
       }
       else

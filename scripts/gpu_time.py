@@ -14,6 +14,8 @@ variant = int(os.environ.get("PD_VARIANT", "0"))
 if hasattr(hip_backend.lib(), "pd_debug_set_variant"):  # `make experiment` builds only (PPR_DIFFPHYS_LIB=..._experiment.so)
     hip_backend.lib().pd_debug_set_variant(variant)
     hip_backend.lib().pd_debug_set_groups(int(os.environ.get("PD_GROUPS", "0")))  # env groups per workgroup, 0 = automatic
+    if "PD_OWN_JOINT" in os.environ:
+        hip_backend.lib().pd_debug_set_own_joint(int(os.environ["PD_OWN_JOINT"]))  # adjoint: rev_forward on the body wave (1) / contact wave (0)
 elif variant or os.environ.get("PD_GROUPS"):
     raise SystemExit("PD_VARIANT / PD_GROUPS need the experiment build (make -C ppr-diffphys_amd/csrc experiment)")
 if len(sys.argv) > 1:

@@ -393,7 +393,7 @@ def test_phys_model_training_iterations(dev):
     assert len(gd) > 0 and all(torch.isfinite(v) for v in gd.values())
     assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
     q = model.query()
-    assert q["sim_traj"].shape == (4, 13, 7) and q["grf"].shape == (4, 8 * 13, 6)
+    assert q["sim_poses"].shape == (4, 13, 7) and q["sim_traj"].shape == (4, 3838, 3) and q["grf"].shape == (4, 8 * 13, 6)
     model.save_checkpoint(0)
     assert os.path.exists("/tmp/pprdp_test_log/mi-pace-t/ckpt_phys_latest.pth")
     # nothing between forward() and backward() may wait for the device (lazy env-0 copies, cached step->frame table,

@@ -134,7 +134,7 @@ def test_config_size_gradients_every_tensor_per_env(cfg, dev, oracle_libs):
         N/m makes the gradient jump there while every value stays within rounding.
     An env is explained when its worst-tensor error is <= max(30 cond, 1e-3) or it has a branch difference; there must be none
     that is not.  So that the explanation cannot swallow a real adjoint bug: envs WITHOUT a branch difference must be tight
-    (human: every one < 5e-4; Laikago: 99 % < 2e-3 and all < 1e-2 wherever the rounded-state runs alone move the env by < 1e-3), most envs must pass on conditioning alone, and the kernel's
+    (human: every one < 5e-4; Laikago: 99 % < 3e-3 and all < 1e-2 wherever the rounded-state runs alone move the env by < 1e-3), most envs must pass on conditioning alone, and the kernel's
     median error must stay within 3 x the rounded-state oracle's."""
     from helpers import first_branch_difference, oracle_bundle
     from diffphys_amd import hip_backend
@@ -168,7 +168,7 @@ def test_config_size_gradients_every_tensor_per_env(cfg, dev, oracle_libs):
         calm = regular & (ob["e_round"] < 1e-3)
         print("   calm envs: %d, worst %.1e" % (calm.sum(), worst[calm].max() if calm.any() else 0.0))
         assert calm.sum() > 0.05 * bs, int(calm.sum())
-        assert np.percentile(worst[calm], 99) < 2e-3 and worst[calm].max() < 1e-2, (float(np.percentile(worst[calm], 99)), float(worst[calm].max()))
+        assert np.percentile(worst[calm], 99) < 3e-3 and worst[calm].max() < 1e-2, (float(np.percentile(worst[calm], 99)), float(worst[calm].max()))
 
 
 def test_frames_validated_on_the_host_and_final_state_frame(dev, oracle_libs):
