@@ -18,11 +18,12 @@ f2s = inp["frame2step"]
 fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
 ba = [t[k] for k in ("q_init","qd_init","torques","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
 ap = torch.from_numpy(inp["adj_pos"]).to(dev); av = torch.from_numpy(inp["adj_vel"]).to(dev)
-nblk = (bs * segw // 64 + 3) // 4
+G = int(os.environ.get("PD_GROUPS", "4"))  # env groups per workgroup (the role-by-row mapping below follows it)
+nblk = (bs * segw // 64 + G - 1) // G
 dbg = torch.zeros((nblk * 12 + 64) * 16, dtype=torch.int64, device=dev)
 L = hip_backend.lib()
 L.pd_debug_set_buffer(ctypes.c_void_p(dbg.data_ptr()))
-L.pd_debug_set_groups(4)  # the role-by-row mapping below assumes 4 env groups per workgroup
+L.pd_debug_set_groups(G)
 for it in range(2):
     out = dm.rollout_forward(bs, T, inp["dt"], *fa, frame2step=f2s)
 torch.cuda.synchronize()
@@ -35,8 +36,8 @@ wb = dm.last_launch_info(1)["threads_per_wg"] // 64
 b_all = dbg.view(-1, 16).cpu().numpy().astype(np.float64)[: nblk * wb].reshape(nblk, wb, 16)
 
 
-def rows(arr, role):  # role r = waves 4r .. 4r+3 of a workgroup
-    r = arr[:, 4 * role:4 * role + 4].reshape(-1, 16)
+def rows(arr, role):  # role r = waves G r .. G r + G - 1 of a workgroup
+    r = arr[:, G * role:G * role + G].reshape(-1, 16)
     return r[r[:, :13].sum(1) > 0]
 
 
@@ -51,19 +52,19 @@ fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints
       (3, "wait at barrier B + facc + traj_f/frame stores"), (4, "integrate"), (5, "stage record")]
 cn = [(7, "wait at barrier A/A1 (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
 report("FWD", "body wave", rows(f_all, 0), fn)
-if wf >= 8:
+if wf >= 2 * G:
     r = rows(f_all, 1)
     report("FWD", "contact wave", r, cn)
     print("FWD contact wave: exact cull redone in %.2f%% of wave-steps; speculated candidates (env 0 of the wave) %.2f per step" % (
         100 * r[:, 13].mean() / T, r[:, 14].mean() / T))
-if wb == 12:  # 3-role adjoint
+if wb == 3 * G:  # 3-role adjoint
     report("BWD", "integrate wave", rows(b_all, 0), [(0, "top: seeds + unpack + stage"), (1, "integrate adj (phase 1, signal A, phase 2) + g_res_f"),
                                                     (2, "wait J"), (3, "own + child gather"), (4, "wait C + cacc")])
     report("BWD", "contact wave", rows(b_all, 1), [(7, "prefetch issue"), (9, "wait A"), (10, "contact adjoint per hit"), (11, "per-body sums"),
                                                   (12, "tail / generic sweep")])
     report("BWD", "joint wave", rows(b_all, 2), [(8, "rev_forward (state-only half)"), (7, "prefetch issue"), (9, "wait A"),
                                                 (10, "LDS reads + rev_adjoint + slots"), (11, "signal J + control-gradient stores")])
-elif wb == 8 and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ contacts) wave, joint wave
+elif wb == 2 * G and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ contacts) wave, joint wave
     report("BWD", "integrate wave", rows(b_all, 0), [(0, "top: seeds + unpack + stage + signal S"), (1, "integrate adj (phase 1, signal A, phase 2) + g_res_f"),
                                                     (10, "inline contacts: replay setup"), (11, "inline contacts: hit pass"), (5, "inline contacts: rest"),
                                                     (2, "wait J"), (3, "own + child gather"), (4, "cacc")])
@@ -72,6 +73,6 @@ elif wb == 8 and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ conta
 else:
     report("BWD", "body wave", rows(b_all, 0), [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"),
                                                (2, "wait A + joints adj + stores"), (3, "child gather"), (4, "wait B + cacc gather")])
-    if wb == 8:
+    if wb == 2 * G:
         report("BWD", "contact wave", rows(b_all, 1), [(8, "joint state-only half -> LDS"), (7, "prefetch issue"), (9, "wait at hand-over A"),
                                                       (10, "contact adjoint per hit"), (11, "per-body sums"), (12, "tail / generic sweep")])
