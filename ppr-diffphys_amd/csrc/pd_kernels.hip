@@ -506,8 +506,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     // When no env of the wave has more candidates than the segment has lanes (the usual case) lane j keeps candidate j --
     // entry, point, material -- in registers for the whole epoch: the per-step hit pass then starts with the record read.
     bool lane_owns = false;  // wave-uniform
-    int c_e = 0;
-    float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P;
+    bool two = false;        // wave-uniform: some env has more candidates than lanes (<= 2 SEGW): lane j also keeps candidate SEGW + j
+    int c_e = 0, c_e2 = 0;
+    float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P, c_P2 = c_P, c_M2 = c_P;
     for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
       // A: records + cull vectors of this step are staged, wrench accumulators are zero; bit 30: a body of one of my envs
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       STAMP_COUNT(13, redo ? 1 : 0);
       STAMP_COUNT(14, __shfl(nh, 0));
       int log_n = 0;
-      bool touching = false;  // lane_owns path: does my candidate touch (logged after hand-over B)
+      bool touching = false, touching2 = false;  // lane_owns path: do my candidates touch (logged after hand-over B)
       if (redo) {
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
         if (is_body) cv = cull[b];
@@ -533,6 +534,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
           if (touching) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) atomicAdd(facc + ((c_e >> 24) & 0x3f) * PD_W6 + i, out[i]);
+          }
+        }
+        if (two) {  // (a body's candidates are contiguous in the list and this pass comes second: the sums keep the list's order)
+          if (SEGW + l < nh) {
+            float out[6];
+            touching2 = contact_hit(rec + ((c_e2 >> 24) & 0x3f) * PD_REC, c_P2, c_M2, out);
+            if (touching2) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) atomicAdd(facc + ((c_e2 >> 24) & 0x3f) * PD_W6 + i, out[i]);
+            }
           }
         }
         STAMP(11);
@@ -568,6 +579,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
       } else if (lane_owns) {
         const int s = seg_slot(touching, sm, log_n);
         if (touching && env_ok && s < PD_HITLOG - 1) lg[1 + s] = c_e;
+        if (two) {
+          const int s2 = seg_slot(touching2, sm, log_n);
+          if (touching2 && env_ok && s2 < PD_HITLOG - 1) lg[1 + s2] = c_e2;
+        }
         if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
       }
       if (redo) lane_owns = false;
@@ -578,10 +593,15 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
         if (is_body) cv = sp[b];
         const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, sp, list, is_body, seg, l STAMP_PASS);
         have = sweep_l3_spec<SEGW>(tabs, sp, list, nlist, hits, seg, l, nh);
-        lane_owns = have && __ballot(nh > SEGW) == 0ull;
+        lane_owns = have && __ballot(nh > 2 * SEGW) == 0ull;
+        two = lane_owns && __ballot(nh > SEGW) != 0ull;
         if (lane_owns) {
           c_e = l < nh ? hits[l] : 0;
           c_P = tabs.pts[c_e & 0xffff]; c_M = tabs.mats[(c_e >> 16) & 0xff];
+          if (two) {
+            c_e2 = SEGW + l < nh ? hits[SEGW + l] : 0;
+            c_P2 = tabs.pts[c_e2 & 0xffff]; c_M2 = tabs.mats[(c_e2 >> 16) & 0xff];
+          }
         }
         STAMP(10);
       }
