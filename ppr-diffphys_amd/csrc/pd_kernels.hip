@@ -408,8 +408,14 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
 #ifndef PD_SPEC_K
 #define PD_SPEC_K 4  // steps served by one speculative cull
 #endif
+#ifndef PD_SPEC_SAFETY
+#define PD_SPEC_SAFETY 1.25f  // allowed sinking per step = this x what the present velocity gives ... (1.5 / 2e-4 until round 3)
+#endif
+#ifndef PD_SPEC_SLACK
+#define PD_SPEC_SLACK 1e-4f  // ... + this (metres)
+#endif
 PD_DEV float sink_margin(const BodyConst &c, const BodyState &s, float dt) {
-  return (float)PD_SPEC_K * (1.5f * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + 2e-4f);
+  return (float)PD_SPEC_K * (PD_SPEC_SAFETY * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + PD_SPEC_SLACK);
 }
 
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.  COPY = false leaves
