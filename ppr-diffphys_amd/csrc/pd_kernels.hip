@@ -374,6 +374,23 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
                            int l, int *log, int replay_cnt, int &log_n, F &&compute STAMP_ARGS, bool have_pre = false, int pre_e = 0) {
   if (replay_cnt >= 0) {  // wave-uniform: every env of this wave has a usable log entry
     const int nh_r = replay_cnt;
+    if (ATOMIC) {
+      // sums by ds_add_f32 in hit order: no per-hit slots, no run bounds, and an entry the caller already holds goes straight
+      // from its register into the hit arithmetic (round 3: the detour through hits[] / rs / re cost the compound robots'
+      // integrate wave two wave syncs and ~20 LDS instructions per step)
+      for (int j = l; __ballot(j < nh_r) != 0ull; j += SEGW) {
+        if (j < nh_r) {
+          const int e = have_pre ? pre_e : log[1 + j];
+          const int pt = e & 0xffff, pb = (e >> 24) & 0x3f;
+          float out[NV];
+          compute(rec + pb * PD_REC, T.pts[pt], T.mats[(e >> 16) & 0xff], out);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) atomicAdd(dst + pb * DSTRIDE + i, out[i]);
+        }
+      }
+      STAMP(11);
+      return;
+    }
     if (have_pre) {  // the caller fetched this lane's entry ahead of time (a list has at most PD_HITLOG - 1 <= SEGW entries then)
       if (l < nh_r) hits[l] = pre_e;
     } else {
