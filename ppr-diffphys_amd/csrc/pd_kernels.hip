@@ -467,8 +467,10 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // =============================================================================================
 // SPLIT = wave specialisation (8 waves, contact waves beside body waves).  Kernels whose body wave needs more than
 // 256 VGPRs (compound joints) run unsplit: 4 waves per workgroup, one per SIMD, sweeps inline.
+// (second launch-bound argument = minimum waves per SIMD: the unsplit kernel's 4-wave workgroups must stay within 256 VGPRs so
+// that two of them are resident per CU)
 template <int SEGW, int JT, bool SPLIT>
-__global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
+__global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
@@ -725,6 +727,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
   };
   if (a.nsteps > 0) load_controls(0);
+  // unsplit kernel: the speculated candidates of this wave's envs (see the sweep in the loop)
+  int u_since = PD_SPEC_K, u_nh = 0, u_e = 0;
+  bool u_have = false, u_owns = false;
+  float4 u_P = make_float4(0.f, 0.f, 0.f, 0.f), u_M = u_P;
   STAMP_DECL;
   for (int step = 0; step < a.nsteps; ++step) {
     // hand-over A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
@@ -739,11 +745,72 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     const int fr = n_fr;
     load_controls(step + 1);
     if (!SPLIT) {
+      // Unsplit kernel (compound / generic robots at large batches): the same speculation as the contact wave's, inline (round 3;
+      // rounds 1-2 ran the exact three-level sweep here EVERY step: ~38 % of quad's forward step).  Every PD_SPEC_K steps -- or at
+      // once when a body outran its margin -- this wave culls with the vectors of the CURRENT state lowered by the margin and keeps
+      // the candidates (lane j = candidate j); the steps in between evaluate them on the state that then exists.  contact_hit
+      // applies the reference's exact test to each, the candidates are a superset of the exact sweep's hits in the same order, so
+      // the wrench sums are those of the exact sweep.
       WAVE_SYNC();
-      int log_n;
-      sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
-                                           is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY, log_n, contact_hit STAMP_PASS);
-      write_hit_log<SEGW>(a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG, hits, log_n, env_ok, l);
+      int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
+      if (u_since >= PD_SPEC_K || spec_failed || !u_have) {  // wave-uniform
+        if (is_body) {
+          margin = sink_margin(c, s, a.dt); sunk = 0.f;
+          float4 cv = cull[b];
+          cv.x -= margin;
+          spec[b] = cv;
+        }
+        WAVE_SYNC();
+        const int nlist = sweep_cull<SEGW>(m, tabs, c, is_body ? spec[b] : make_float4(0.f, 0.f, 1.f, 0.f), spec, list, is_body, seg, l STAMP_PASS);
+        u_have = sweep_l3_spec<SEGW>(tabs, spec, list, nlist, hits, seg, l, u_nh);
+        u_owns = u_have && __ballot(u_nh > SEGW) == 0ull;
+        if (u_owns) {
+          u_e = l < u_nh ? hits[l] : 0;
+          u_P = tabs.pts[u_e & 0xffff]; u_M = tabs.mats[(u_e >> 16) & 0xff];
+        }
+        u_since = 0;
+      }
+      ++u_since;
+      if (!u_have) {  // the candidates did not fit the list: the exact sweep, which flushes in pieces
+        int log_n;
+        sweep_contacts<SEGW, 6, PD_W6, true>(m, tabs, c, is_body ? cull[b] : make_float4(0.f, 0.f, 1.f, 0.f), rec, cull, list, hits, slot, facc,
+                                             is_body, env_ok, seg, l, nullptr, PD_NO_REPLAY, log_n, contact_hit STAMP_PASS);
+        write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);
+      } else {
+        const SegMask usm = seg_mask<SEGW>(seg);
+        int log_n = 0;
+        if (u_owns) {
+          bool tch = false;
+          if (l < u_nh) {
+            float out[6];
+            tch = contact_hit(rec + ((u_e >> 24) & 0x3f) * PD_REC, u_P, u_M, out);
+            if (tch) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) atomicAdd(facc + ((u_e >> 24) & 0x3f) * PD_W6 + i, out[i]);
+            }
+          }
+          const int sl = seg_slot(tch, usm, log_n);
+          if (tch && env_ok && sl < PD_HITLOG - 1) lg[1 + sl] = u_e;
+        } else {  // more candidates than lanes: batches out of the LDS list
+          for (int j0 = 0; __ballot(j0 < u_nh) != 0ull; j0 += SEGW) {
+            const int j = j0 + l;
+            bool tch = false;
+            int e = 0;
+            if (j < u_nh) {
+              e = hits[j];
+              float out[6];
+              tch = contact_hit(rec + ((e >> 24) & 0x3f) * PD_REC, tabs.pts[e & 0xffff], tabs.mats[(e >> 16) & 0xff], out);
+              if (tch) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) atomicAdd(facc + ((e >> 24) & 0x3f) * PD_W6 + i, out[i]);
+              }
+            }
+            const int sl = seg_slot(tch, usm, log_n);
+            if (tch && env_ok && sl < PD_HITLOG - 1) lg[1 + sl] = e;
+          }
+        }
+        if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
+      }
     }
     STAMP(1);
     // ---- eval_body_joints (runs while the contact wave sweeps)
@@ -817,7 +884,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_fwd(
     }
     o_mask = clamp_mask;
     STAMP(4);
-    if (SPLIT) {  // did every body stay inside the margin the contact wave speculated with?  (NaN counts as "no")
+    {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
       sunk += sink_rate * a.dt;
       const bool bad = is_body && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin);
       spec_failed = __ballot(bad) != 0ull;
