@@ -469,6 +469,13 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // 256 VGPRs (compound joints) run unsplit: 4 waves per workgroup, one per SIMD, sweeps inline.
 // (second launch-bound argument = minimum waves per SIMD: the unsplit kernel's 4-wave workgroups must stay within 256 VGPRs so
 // that two of them are resident per CU)
+// Which contact wave serves which body wave.  A workgroup's waves are dealt to the four SIMDs cyclically; with shift 0 a body wave
+// and its contact wave share a SIMD, with shift 1 the contact wave of group g runs beside the body wave of group g - 1.
+// Measured (same-box A/B, Laikago 4096 / 8192): the FORWARD pass is 1 % faster shifted (0.227 against 0.229-0.231 ms: joint pass and
+// hit pass of a pair start together at hand-over A and would compete for one SIMD), the ADJOINT 11 % slower (0.327 against 0.292:
+// its pair alternates -- the contact wave is busy while the body wave waits -- and two unrelated busy waves collide instead).
+#define PD_PAIR_SHIFT_FWD 1
+#define PD_PAIR_SHIFT_BWD 0
 template <int SEGW, int JT, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -477,8 +484,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   // env groups (= body waves) per workgroup: chosen by the host per launch (1 .. PD_BWAVES) so that small batches spread
   // over all compute units instead of filling a few
   const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);
-  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
+  const int lane = threadIdx.x & 63, wave = ((int)(threadIdx.x >> 6) + (contact_wave ? PD_PAIR_SHIFT_FWD : 0)) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
@@ -929,8 +936,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
   const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);  // env groups per workgroup (host's choice per launch)
-  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
+  const int lane = threadIdx.x & 63, wave = ((int)(threadIdx.x >> 6) + (contact_wave ? PD_PAIR_SHIFT_BWD : 0)) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
