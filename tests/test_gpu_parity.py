@@ -685,6 +685,56 @@ def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle
     assert np.array_equal(out2["grads"]["q_init"].reshape(len(pick), -1), out["grads"]["q_init"].reshape(bs, -1)[pick])
 
 
+def test_unsplit_forward_speculates_and_redoes_its_cull(dev, oracle_libs):
+    """Compound robots at more than four env groups per compute unit run the UNSPLIT forward kernel (one wave does bodies, joints
+    and contacts), which since round 3 keeps speculated contact candidates for PD_SPEC_K steps like the contact wave does.  A quad
+    batch just above that threshold with downward kicks on part of the envs (margins outrun inside an epoch => the cull is redone
+    at once) must match the fp32 C oracle, and the same envs in a small batch -- which takes the wave-specialised kernel and the
+    exact hand-over path -- must give the same forward bits: both kernels sum an env's contact wrenches in list order."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template("quad")
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    bs, T = 8 * cus + 64, 22   # env groups (2 envs each) > 4 per compute unit
+    inp = synth.make_inputs(tpl, "quad", bs=bs, nsteps=T, seed=23, steps_per_frame=7, penetration=0.004)
+    nb = int(tpl["nb"])
+    rf = inp["res_f"].reshape(T, bs, nb, 6)
+    mass = inp["body_mass"].reshape(bs, nb)
+    kick = np.zeros((T, bs), np.float32)
+    kick[2:12, ::3] = 3000.0     # every third env: its wave-mate stays calm
+    kick[9:18, 1::5] = 1500.0
+    rf[..., 4] -= kick[:, :, None] * mass[None]
+    dm = hip_backend.DeviceModel(tpl)
+    out = gpu_rollout(dm, inp, dev)
+    info = dm.last_launch_info(0)
+    assert info["threads_per_wg"] * 2 == 64 * info["envs_per_wg"], info   # one wave per env group: the unsplit kernel ran
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert np.abs(st["grf"]).max() > 100.0, "the kicked robots must hit the ground hard"
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-4 and relmax(out["wp_vel"], st["wp_vel"]) < 5e-3
+    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 1e-2
+    for k in ("q_init", "qd_init", "res_f", "refs", "body_inv_mass"):
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+    sub = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
+    pick = np.arange(0, 96, 1)   # kicked and calm envs alike
+    for k in ("q_init", "qd_init", "target_ke", "target_kd", "body_mass", "body_inv_mass", "body_inertia", "body_inv_inertia"):
+        sub[k] = inp[k].reshape(bs, -1)[pick].reshape(-1)
+    for k in ("torques", "refs", "res_f"):
+        sub[k] = inp[k].reshape(T, bs, -1)[:, pick].reshape(T, -1)
+    F = len(inp["frame2step"])
+    for k in ("adj_pos", "adj_vel"):
+        sub[k] = inp[k].reshape(F, bs, -1)[:, pick].reshape(F, -1)
+    dm2 = hip_backend.DeviceModel(tpl)
+    out2 = gpu_rollout(dm2, sub, dev)
+    info2 = dm2.last_launch_info(0)
+    assert info2["threads_per_wg"] == 64 * info2["envs_per_wg"], info2    # two waves per env group: the wave-specialised kernel
+    for k in ("wp_pos", "wp_vel", "grf", "jaf"):
+        assert np.array_equal(out2[k].reshape(F, len(pick), -1), out[k].reshape(F, bs, -1)[:, pick]), k
+    assert np.array_equal(out2["grads"]["q_init"].reshape(len(pick), -1), out["grads"]["q_init"].reshape(bs, -1)[pick])
+
+
 @pytest.mark.parametrize("dim", [7, 6])
 def test_fused_se3_loss_matches_the_torch_composition(dim, dev):
     """pd_se3_loss (one launch: loss + both gradients) against the torch restatement of the reference's
