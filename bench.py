@@ -324,6 +324,17 @@ def main():
                 "wave_wait_share": p.get("wait_share") if same_cfg else None,
             }
 
+        def valu_roofline(p, ms):
+            """The bound that actually binds: a SIMD issues one non-packed fp32 wave64 instruction per ~4.2
+            cycles whatever the waves or their ILP (scripts/micro/valu_chain.hip, pk_issue.hip).  Instructions per launch from the
+            committed profile (SQ_INSTS_VALU), duration from THIS run, clock taken as 2.4 GHz (GRBM_GUI_ACTIVE of the profile agrees)."""
+            n = p.get("valu_insts_per_launch") if same_cfg else None
+            if not n:
+                return None
+            peak = cus * 4.0 * 2.4e9 / 4.2
+            return {"unit": "wave64 fp32 instructions/s", "achieved": n / (ms * 1e-3), "peak": peak, "frac": n / (ms * 1e-3) / peak,
+                    "insts_per_launch": n, "cycles_per_instruction": 4.2, "clock_ghz_assumed": 2.4}
+
         line = {
             "metric": "env-steps/sec (fwd+adjoint), Laikago 12-DoF, batch=4096, 1/2/4/8 MI355X",
             "value": gbs * T * args.steps / elapsed,
@@ -353,8 +364,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "limiter": "instruction issue / dependency-chain latency of one wave per SIMD (frac of HBM is what the contract asks for; "
-                           "see secondary: VALU busy, waves per SIMD)",
+                "limiter": "fp32 VALU issue: a SIMD issues one non-packed wave64 fp32 instruction per ~4.2 cycles whatever the waves or "
+                           "their ILP; the adjoint's two waves per SIMD keep it ~95 % busy (roofline.valu; the forward pass ~53 %: hand-over "
+                           "latency).  frac of HBM is what the contract asks for",
+                "valu": valu_roofline(pb, bwd_ms),
                 "kernel": "k_rollout_bwd",
                 "achieved": ach_bwd / 1e9,
                 "peak": HBM_PEAK_BYTES / 1e9,
@@ -370,9 +383,9 @@ def main():
                 "secondary": secondary(geo_b, pb),
                 "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,
                                "frac_of_achievable": ach_fwd / HBM_ACHIEVABLE_BYTES, "avg_launch_ms": fwd_ms,
-                               "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf)},
-                "note": "dependency-chain latency / issue bound, not HBM-bound (see roofline.secondary and DESIGN.md section 4); launch "
-                        "durations are per dispatch, measured on launches enqueued back to back like the timed region",
+                               "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf), "valu": valu_roofline(pf, fwd_ms)},
+                "note": "VALU-issue bound (adjoint) / hand-over-latency bound (forward), not HBM-bound (roofline.valu, roofline.secondary, "
+                        "DESIGN.md section 4); launch durations are per dispatch, measured on launches enqueued back to back like the timed region",
             },
         }
         if other is not None:

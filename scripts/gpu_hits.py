@@ -28,6 +28,11 @@ w = np.clip(cnt, 0, None).reshape(T, bs // epw, epw)
 print("per wave (%d envs): mean sum %.1f  mean max-env %.1f  p90 sum %d" % (epw, w.sum(2).mean(), w.max(2).mean(), np.percentile(w.sum(2), 90)))
 print("batches of %d per env-step now (max over the wave's envs): mean %.2f" % (segw, np.ceil(w.max(2) / segw).mean()))
 print("batches of 64 if compacted wave-wide: mean %.2f" % np.ceil(w.sum(2) / 64.0).mean())
+for g in (2, 4):  # would one contact wave serve g env groups (round-3 question: the adjoint is VALU-issue bound)?
+    wg = np.clip(cnt, 0, None).reshape(T, bs // (epw * g), epw * g)
+    print("per %d groups (%d envs): mean sum %.1f  P(sum <= 64) %.3f  P(max-env <= %d) %.3f  mean passes of 64 %.2f" % (
+        g, epw * g, wg.sum(2).mean(), (wg.sum(2) <= 64).mean(), 64 // (epw * g), (wg.max(2) <= 64 // (epw * g)).mean(), np.ceil(wg.sum(2) / 64.0).mean()))
+print("P(max-env of a wave <= 4) %.3f  <= 8 %.3f" % ((w.max(2) <= 4).mean(), (w.max(2) <= 8).mean()))
 print("histogram of counts:", np.bincount(np.clip(cnt, 0, None).ravel(), minlength=33)[:33].tolist())
 bodies = (log[:, :, 1:] >> 24) & 0x3f
 valid = np.arange(log.shape[2] - 1)[None, None, :] < np.clip(cnt, 0, None)[:, :, None]

@@ -30,18 +30,28 @@ __global__ void k(float *out, unsigned long long *cyc, int iters) {
 template <int MODE>
 void run(float *d, unsigned long long *c, int wps) {
   const int iters = 20000;
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, d, c, iters);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, d, c, iters);
   (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0);
+  hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(256 * wps), 0, 0, d, c, iters);
+  (void)hipEventRecord(e1);
+  (void)hipDeviceSynchronize();
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
   unsigned long long h[256];
   (void)hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost);
   double avg = 0;
   for (int i = 0; i < 256; ++i) avg += (double)h[i];
   const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"};
-  printf("%-13s waves/SIMD %d : %.2f shader cycles per instruction per wave\n", names[MODE], wps, avg / 256.0 / ((double)iters * 64));
+  // wall time: the s_memtime tick is not wall time once several waves share a SIMD (it stays at 4.4 per instruction per wave)
+  printf("%-13s waves/SIMD %d : %.2f ticks per instruction per wave; wall %.3f ms = %.2f ns per instruction per SIMD (%.2f cycles at 2.4 GHz)\n",
+         names[MODE], wps, avg / 256.0 / ((double)iters * 64), ms, ms * 1e6 / ((double)iters * 64 * wps), ms * 1e6 / ((double)iters * 64 * wps) * 2.4);
 }
 int main() {
   float *d; unsigned long long *c;
   (void)hipMalloc(&d, 1 << 22); (void)hipMalloc(&c, 256 * 8);
-  for (int wps : {1, 2, 4}) { run<0>(d, c, wps); run<1>(d, c, wps); run<2>(d, c, wps); run<3>(d, c, wps); }
+  for (int wps : {1, 2, 3, 4, 8}) { run<0>(d, c, wps); run<1>(d, c, wps); run<2>(d, c, wps); run<3>(d, c, wps); }
   return 0;
 }

@@ -1,4 +1,8 @@
-// Microbenchmark: cycles per wave64 fp32 FMA for 1/2/4/8 independent dependency chains, one and two waves per SIMD.
+// Microbenchmark: cycles per wave64 fp32 FMA for 1/2/4/8 independent dependency chains, 1 / 2 / 4 waves per SIMD.
+// BUILD WITH -fno-slp-vectorize (as the library is): plain -O3 turns 2+ chains into v_pk_fma_f32 and the figure per FMA halves --
+// that artefact is where rounds 1-2 got "independent FMAs issue every 2.5-3 cycles" from.  Without it (round 3, MI355X):
+//   1 wave : 6.0 (one chain) / 4.8-5.0 (2-8 chains);  2 waves: 4.4-4.8 per SIMD;  4 waves: 4.15-4.4 per SIMD
+// i.e. a SIMD issues one non-packed fp32 wave64 instruction per ~4.2 cycles, whatever the waves or their ILP.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 template <int C>

@@ -49,6 +49,10 @@ summary = {}
 cmd_file = os.path.join(src, "command.txt")
 cmd = open(cmd_file).read().strip().split("bench.py", 1)[-1].strip() if os.path.exists(cmd_file) else "--steps 10 --warmup 2"
 N_SIMD = 1024  # 256 CUs x 4
+# A SIMD issues ONE non-packed fp32 wave64 instruction per 4.15-4.45 cycles whatever the number of waves or their instruction-level
+# parallelism (scripts/micro/valu_chain.hip built with -fno-slp-vectorize, scripts/micro/pk_issue.hip; rounds 1-2 used 2.5, which was the
+# rate of the v_pk_fma_f32 the SLP vectoriser had made of that microbenchmark, per FMA)
+VALU_CYC = 4.2
 lines = ["# rocprofv3 summary `%s` (bench.py %s, 1x MI355X)\n" % (tag, cmd),
          "Source: `scripts/profile_gpu.sh %s` on the GPU box; raw csv under `gpurun_out/prof_%s/` (scratch)." % (tag, tag), ""]
 for k in ("k_rollout_fwd", "k_rollout_bwd"):
@@ -62,7 +66,7 @@ for k in ("k_rollout_fwd", "k_rollout_bwd"):
     valu_rate = mean(k, "SQ_INSTS_VALU") / max(1.0, gui * N_SIMD)  # wave-instructions issued per SIMD and GPU-busy cycle
     waves_per_simd = float(meta.get(k, {}).get("grid", 0)) / 64.0 / N_SIMD
     summary[k] = dict(avg_launch_ns=avg_ns[k], fetch_size_kb_raw=fetch_kb, write_size_kb=write_kb, hbm_bytes_per_launch=hbm,
-                      valu_issue_per_simd_cycle=valu_rate, valu_busy=2.5 * valu_rate,  # 2.5 cycles per wave64 fp32 op (scripts/micro/valu_chain.hip)
+                      valu_issue_per_simd_cycle=valu_rate, valu_busy=VALU_CYC * valu_rate, valu_insts_per_launch=mean(k, "SQ_INSTS_VALU"),
                       wait_share=mean(k, "SQ_WAIT_ANY") / max(1.0, wc), waves_per_simd=waves_per_simd, meta=meta.get(k, {}))
     lines += ["## %s  (%s)" % (k, meta.get(k, {}).get("name", "")),
               "* average launch %.1f us; grid %s x wg %s; VGPR %s (+%s accum), SGPR %s, scratch %s" % (
@@ -74,8 +78,8 @@ for k in ("k_rollout_fwd", "k_rollout_bwd"):
                   mean(k, "SQ_INSTS_VMEM_RD"), mean(k, "SQ_INSTS_VMEM_WR")),
               "* wave cycles (quad-cycles) %.3g: waiting (SQ_WAIT_ANY) %.0f%%, issuing (SQ_ACTIVE_INST_ANY) %.0f%%, issue-stalled (SQ_WAIT_INST_ANY) %.0f%%" % (
                   wc, 100 * mean(k, "SQ_WAIT_ANY") / wc, 100 * mean(k, "SQ_ACTIVE_INST_ANY") / wc, 100 * mean(k, "SQ_WAIT_INST_ANY") / wc),
-              "* secondary bound: %.2f waves per SIMD launched; VALU issue %.3f wave-instructions per SIMD-cycle (x 2.5 cycles each = %.0f%% VALU busy); GPU busy %.3g cycles" % (
-                  waves_per_simd, valu_rate, 250 * valu_rate, gui),
+              "* secondary bound: %.2f waves per SIMD launched; VALU issue %.3f wave-instructions per SIMD-cycle (x 4.2 cycles each = %.0f%% of the SIMDs' fp32 issue rate); GPU busy %.3g cycles" % (
+                  waves_per_simd, valu_rate, 100 * VALU_CYC * valu_rate, gui),
               "* LDS: bank-conflict cycles %.3g of %.3g active (%.0f%%)" % (
                   mean(k, "SQ_LDS_BANK_CONFLICT"), mean(k, "SQ_LDS_IDX_ACTIVE"),
                   100 * mean(k, "SQ_LDS_BANK_CONFLICT") / max(1.0, mean(k, "SQ_LDS_IDX_ACTIVE"))), ""]
