@@ -469,13 +469,15 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // 256 VGPRs (compound joints) run unsplit: 4 waves per workgroup, one per SIMD, sweeps inline.
 // (second launch-bound argument = minimum waves per SIMD: the unsplit kernel's 4-wave workgroups must stay within 256 VGPRs so
 // that two of them are resident per CU)
-// Which contact wave serves which body wave.  A workgroup's waves are dealt to the four SIMDs cyclically; with shift 0 a body wave
-// and its contact wave share a SIMD, with shift 1 the contact wave of group g runs beside the body wave of group g - 1.
-// Measured (same-box A/B, Laikago 4096 / 8192): the FORWARD pass is 1 % faster shifted (0.227 against 0.229-0.231 ms: joint pass and
-// hit pass of a pair start together at hand-over A and would compete for one SIMD), the ADJOINT 11 % slower (0.327 against 0.292:
-// its pair alternates -- the contact wave is busy while the body wave waits -- and two unrelated busy waves collide instead).
-#define PD_PAIR_SHIFT_FWD 1
-#define PD_PAIR_SHIFT_BWD 0
+// A body wave and its contact wave share a SIMD (a workgroup's waves are dealt to the four SIMDs cyclically), and a SIMD issues one
+// fp32 vector instruction per ~4.2 cycles whatever the waves -- so WHO gets the issue slots matters.  The
+// hardware prefers the older wave (the body wave); the contact wave raises its priority (s_setprio) for the windows in which the
+// pair waits for IT: forward, hand-over A .. B (the hit pass the body wave then waits for) and on through the speculative cull
+// that the next hit pass needs (0.226 -> 0.214 ms at 4096 envs, 0.442 -> 0.418 at 8192); adjoint, A .. B (0.293 -> 0.282,
+// 0.577 -> 0.562).  Raised while it recomputes rev_forward, or for the whole kernel (round 2), the adjoint is slower (0.298).
+// Serving the body wave of the NEXT group instead (contact wave beside an unrelated body wave) was 1 % faster in the forward pass
+// without priorities, is 1 % slower with them, and is 11 % slower in the adjoint: pairs stay on one SIMD.
+#define PD_PRIO_CRITICAL 3
 template <int SEGW, int JT, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   // over all compute units instead of filling a few
   const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);
   const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
-  const int lane = threadIdx.x & 63, wave = ((int)(threadIdx.x >> 6) + (contact_wave ? PD_PAIR_SHIFT_FWD : 0)) % bw;
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       // A: records + cull vectors of this step are staged, wrench accumulators are zero; bit 30: a body of one of my envs
       // outran its margin
       const int sigA = pair_wait(sig, step + 1);
+      __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for this hit pass
       STAMP(7);
       const bool redo = !have || (sigA & PD_SIG_FLAG) != 0;  // wave-uniform
       STAMP_COUNT(13, redo ? 1 : 0);
@@ -605,6 +608,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
       STAMP(12);
       pair_signal(sig + 1, step + 1);  // B: contact wrenches are complete
+      const bool cull_now = step % PD_SPEC_K == 0 && step + 1 < a.nsteps;  // state `step` opened an epoch: cull for the steps it serves
+      if (!cull_now) __builtin_amdgcn_s_setprio(0);  // (the cull stays urgent: the next hit pass needs its candidates)
       // the adjoint's log is written off the critical path
       if (redo) {
         write_hit_log<SEGW>(lg, hits, log_n, env_ok, l);
@@ -618,7 +623,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
       }
       if (redo) lane_owns = false;
-      if (step % PD_SPEC_K == 0 && step + 1 < a.nsteps) {  // state `step` opened an epoch: cull for the steps it serves
+      if (cull_now) {
         WAVE_SYNC();  // the log is read out of hits[] before the candidates overwrite it
         const float4 *sp = spec + ((step / PD_SPEC_K) & 1) * nb;
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
@@ -636,6 +641,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
           }
         }
         STAMP(10);
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     STAMP_FLUSH(a);
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
   const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);  // env groups per workgroup (host's choice per launch)
   const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
-  const int lane = threadIdx.x & 63, wave = ((int)(threadIdx.x >> 6) + (contact_wave ? PD_PAIR_SHIFT_BWD : 0)) % bw;
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
@@ -1056,6 +1062,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
       if (!a.own_joint) pair_signal(sig + 1, a.nsteps - step);
       pair_wait(sig, a.nsteps - step);
+      __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for these contact adjoints
       STAMP(9);
       if (fast) {
         float out[PD_ADJ];
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       }
       STAMP(12);
       pair_signal(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
+      __builtin_amdgcn_s_setprio(0);
       cnt_c = cnt_n; e_c = e_n; P_c = P_n; M_c = M_n; tgt_c = tgt_n; act_c = act_n;
       cnt_n = cnt_n2; e_n = e_n2;
     }
@@ -1620,6 +1628,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         }
         STAMP(8);
         pair_wait(sig, a.nsteps - step);  // A: the wrench adjoints of this step are staged
+        __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the integrate wave will wait for these contributions (quad 8192: 1.43 -> 1.40 ms)
         STAMP(9);
         BodyAdj own = adj_zero(), par = adj_zero();
         float a_tgt[ND], a_act[ND], a_ke[ND], a_kd[ND];
@@ -1634,6 +1643,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
         STAMP(10);
         pair_signal(sig + 1, a.nsteps - step);  // J: (own, parent) contributions are complete
+        __builtin_amdgcn_s_setprio(0);
         store_controls(step, a_tgt, a_act, a_ke, a_kd);
         STAMP(11);
       }
