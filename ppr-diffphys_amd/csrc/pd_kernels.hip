@@ -836,16 +836,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     STAMP(2);
     WAVE_SYNC();
     v3 jt = -wc_t, jf = -wc_f;  // joint wrench on this body: own joint first, then children in index order
-    {  // first four children: all LDS reads are issued back to back (one exposed latency instead of one per child)
-      float cw[4][6];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float *pc = pcon + cz[k] * PD_W6;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) cw[k][i] = pc[i];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { jt += V3(cw[k][0], cw[k][1], cw[k][2]); jf += V3(cw[k][3], cw[k][4], cw[k][5]); }
+    {  // first four children: all LDS reads are issued back to back (one exposed latency instead of one per child), packed sums
+      const float *const src[4] = {pcon + cz[0] * PD_W6, pcon + cz[1] * PD_W6, pcon + cz[2] * PD_W6, pcon + cz[3] * PD_W6};
+      wrench_add_from_n(jt, jf, src);
     }
     for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
@@ -1260,16 +1253,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     }
     STAMP(2);
     WAVE_SYNC();
-    {  // first four children with all LDS reads in flight together, then any further ones
-      float cw[4][PD_ADJ];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float *pc = cslot + cz[k] * PD_ADJ;
-#pragma unroll
-        for (int i = 0; i < PD_ADJ; ++i) cw[k][i] = pc[i];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) adj_add_from(ga, cw[k]);
+    {  // first four children with all LDS reads in flight together (packed sums), then any further ones
+      const float *const src[4] = {cslot + cz[0] * PD_ADJ, cslot + cz[1] * PD_ADJ, cslot + cz[2] * PD_ADJ, cslot + cz[3] * PD_ADJ};
+      adj_add_from_n(ga, src);
     }
     for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
@@ -1289,7 +1275,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     }
     if (is_body) {
       float *d = cacc + b * PD_ADJ;
-      adj_add_from(ga, d);
+      const float *const src[1] = {d};
+      adj_add_from_n(ga, src);
 #pragma unroll
       for (int k = 0; k < PD_ADJ; ++k) d[k] = 0.f;
     }
@@ -1790,19 +1777,9 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     STAMP(6);
     pair_wait(sig + 1, a.nsteps - step);  // J: joint contributions are complete
     STAMP(2);
-    {  // own joint first, then the first four children with all LDS reads in flight together, then any further ones
-      float ow[PD_ADJ], cw[4][PD_ADJ];
-#pragma unroll
-      for (int i = 0; i < PD_ADJ; ++i) ow[i] = oslot[b * PD_ADJ + i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float *pc = cslot + cz[k] * PD_ADJ;
-#pragma unroll
-        for (int i = 0; i < PD_ADJ; ++i) cw[k][i] = pc[i];
-      }
-      adj_add_from(ga, ow);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) adj_add_from(ga, cw[k]);
+    {  // own joint first, then the first four children with all LDS reads in flight together (packed sums), then any further ones
+      const float *const src[5] = {oslot + b * PD_ADJ, cslot + cz[0] * PD_ADJ, cslot + cz[1] * PD_ADJ, cslot + cz[2] * PD_ADJ, cslot + cz[3] * PD_ADJ};
+      adj_add_from_n(ga, src);
     }
     for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
@@ -1812,7 +1789,8 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     if (ROLES == 3) pair_wait(sig + 2, a.nsteps - step);  // C: contact adjoints are complete
     if (is_body) {
       float *d = cacc + b * PD_ADJ;
-      adj_add_from(ga, d);
+      const float *const src[1] = {d};
+      adj_add_from_n(ga, src);
 #pragma unroll
       for (int k = 0; k < PD_ADJ; ++k) d[k] = 0.f;
     }
