@@ -16,7 +16,9 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+# gpurun MERGES a call's output into gpurun_out/: a tag profiled twice leaves two runs' files side by side -- take the newest of each
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 rows = [r for r in csv.DictReader(open(stats))]
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
@@ -29,7 +31,7 @@ meta = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
         continue
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if "rollout" not in r["Kernel_Name"]:
                 continue
