@@ -1,0 +1,42 @@
+"""The bench line itself (the driver parses it): one short run of bench.py on the GPU, checked for the contract's fields and for
+internal consistency -- value against ms_per_step, the roofline fraction against the launch duration, the VALU-issue roofline
+below its peak."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_and_consistency():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--repeats", "3", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "boundary", "blocks"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "env-steps/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["global_batch"] == 4096 and d["config"]["sim_steps"] == 100 and d["config"]["nan_grads"] == 0
+    # value = env-steps of one step / the median block's time per step
+    assert abs(d["value"] - 4096 * 100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["blocks"]["n"] == 3 and d["blocks"]["min_value"] <= d["value"] <= d["blocks"]["max_value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # achieved = algorithmic bytes per launch / the kernel's launch duration, measured in this run
+    assert abs(r["achieved"] * 1e9 - 4096 * 100 * r["algorithmic_bytes_per_env_step"] / (r["avg_launch_ms"] * 1e-3)) < 1e-6 * r["achieved"] * 1e9
+    assert 0.05 < r["frac"] < 1.0
+    # the dominant kernel cannot take longer than the whole step; forward + adjoint launches are about the step
+    f = r["fwd_kernel"]
+    assert r["avg_launch_ms"] < d["ms_per_step"] and 0.8 * d["ms_per_step"] < r["avg_launch_ms"] + f["avg_launch_ms"] < 1.2 * d["ms_per_step"]
+    # the roofline that binds (fp32 VALU issue): below its peak, and the adjoint close to it
+    assert r["valu"] is not None and 0.5 < r["valu"]["frac"] < 1.02, r["valu"]
+    assert f["valu"] is not None and 0.2 < f["valu"]["frac"] < r["valu"]["frac"]
+    b = d["boundary"]
+    assert 0.8 < b["ratio_to_value"] < 1.1 and b["nan_grads"] == 0
