@@ -42,7 +42,7 @@ def _oracle(tpl, inp, dtype):
 
 
 CAPS = {  # absolute caps (relmax per tensor): pose, twist, wrench, gradient
-    "laikago": (2e-6, 1e-3, 3e-4, 2e-3),
+    "laikago": (2e-6, 3e-4, 3e-4, 6e-4),  # round 3 (twist angle through atan2): measured <= 1.6e-7 / 8.5e-5 / 1.1e-4 / 2.1e-4 over six seeds; were 1e-3 / 2e-3
     "human": (2e-6, 2e-5, 3e-4, 1e-4),
     "quad": (2e-6, 2e-5, 3e-4, 1e-4),
 }
