@@ -57,12 +57,14 @@ def test_golden_one_frame_interval(name, segw, dev):
     if segw:
         dm.set_segment_width(segw)
     out = gpu_rollout(dm, inp, dev)
-    assert relmax(out["wp_pos"], g["wp_pos"]) < 5e-5
-    assert relmax(out["wp_vel"], g["wp_vel"]) < 2e-3
-    assert relmax(out["grf"], g["grf"]) < 5e-3 and relmax(out["jaf"], g["jaf"]) < 5e-3
+    # bars = ~5x what round 3's kernels measure on these fixtures (poses 6e-7, twists 2e-5, wrenches 1e-4, gradients 4e-5);
+    # rounds 1-2 had 5e-5 / 2e-3 / 5e-3 / 2e-2
+    assert relmax(out["wp_pos"], g["wp_pos"]) < 5e-6
+    assert relmax(out["wp_vel"], g["wp_vel"]) < 1e-4
+    assert relmax(out["grf"], g["grf"]) < 5e-4 and relmax(out["jaf"], g["jaf"]) < 5e-4
     for k in GRADS:
         assert np.isfinite(out["grads"][k]).all(), k
-        assert relmax(out["grads"][k].reshape(g["grad_" + k].shape), g["grad_" + k]) < 2e-2, k
+        assert relmax(out["grads"][k].reshape(g["grad_" + k].shape), g["grad_" + k]) < 2e-4, k
     # FK fixture
     bq, bqd = dm.fk_forward(torch.from_numpy(g["fk_joint_q"]).to(dev), torch.from_numpy(g["fk_joint_qd"]).to(dev))
     assert relmax(bq.cpu().numpy(), g["fk_body_q"]) < 2e-6 and relmax(bqd.cpu().numpy(), g["fk_body_qd"]) < 2e-6
@@ -96,8 +98,9 @@ def test_vs_c_oracle_fresh_seed(name, bs, dev, oracle_libs):
     st32 = rc32.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
     g32 = rc32.rollout_backward(st32, inp["adj_pos"], inp["adj_vel"])
     assert np.abs(st["grf"]).max() > 1.0, "contacts must be active in this test"
-    assert relmax(out["wp_pos"], st["wp_pos"]) < 5e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 2e-3
-    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 5e-3
+    # (measured over three seeds: poses <= 2e-6, twists <= 5.3e-4 (quad), wrenches <= 1.7e-4)
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 2e-3
+    assert relmax(out["grf"], st["grf"]) < 1e-3 and relmax(out["jaf"], st["jaf"]) < 1e-3
     for k in GRADS:
         e, e32 = relmax(out["grads"][k].reshape(gr[k].shape), gr[k]), relmax(g32[k], gr[k])
         print("%s %-18s kernel vs float64 %.1e   fp32 oracle vs float64 %.1e" % (name, k, e, e32))
