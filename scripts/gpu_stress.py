@@ -100,10 +100,18 @@ for case in range(ncases):
         ee = grad_env_errors(full["grads"], ob["g64"], bs)
         w = np.max(np.stack([ee[k] for k in GRAD_LEAD]), 0)
         first = first_branch_difference(ob["rc64"], ob["st64"], full["traj"], inp, bs)
-        unexpl = (w > np.maximum(30 * ob["cond"], 1e-3)) & (first >= T)
-        fwd_ok = all(e[k] < lim[k] for k in ("pos", "vel", "grf"))
-        if fwd_ok and not unexpl.any():
-            ok, note = True, "every env explained (%d of %d above 1e-3, %d with a branch difference)" % ((w > 1e-3).sum(), bs, (first < T).sum())
+        # forward outputs env by env too (round 3, 12 000-case sweep: a branch difference -- a clamp, a contact, the Coulomb switch --
+        # in a kicked or spinning robot moves THAT env's poses off the bars as well; the other envs of the batch stay inside them)
+        F = len(inp["frame2step"])
+        def fwd_env(a, r, wd):
+            a = np.asarray(a, np.float64).reshape(F, bs, nb, wd); r = np.asarray(r, np.float64).reshape(F, bs, nb, wd)
+            return np.abs(a - r).max((0, 2, 3)) / (np.abs(r).max() + 1e-30)
+        st64 = ob["st64"]
+        excess = np.maximum(np.maximum(fwd_env(full["wp_pos"], st64["wp_pos"], 7) / lim["pos"], fwd_env(full["wp_vel"], st64["wp_vel"], 6) / lim["vel"]),
+                            np.maximum(fwd_env(full["grf"], st64["grf"], 6) / lim["grf"], w / 1e-3))  # > 1: off a bar
+        unexpl = (excess > 1.0) & (first >= T) & (excess > 30 * ob["cond"] / 1e-3)
+        if not unexpl.any():
+            ok, note = True, "every env explained (%d of %d off a bar, %d with a branch difference)" % ((excess > 1.0).sum(), bs, (first < T).sum())
     bad += 0 if ok else 1
     if not ok:  # keep the failing case for offline inspection
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -143,11 +143,15 @@ def grad_env_errors(g, r, bs):
 
 
 
-def first_branch_difference(rc64, st64, traj, inp, bs, height_tol=5e-7):
+def first_branch_difference(rc64, st64, traj, inp, bs, height_tol=5e-7, coulomb_tol=1e-3):
     """First step (per env, or nsteps when there is none) at which the GPU rollout took a discrete decision the float64 oracle
     did not: a different number of touching contact candidates on some body, a different number of them on the sliding branch of
     the Coulomb min, a different velocity-clamp mask (the kernel's own, stored with its trajectory) -- or a candidate within
-    `height_tol` of the ground in the kernel's state, where its fp32 height can fall on either side.  The oracle's branch log is
+    `height_tol` of the ground in the kernel's state, where its fp32 height can fall on either side, or a touching candidate whose
+    two friction bounds (kf |vt| and -mu (fn + fd), integrator_euler.py:158-165) are within `coulomb_tol` newtons of each other, where the
+    kernel's fp32 comparison can pick the other branch of the min (kf = 100 N s/m: 1e-5 m/s of fp32 noise in a point velocity is 1e-3 N;
+    found by the round-3 stress sweep: seed 9001 case 3933, one env 0.27 off in its gradients with poses equal to 1e-7, |a - b| =
+    2e-4 N at step 4, float64 slides where the fp32 arithmetic sticks).  The oracle's branch log is
     evaluated in float64 on the oracle's trajectory and on the kernel's saved trajectory (oracle/ref_c.py branch_log).
     Envs WITHOUT such a step differentiate the same smooth function as the oracle."""
     nsteps = inp["nsteps"]
@@ -161,6 +165,7 @@ def first_branch_difference(rc64, st64, traj, inp, bs, height_tol=5e-7):
     st_g = {k: (rc64._c(v) if k.startswith("states") else v) for k, v in st_g.items()}
     probe = rc64.singularity_probe(st_g)
     diff |= probe[:, :, 0] < height_tol
+    diff |= probe[:, :, 2] < coulomb_tol
     first = np.where(diff.any(0), diff.argmax(0), nsteps)
     return first
 
