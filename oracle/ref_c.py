@@ -114,11 +114,11 @@ class RefC:
         return g
 
     def singularity_probe(self, st):
-        """[nsteps, bs, 4] for a trajectory returned by rollout_forward: min |contact height|, min distance of a pre-clamp
+        """[nsteps, bs, 5] for a trajectory returned by rollout_forward: min |contact height|, min distance of a pre-clamp
         velocity component from +-10, min |a - b| of the Coulomb switch over touching points, min 1 - |twist.w| over revolute
-        joints (see ref_singularity_probe in diffphys_ref.c)."""
+        joints, min distance of a contact force component from the +-500 N clamp (see ref_singularity_probe in diffphys_ref.c)."""
         a, bs, nsteps = st["_inputs"], st["_bs"], st["_nsteps"]
-        out = np.zeros((nsteps, bs, 4), dtype=self.dtype)
+        out = np.zeros((nsteps, bs, 5), dtype=self.dtype)
         self.lib.ref_singularity_probe(self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self.real(st["_dt"]), self._p(st["states_q"]),
                                        self._p(st["states_qd"]), self._p(st["states_f"]), self._p(a["body_inv_mass"]),
                                        self._p(a["body_inertia"]), self._p(a["body_inv_inertia"]), self._p(out))

@@ -832,7 +832,8 @@ static void integrate_adj(const RefTemplate *t, const real *body_q, const real *
  *   out[1]  min over bodies and components of | |x| - 10 | for the velocities BEFORE the clamp of :78-88 (w1 after damping, v1)
  *   out[2]  min over TOUCHING candidates of |kf |vt| - mu (fn + fd) ... | i.e. |a_ - b_| of the Coulomb switch (:160-165), newtons
  *   out[3]  min over revolute joints of 1 - |twist.w|: the acos / its guarded adjoint at joint angle 0 (:398-400)
- * layout out[(step * bs + env) * 4 + k].  tests/test_gpu_tight.py uses it to EXPLAIN every env whose fp32 gradient is off. */
+ *   out[4]  min over TOUCHING candidates and force components of | |f_k| - 500 |: the contact force clamp (:172-175), newtons
+ * layout out[(step * bs + env) * 5 + k].  tests/test_gpu_tight.py uses it to EXPLAIN every env whose fp32 gradient is off. */
 void ref_singularity_probe(const RefTemplate *t, int bs, int nsteps, real dt, const real *states_q, const real *states_qd,
                            const real *states_f, const real *inv_mass, const real *inertia, const real *inv_inertia, real *out) {
   const int nb = t->nb;
@@ -842,7 +843,7 @@ void ref_singularity_probe(const RefTemplate *t, int bs, int nsteps, real dt, co
     size_t oq = (size_t)e * nb * 7, od = (size_t)e * nb * 6;
     for (int s = 0; s < nsteps; ++s) {
       const real *bq = states_q + s * SQ + oq, *bqd = states_qd + s * SD + od, *bf = states_f + s * SD + od;
-      real c_min = (real)1e30, cl_min = (real)1e30, fr_min = (real)1e30, ac_min = (real)1e30;
+      real c_min = (real)1e30, cl_min = (real)1e30, fr_min = (real)1e30, ac_min = (real)1e30, fc_min = (real)1e30;
       for (int k = 0; k < t->nc; ++k) {
         int b = t->c_body[k];
         v3 p = ld3(bq + b * 7); qt q = ld4(bq + b * 7 + 3);
@@ -859,8 +860,19 @@ void ref_singularity_probe(const RefTemplate *t, int bs, int nsteps, real dt, co
         v3 vt = V(dpdt.x, 0, dpdt.z);
         real fn = c * mat[0], fd = (vn < (real)0 ? vn : (real)0) * mat[1] * (c < (real)0 ? (real)1 : (real)0);
         real d = mat[2] * vlen(vt) - ((real)0 - mat[3] * (fn + fd));
+        real a_ = mat[2] * vlen(vt), b_ = (real)0 - mat[3] * (fn + fd);
         if (d < 0) d = -d;
         if (d < fr_min) fr_min = d;
+        {
+          real lvt = vlen(vt), mm = a_ < b_ ? a_ : b_;
+          v3 nv = lvt > (real)0 ? vscale(vt, (real)1 / lvt) : V(0, 0, 0);
+          real comps[3] = {nv.x * mm, (fn + fd) + nv.y * mm, nv.z * mm};
+          for (int kk = 0; kk < 3; ++kk) {
+            real dd = (comps[kk] < 0 ? -comps[kk] : comps[kk]) - (real)500;
+            if (dd < 0) dd = -dd;
+            if (dd < fc_min) fc_min = dd;
+          }
+        }
       }
       for (int i = 0; i < nb; ++i) {
         v3 x0 = ld3(bq + i * 7); qt r0 = ld4(bq + i * 7 + 3);
@@ -893,8 +905,8 @@ void ref_singularity_probe(const RefTemplate *t, int bs, int nsteps, real dt, co
           if (d < ac_min) ac_min = d;
         }
       }
-      real *o = out + ((size_t)s * bs + e) * 4;
-      o[0] = c_min; o[1] = cl_min; o[2] = fr_min; o[3] = ac_min;
+      real *o = out + ((size_t)s * bs + e) * 5;
+      o[0] = c_min; o[1] = cl_min; o[2] = fr_min; o[3] = ac_min; o[4] = fc_min;
     }
   }
 }
