@@ -110,7 +110,7 @@ def source_hash():
     import hashlib
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "../../include/ppr_diffphys.h"]
+    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "../../include/ppr_diffphys.h", "Makefile"]
     h = hashlib.sha256()
     try:
         for f in srcs:
