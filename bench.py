@@ -45,6 +45,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_BYTES = 8.0e12        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_BYTES = 6.3e12  # same guide: what a streaming kernel reaches in practice
+VECTOR_PEAK_FLOPS = 157.3e12   # same guide: fp32 vector peak (packed v_pk_fma_f32: 256 CUs x 4 SIMDs x 16 lanes x 2 x 2 x 2.4 GHz)
 GLOBAL_BS = 4096               # BASELINE.json: "batch=4096"
 
 
@@ -114,6 +115,35 @@ def cpu_baseline(tpl, robot, nsteps, seqs, budget_s=12.0):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): N fresh child processes of this same file, one per GPU,
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would -- children, never an
+    exec, and started before this process makes any GPU call (it never makes one).  Rank 0's stdout (the one JSON line) is
+    forwarded; the return code is non-zero if any rank failed.  SURVEY.md section 8(e): batch split only."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:  # a free rendezvous port on the loopback
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PPR_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, rc): %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,28 +161,41 @@ def main():
     ap.add_argument("--both", action="store_true", help="also measure the other scaling mode at N = 1 (always done for N > 1)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # typed as `python bench.py --gpus N`: start the N ranks ourselves, BEFORE anything in this process touches the GPU
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-        args.gpus = world
+        args.gpus = world  # a launcher's WORLD_SIZE is authoritative
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not os.environ.get("PPR_BENCH_SHARE_GPU"):
+            raise SystemExit("bench.py: rank %d has no GPU of its own (%d visible); one process per GPU" % (rank, ndev))
+        local_rank %= ndev  # test hook (tests/test_gpu_bench.py): the N-rank code path on a 1-GPU box, ranks sharing the device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
     red_dev = dev
+    backend, ranks_seen = None, 1
     if world > 1:
+        backend = "nccl"
         try:  # RCCL (backend "nccl" on ROCm); only the barrier and the MAX of the elapsed time go through it
             dist.init_process_group(backend="nccl", device_id=dev)
-        except Exception as e:  # keep the measurement alive if RCCL cannot come up on this node: same semantics over gloo
+        except Exception as e:  # keep the measurement alive if RCCL cannot come up on this node: same semantics over gloo,
+            #                     and the line SAYS so ("collective_backend": "gloo")
             if rank == 0:
                 print("bench.py: nccl/RCCL init failed (%s); using gloo for the barrier" % e, file=sys.stderr)
             dist.init_process_group(backend="gloo")
             red_dev = torch.device("cpu")
+            backend = "gloo"
+        one = torch.ones(1, dtype=torch.float64, device=red_dev)  # how many ranks the collective really spans
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
 
     from diffphys_amd import hip_backend, robots, synth
 
@@ -332,7 +375,13 @@ def main():
             if not n:
                 return None
             peak = cus * 4.0 * 2.4e9 / 4.2
+            # the data-sheet number beside the self-measured ceiling: 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md; v_pk_fma_f32
+            # only: 2 FMAs per lane and issue).  Upper bound of what this kernel does against it: EVERY vector instruction counted as
+            # one FMA per lane (2 flop x 64 lanes)
             return {"unit": "wave64 fp32 instructions/s", "achieved": n / (ms * 1e-3), "peak": peak, "frac": n / (ms * 1e-3) / peak,
+                    "peak_source": "self-measured: scripts/micro/valu_chain.hip, pk_issue.hip (one non-packed wave64 instruction per ~4.2 cycles and SIMD)",
+                    "frac_of_vector_peak": n * 128.0 / (ms * 1e-3) / VECTOR_PEAK_FLOPS, "vector_peak_tflops": VECTOR_PEAK_FLOPS / 1e12,
+                    "frac_of_vector_peak_note": "instructions x 64 lanes x 2 flop (every instruction priced as an FMA: an upper bound) / 157.3 TFLOP/s",
                     "insts_per_launch": n, "cycles_per_instruction": 4.2, "clock_ghz_assumed": 2.4}
 
         line = {
@@ -340,6 +389,9 @@ def main():
             "value": gbs * T * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
+            "collective_backend": backend,   # "nccl" (= RCCL) | "gloo" (RCCL could not come up) | null at N = 1: barrier + MAX only
+            "ranks_seen": ranks_seen,        # all-reduced count of ranks behind that backend
+            "launcher": "self" if os.environ.get("PPR_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "none"),
             "steps": args.steps,
             "warmup": args.warmup,
             "warmup_extra_steps": warm_extra,
@@ -363,7 +415,10 @@ def main():
                 "nan_grads": bad,
             },
             "roofline": {
-                "bound": "hbm",
+                # what binds is fp32 VALU issue (roofline.valu); achieved / peak / unit / frac below stay the HBM figures the contract
+                # defines (algorithmic bytes / launch duration against 8 TB/s), repeated as hbm_frac
+                "bound": "valu-issue",
+                "hbm_frac": ach_bwd / HBM_PEAK_BYTES,
                 "limiter": "fp32 VALU issue: a SIMD issues one non-packed wave64 fp32 instruction per ~4.2 cycles whatever the waves or "
                            "their ILP; the adjoint's two waves per SIMD keep it ~95 % busy (roofline.valu; the forward pass ~53 %: hand-over "
                            "latency).  frac of HBM is what the contract asks for",

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 4   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id */
+#define PD_ABI_VERSION 5   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log) */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -84,6 +84,13 @@ int pd_model_get_segment_width(const pd_model *m);
  * by the forward sweep's contact hit log (32 ints per env-step) that the adjoint replays.  The base must be 16-byte
  * aligned. */
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps);
+
+/* Inspection of the saved trajectory (tests, diagnostics): the hit log behind the planes holds, per (step, env), 32 ints --
+ * [0] the number n of contact candidates that touched in that step (eval_body_contacts' `c <= 0`, integrator_euler.py:130-133;
+ * -1 when more than 31 did: the adjoint then sweeps again), [1..n] packed entries  point | material << 16 | body << 24  with
+ * `point` an index into the DEVICE contact table (candidates grouped by body, spatially ordered inside a body).
+ * order_host[i] (HOST, capacity >= nc ints) receives the index into the template's contact_* arrays of device entry i. */
+int pd_model_contact_order(const pd_model *m, int *order_host, int capacity);
 
 /* Per-env joint_X_p (the lab4d path rebinds env.joint_X_p from a torch tensor before every rollout,
  * diffphys/dp_interface.py:465): joint_X_p_dev is [n_envs][nb][7] DEVICE memory owned by the caller and read by every

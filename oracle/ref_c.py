@@ -60,6 +60,11 @@ class RefC:
         Appendix A.1 recalls Warp.  Process-wide switch of this precision's library: reset it after use."""
         self.lib.ref_set_acos_policy(1 if unguarded else 0)
 
+    def set_twist_eval(self, use_atan2):
+        """True: the revolute twist angle through atan2 (the same function as the literal 2 acos(twist.w) sign(..), see
+        ref_set_twist_eval in diffphys_ref.c).  Process-wide switch of this precision's library: reset it after use."""
+        self.lib.ref_set_twist_eval(1 if use_atan2 else 0)
+
     def set_state_rounding(self, on):
         """1 / True: rollout_forward rounds every stored state to fp32; 2: to an adjacent fp32 number (ref_set_state_rounding in diffphys_ref.c).  Process-wide switch
         of this precision's library: reset it after use."""
@@ -112,6 +117,53 @@ class RefC:
             self._p(g["torques"]), self._p(g["res_f"]), self._p(g["refs"]), self._p(g["target_ke"]), self._p(g["target_kd"]),
             self._p(g["body_inv_mass"]), self._p(g["body_inertia"]), self._p(g["body_inv_inertia"]))
         return g
+
+    def trajectory_state(self, traj, inp):
+        """Wraps a trajectory ANOTHER implementation saved (dict with states_q [T, bs*nb, 7], states_qd [T, bs*nb, 6], states_f
+        [T, bs*nb, 6]: the HIP kernels' DeviceModel.saved_trajectory) into what rollout_backward* / singularity_probe take: the
+        stored values cast to this precision, the inputs of `inp`.  The reverse sweep never reads state T."""
+        a = {k: self._c(inp[k]) for k in ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd",
+                                          "body_inv_mass", "body_inertia", "body_inv_inertia")}
+        nsteps = int(np.asarray(traj["states_f"]).shape[0])
+        st = dict(states_q=self._c(traj["states_q"]), states_qd=self._c(traj["states_qd"]), states_f=self._c(traj["states_f"]))
+        assert st["states_q"].shape[0] >= nsteps
+        st.update(_inputs=a, _f2s=np.ascontiguousarray(inp["frame2step"], dtype=np.int32), _bs=a["q_init"].size // self.nq,
+                  _nsteps=nsteps, _dt=inp["dt"])
+        return st
+
+    def rollout_backward_forced(self, st, adj_pos, adj_vel, clamp_mask=None, pinned_touch=False, touch_list=None):
+        """rollout_backward with the discrete decisions of the implementation that saved `st` (see ref_rollout_backward_forced in
+        diffphys_ref.c): clamp_mask int [T, bs*nb] = its stored velocity-clamp masks, pinned_touch = contacts touch where its pinned
+        fp32 height test says so; touch_list int [T, bs, cap] (what touch_fp32 returned for the UNPERTURBED states) names the touching
+        candidates outright.  None given: identical to rollout_backward."""
+        a, bs, nsteps = st["_inputs"], st["_bs"], st["_nsteps"]
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        z = lambda *s: np.zeros(s, dtype=self.dtype)
+        g = dict(q_init=z(bs * nq), qd_init=z(bs * nqd), torques=z(nsteps, bs * nqd), res_f=z(nsteps, bs * nb, 6),
+                 refs=z(nsteps, bs * nqd), target_ke=z(bs * nqd), target_kd=z(bs * nqd), body_mass=z(bs * nb),
+                 body_inv_mass=z(bs * nb), body_inertia=z(bs * nb, 3, 3), body_inv_inertia=z(bs * nb, 3, 3))
+        ap, av = self._c(adj_pos), self._c(adj_vel)
+        tl = None if touch_list is None else np.ascontiguousarray(touch_list, dtype=np.int32)
+        mk = None if clamp_mask is None else np.ascontiguousarray(np.asarray(clamp_mask).reshape(nsteps, bs * nb) & 63, dtype=np.int32)
+        self.lib.ref_rollout_backward_forced(
+            self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self.real(st["_dt"]), self._p(a["q_init"]), self._p(a["qd_init"]),
+            self._p(a["torques"]), self._p(a["refs"]), self._p(a["target_ke"]), self._p(a["target_kd"]),
+            self._p(a["body_inv_mass"]), self._p(a["body_inertia"]), self._p(a["body_inv_inertia"]),
+            ctypes.c_int(len(st["_f2s"])), self._p(st["_f2s"]), self._p(st["states_q"]), self._p(st["states_qd"]),
+            self._p(st["states_f"]), self._p(ap), self._p(av), self._p(g["q_init"]), self._p(g["qd_init"]),
+            self._p(g["torques"]), self._p(g["res_f"]), self._p(g["refs"]), self._p(g["target_ke"]), self._p(g["target_kd"]),
+            self._p(g["body_inv_mass"]), self._p(g["body_inertia"]), self._p(g["body_inv_inertia"]),
+            self._p(mk) if mk is not None else ctypes.c_void_p(0), ctypes.c_int(1 if pinned_touch else 0),
+            self._p(tl) if tl is not None else ctypes.c_void_p(0), ctypes.c_int(tl.shape[-1] if tl is not None else 0))
+        return g
+
+    def touch_fp32(self, st, cap=32):
+        """int32 [T, bs, cap]: per env-step the count and the template indices (ascending) of the contact candidates that touch by
+        the kernels' pinned fp32 height test on the stored state (ref_touch_fp32)."""
+        bs, nsteps = st["_bs"], st["_nsteps"]
+        out = np.zeros((nsteps, bs, cap), dtype=np.int32)
+        self.lib.ref_touch_fp32(self.h, ctypes.c_int(bs), ctypes.c_int(nsteps), self._p(st["states_q"]), self._p(out), ctypes.c_int(cap))
+        return out
 
     def singularity_probe(self, st):
         """[nsteps, bs, 5] for a trajectory returned by rollout_forward: min |contact height|, min distance of a pre-clamp

@@ -115,6 +115,19 @@ static inline qt q_axis_angle(v3 axis, real ang) {
  * gradients (scrubbed to 0 by remove_nan at the boundary) for an env whose joint passes through angle 0 in fp32. */
 static int g_acos_unguarded = 0;
 void ref_set_acos_policy(int unguarded) { g_acos_unguarded = unguarded; }
+/* Evaluation of the revolute twist angle (integrator_euler.py:394-400).  0 (default): literally -- normalize, q = 2 acos(twist.w) sign(..),
+ * adjoint through acos' and the normalisation.  1: the SAME function as q = 2 sign(d) atan2(|axis| |d|, r.w), d = r.xyz . axis, with its
+ * partials 2 |axis| r.w / (r.w^2 + y^2) and -2 |axis| d / (..): no cancellation near angle 0 (one ulp of twist.w is 7e-4 rad there).
+ * In float64 the two agree to rounding; in fp32 the second is what the HIP kernels evaluate (pd_math.h twist_angle), so the fp32
+ * build with this switch on is the like-for-like "plain fp32 evaluation" the tests measure the kernels' arithmetic against. */
+static int g_twist_atan2 = 0;
+void ref_set_twist_eval(int use_atan2) { g_twist_atan2 = use_atan2; }
+static inline real twist_angle_atan2(v3 axis, real da, real w, real *dq_dda, real *dq_dw) {
+  const real L = vlen(axis), y = L * (da < (real)0 ? -da : da), den = w * w + y * y;
+  const real sgn = da < (real)0 ? (real)-1 : (real)1;
+  if (dq_dda) { *dq_dda = den > (real)0 ? (real)2 * L * w / den : (real)0; *dq_dw = den > (real)0 ? -(real)2 * L * da / den : (real)0; }
+  return (real)2 * sgn * R_ATAN2(y, w);
+}
 /* Conditioning probe (tests): with this on, ref_rollout_forward rounds every state it stores to fp32 (value kept in `real`).  In
  * the float64 build that is the LEAST any fp32 implementation does to a rollout -- one rounding per state component and step,
  * exact arithmetic otherwise -- so how far the gradients of an env move under it measures how ill-conditioned the env is.
@@ -400,9 +413,33 @@ static void contacts_fwd(const RefTemplate *t, const real *body_q, const real *b
   }
 }
 
+/* The touch decision of the HIP kernels, bit for bit (ref_rollout_backward_forced, ref_touch_fp32): they evaluate the height of
+ * integrator_euler.py:118-121 in fp32 with PINNED roundings -- row 1 of the rotation matrix of q and the dot product as explicit
+ * fused multiply-adds, nothing else contracted (ppr-diffphys_amd/csrc/pd_math.h rot_row1 / contact_height) -- so that their forward
+ * and adjoint kernels, and this restatement, get the same bits from the same stored (q, p_y) and candidate.  This file is built
+ * with -ffp-contract=off; fmaf is the correctly rounded fused operation. */
+static int touch_pinned_fp32(const RefTemplate *t, int k, const real *body_q) {
+  const int b = t->c_body[k];
+  const float py = (float)body_q[b * 7 + 1];
+  const float qx = (float)body_q[b * 7 + 3], qy = (float)body_q[b * 7 + 4], qz = (float)body_q[b * 7 + 5], qw = (float)body_q[b * 7 + 6];
+  const float s = fmaf(2.0f * qw, qw, -1.0f), tx = 2.0f * qx, ty = 2.0f * qy, tz = 2.0f * qz;
+  const float wz = tz * qw, wx = tx * qw;
+  const float r0 = fmaf(tx, qy, wz), r1 = fmaf(ty, qy, s), r2 = fmaf(ty, qz, -wx);
+  const float Px = (float)t->c_point[k * 3], Py = (float)t->c_point[k * 3 + 1], Pz = (float)t->c_point[k * 3 + 2];
+  const float h = fmaf(r2, Pz, fmaf(r1, Py, fmaf(r0, Px, py))) - (float)t->c_dist[k];
+  return !(h > 0.0f);
+}
+
+/* pinned != 0 (ref_rollout_backward_forced): `touching` is the decision of the fp32 implementation whose trajectory is being
+ * differentiated (touch_pinned_fp32 on its stored state), whatever side of 0 this precision's height lands on.
+ * list != NULL && list[0] >= 0: exactly the candidates list[1 .. list[0]] touch (a decision taken elsewhere, e.g. by ref_touch_fp32
+ * on the unperturbed states when the states passed here carry a deliberate perturbation). */
 static void contacts_adj(const RefTemplate *t, const real *body_q, const real *body_qd, const real *adj_body_f,
-                         real *adj_body_q, real *adj_body_qd) {
-  for (int k = 0; k < t->nc; ++k) {
+                         real *adj_body_q, real *adj_body_qd, int pinned, const int *list) {
+  const int use_list = list != NULL && list[0] >= 0;
+  const int n_it = use_list ? list[0] : t->nc;
+  for (int it = 0; it < n_it; ++it) {
+    const int k = use_list ? list[1 + it] : it;
     int b = t->c_body[k];
     v3 p = ld3(body_q + b * 7); qt q = ld4(body_q + b * 7 + 3);
     v3 w = ld3(body_qd + b * 6), v = ld3(body_qd + b * 6 + 3);
@@ -412,7 +449,7 @@ static void contacts_adj(const RefTemplate *t, const real *body_q, const real *b
     v3 r = vsub(cp, vadd(p, qrot(q, com)));
     v3 dpdt = vadd(v, vcross(w, r));
     real c = vdot(n, cp);
-    if (c > (real)0) continue;
+    if (!use_list && (pinned ? !touch_pinned_fp32(t, k, body_q) : c > (real)0)) continue;
     const real *mat = t->materials + t->c_mat[k] * 4;
     real ke = mat[0], kd = mat[1], kf = mat[2], mu = mat[3];
     real vn = vdot(n, dpdt);
@@ -542,6 +579,7 @@ static void joints_fwd(const RefTemplate *t, const real *body_q, const real *bod
       qt twist = qnormalize(Q(a.x, a.y, a.z, c.r_err.w));
       real sgn = vdot(axis, qv(twist)) < (real)0 ? (real)-1 : (real)1;
       real q = acos_c(twist.w) * (real)2 * sgn;
+      if (g_twist_atan2) q = twist_angle_atan2(axis, vdot(qv(c.r_err), axis), c.r_err.w, NULL, NULL);
       real qd = vdot(c.w_err, axis_p);
       real jf = joint_force(q, qd, target[qds], tke[qds], tkd[qds], act[qds], t->limit_lower[qds], t->limit_upper[qds],
                             t->limit_ke[qds], t->limit_kd[qds]);
@@ -628,6 +666,8 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
       qt twist = qnormalize(tq);
       real sgn = vdot(axis, qv(twist)) < (real)0 ? (real)-1 : (real)1;
       real q = acos_c(twist.w) * (real)2 * sgn;
+      real dq_dda = 0, dq_dw = 0;
+      if (g_twist_atan2) q = twist_angle_atan2(axis, da, c.r_err.w, &dq_dda, &dq_dw);
       real qd = vdot(c.w_err, axis_p);
       real jf = joint_force(q, qd, target[qds], tke[qds], tkd[qds], act[qds], t->limit_lower[qds], t->limit_upper[qds],
                             t->limit_ke[qds], t->limit_kd[qds]);
@@ -650,6 +690,7 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
       qt adj_tq = Q(0, 0, 0, 0);
       adj_qnormalize(tq, &adj_tq, adj_twist);
       real adj_da = vdot(qv(adj_tq), axis);
+      if (g_twist_atan2) { adj_da = adj_q * dq_dda; adj_tq.w = adj_q * dq_dw; }
       adj_r_err.x += axis.x * adj_da; adj_r_err.y += axis.y * adj_da; adj_r_err.z += axis.z * adj_da;
       adj_r_err.w += adj_tq.w;
       adj_qrot(c.q_p, axis, &adj_q_p, NULL, adj_axis_p);
@@ -763,7 +804,10 @@ static void integrate_fwd(const RefTemplate *t, const real *body_q, const real *
 
 static void integrate_adj(const RefTemplate *t, const real *body_q, const real *body_qd, const real *body_f, const real *inv_m,
                           const real *I, const real *inv_I, real dt, const real *adj_q_new, const real *adj_qd_new,
-                          real *adj_body_q, real *adj_body_qd, real *adj_body_f, real *adj_inv_m, real *adj_I, real *adj_inv_I) {
+                          real *adj_body_q, real *adj_body_qd, real *adj_body_f, real *adj_inv_m, real *adj_I, real *adj_inv_I,
+                          const int *forced_mask) {
+  /* forced_mask != NULL (ref_rollout_backward_forced): per body the 6-bit mask (w.x w.y w.z v.x v.y v.z) of the components the
+   * forward pass being differentiated clamped (:78-88) -- its decision, not this precision's recomputation */
   for (int i = 0; i < t->nb; ++i) {
     v3 x0 = ld3(body_q + i * 7); qt r0 = ld4(body_q + i * 7 + 3);
     v3 w0 = ld3(body_qd + i * 6), v0 = ld3(body_qd + i * 6 + 3);
@@ -788,7 +832,13 @@ static void integrate_adj(const RefTemplate *t, const real *body_q, const real *
     v3 adj_x1 = g_p; qt adj_r1 = g_r;
     adj_qrot(r1, com, &adj_r1, NULL, vneg(g_p));
     v3 adj_v1 = clamp3_pass(v1, g_v, 10);
-    v3 adj_w1 = vscale(clamp3_pass(w1d, g_w, 10), (real)1 - (real)0.1 * dt);
+    v3 adj_w1 = clamp3_pass(w1d, g_w, 10);
+    if (forced_mask) {
+      const int mk = forced_mask[i];
+      adj_w1 = V(mk & 1 ? (real)0 : g_w.x, mk & 2 ? (real)0 : g_w.y, mk & 4 ? (real)0 : g_w.z);
+      adj_v1 = V(mk & 8 ? (real)0 : g_v.x, mk & 16 ? (real)0 : g_v.y, mk & 32 ? (real)0 : g_v.z);
+    }
+    adj_w1 = vscale(adj_w1, (real)1 - (real)0.1 * dt);
     qt adj_rq = Q(0, 0, 0, 0);
     adj_qnormalize(rq, &adj_rq, adj_r1);
     qt adj_r0 = adj_rq; qt adj_W = Q(0, 0, 0, 0);
@@ -1013,13 +1063,23 @@ void ref_rollout_forward(const RefTemplate *t, int bs, int nsteps, real dt, cons
 
 /* Reverse sweep.  All grad outputs must be zero-initialised by the caller; they are accumulated.
  * grad shapes mirror the inputs; g_mass is left untouched (body_mass is loaded but unused, integrator_euler.py:43). */
-void ref_rollout_backward(const RefTemplate *t, int bs, int nsteps, real dt, const real *q_init, const real *qd_init,
+/* Forced variant (test diagnostics): the reverse sweep over a trajectory ANOTHER implementation saved (the HIP kernels' fp32
+ * states and total wrenches, cast to this precision), taking the discrete decisions that implementation recorded instead of
+ * re-deciding them here on rounded states:
+ *   clamp_mask [nsteps][bs*nb]  6-bit velocity-clamp masks of each step's integration (integrator_euler.py:78-88) as that
+ *                               implementation stored them, or NULL (re-decide here)
+ *   pinned_touch != 0           "this candidate touches" (c <= 0, :130-133) is decided by touch_pinned_fp32 on the stored state
+ *   touch_list [nsteps][bs][touch_cap]  or NULL: per env-step [0] = n, then the n candidates that touch (what ref_touch_fp32
+ *                               returns); takes precedence where n < touch_cap, i.e. where the list is complete
+ * What these leave undecided (the Coulomb min of :160-165, the +-500 N force clamp of :172-175) is re-decided here in this
+ * precision; ref_singularity_probe reports how close to those switches a step sits.  With NULL / 0 this IS ref_rollout_backward. */
+static void rollout_backward_impl(const RefTemplate *t, int bs, int nsteps, real dt, const real *q_init, const real *qd_init,
                           const real *torques, const real *refs, const real *target_ke, const real *target_kd,
                           const real *inv_mass, const real *inertia, const real *inv_inertia, int nframes,
                           const int *frame2step, const real *states_q, const real *states_qd, const real *states_f,
                           const real *adj_pos, const real *adj_vel, real *g_q_init, real *g_qd_init, real *g_torques,
                           real *g_res_f, real *g_refs, real *g_ke, real *g_kd, real *g_inv_mass, real *g_inertia,
-                          real *g_inv_inertia) {
+                          real *g_inv_inertia, const int *clamp_mask, int pinned_touch, const int *touch_list, int touch_cap) {
   const int nb = t->nb, nq = t->nq, nqd = t->nqd;
   const size_t SQ = (size_t)bs * nb * 7, SD = (size_t)bs * nb * 6;
 #pragma omp parallel for schedule(static)
@@ -1043,11 +1103,11 @@ void ref_rollout_backward(const RefTemplate *t, int bs, int nsteps, real dt, con
       memset(aq, 0, sizeof(real) * nb * 7); memset(aqd, 0, sizeof(real) * nb * 6); memset(af, 0, sizeof(real) * nb * 6);
       integrate_adj(t, bq, bqd, bf, inv_mass + (size_t)e * nb, inertia + (size_t)e * nb * 9, inv_inertia + (size_t)e * nb * 9,
                     dt, aq_next, aqd_next, aq, aqd, af, g_inv_mass + (size_t)e * nb, g_inertia + (size_t)e * nb * 9,
-                    g_inv_inertia + (size_t)e * nb * 9);
+                    g_inv_inertia + (size_t)e * nb * 9, clamp_mask ? clamp_mask + ((size_t)st * bs + e) * nb : NULL);
       size_t oc = (size_t)st * bs * nqd + (size_t)e * nqd;
       joints_adj(t, bq, bqd, refs + oc, torques + oc, target_ke + (size_t)e * nqd, target_kd + (size_t)e * nqd, af, aq, aqd,
                  g_refs + oc, g_torques + oc, g_ke + (size_t)e * nqd, g_kd + (size_t)e * nqd);
-      contacts_adj(t, bq, bqd, af, aq, aqd);
+      contacts_adj(t, bq, bqd, af, aq, aqd, pinned_touch, (touch_list && touch_list[((size_t)st * bs + e) * touch_cap] < touch_cap) ? touch_list + ((size_t)st * bs + e) * touch_cap : NULL);
       for (int k = 0; k < nb * 6; ++k) g_res_f[st * SD + od + k] += af[k]; /* adjoint of wp_add */
       real *tmp;
       tmp = aq_next; aq_next = aq; aq = tmp;
@@ -1057,6 +1117,45 @@ void ref_rollout_backward(const RefTemplate *t, int bs, int nsteps, real dt, con
                g_q_init + (size_t)e * nq, g_qd_init + (size_t)e * nqd);
     free(aq_next); free(aqd_next); free(aq); free(aqd); free(af);
   }
+}
+
+void ref_rollout_backward(const RefTemplate *t, int bs, int nsteps, real dt, const real *q_init, const real *qd_init,
+                          const real *torques, const real *refs, const real *target_ke, const real *target_kd,
+                          const real *inv_mass, const real *inertia, const real *inv_inertia, int nframes,
+                          const int *frame2step, const real *states_q, const real *states_qd, const real *states_f,
+                          const real *adj_pos, const real *adj_vel, real *g_q_init, real *g_qd_init, real *g_torques,
+                          real *g_res_f, real *g_refs, real *g_ke, real *g_kd, real *g_inv_mass, real *g_inertia,
+                          real *g_inv_inertia) {
+  rollout_backward_impl(t, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
+                        frame2step, states_q, states_qd, states_f, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs,
+                        g_ke, g_kd, g_inv_mass, g_inertia, g_inv_inertia, NULL, 0, NULL, 0);
+}
+void ref_rollout_backward_forced(const RefTemplate *t, int bs, int nsteps, real dt, const real *q_init, const real *qd_init,
+                          const real *torques, const real *refs, const real *target_ke, const real *target_kd,
+                          const real *inv_mass, const real *inertia, const real *inv_inertia, int nframes,
+                          const int *frame2step, const real *states_q, const real *states_qd, const real *states_f,
+                          const real *adj_pos, const real *adj_vel, real *g_q_init, real *g_qd_init, real *g_torques,
+                          real *g_res_f, real *g_refs, real *g_ke, real *g_kd, real *g_inv_mass, real *g_inertia,
+                          real *g_inv_inertia, const int *clamp_mask, int pinned_touch, const int *touch_list, int touch_cap) {
+  rollout_backward_impl(t, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
+                        frame2step, states_q, states_qd, states_f, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs,
+                        g_ke, g_kd, g_inv_mass, g_inertia, g_inv_inertia, clamp_mask, pinned_touch, touch_list, touch_cap);
+}
+
+/* Per (step, env): the template indices of the candidates touch_pinned_fp32 says touch, ascending; out [nsteps][bs][cap]
+ * ([0] = count, then up to cap - 1 indices, -1 padded).  tests cross-check it against the hit log the kernels wrote. */
+void ref_touch_fp32(const RefTemplate *t, int bs, int nsteps, const real *states_q, int *out, int cap) {
+  const int nb = t->nb;
+  const size_t SQ = (size_t)bs * nb * 7;
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < bs; ++e)
+    for (int s = 0; s < nsteps; ++s) {
+      int *o = out + ((size_t)s * bs + e) * cap, n = 0;
+      for (int k = 1; k < cap; ++k) o[k] = -1;
+      for (int k = 0; k < t->nc; ++k)
+        if (touch_pinned_fp32(t, k, states_q + s * SQ + (size_t)e * nb * 7)) { if (1 + n < cap) o[1 + n] = k; ++n; }
+      o[0] = n;
+    }
 }
 
 /* Batched FK for ForwardKinematics (dp_model.py:1022-1130): n independent articulations. */

@@ -71,8 +71,10 @@ struct RolloutArgs {
   float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
   int *hitlog;              // workspace tail: per (step, env) the compacted contact hit list of the forward sweep
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
-  int own_joint;            // adjoint, 2-role kernel: the body wave recomputes its joint's state-only half itself (shared SIMD)
-  int variant;              // A/B experiments (pd_debug_set_variant, not in the public header): which adjoint kernel a revolute robot runs
+#ifdef PD_EXPERIMENT        // timing builds only (make experiment): rejected variants, DESIGN.md section 4 / EXPERIMENTS.md
+  int own_joint;            // adjoint, 2-role kernel: the body wave recomputes its joint's state-only half itself (measured: slower)
+  int variant;              // pd_debug_set_variant: which adjoint kernel a revolute robot runs
+#endif
 };
 
 

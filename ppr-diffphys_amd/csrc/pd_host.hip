@@ -22,6 +22,7 @@ struct pd_model {
   float gravity[3] = {0, 0, 0}, attach_ke = 0, attach_kd = 0;
   // derived
   int segw = 0, jt = 0;
+  std::vector<int> contact_order;  // device contact-table entry -> template candidate (pd_model_contact_order)
   void *blob = nullptr;
   PdDevModel dev{};
   size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;  // at PD_BWAVES env groups per workgroup (the maximum)
@@ -156,6 +157,7 @@ static int build_device(pd_model *m, int segw) {
   std::vector<int> tile_pack;
   std::vector<int2> body_tiles(nb, make_int2(0, 0));
   std::vector<float4> body_sphere(nb, make_float4(0, 0, 0, -1.0f));
+  std::vector<int> order;
   for (int b = 0; b < nb; ++b) {
     std::vector<int> ids;
     for (int k = 0; k < m->nc; ++k) if (m->cbody[k] == b) ids.push_back(k);
@@ -175,6 +177,7 @@ static int build_device(pd_model *m, int segw) {
         int mi = m->cmat[k];
         if (mi < 0 || mi >= m->nmat) return fail("contact_material out of range");
         pt_mat.push_back((unsigned char)mi);
+        order.push_back(k);
       }
     }
   }
@@ -281,13 +284,15 @@ static int build_device(pd_model *m, int segw) {
   free_device(m);
   m->blob = blob; m->dev = d;
   m->lds_rollout = lds_rollout; m->lds_rollout_bwd = lds_rollout_bwd; m->lds_fk = lds_fk; m->lds_tables = lds_tables;
-  m->segw = segw; m->jt = jt;
+  m->segw = segw; m->jt = jt; m->contact_order = order;
   return 0;
 }
 
-static int g_variant = 0;  // -DPD_EXPERIMENT builds only (pd_debug_set_variant)
+static int g_variant = 0;  // -DPD_EXPERIMENT builds only (pd_debug_set_variant); the shipped launch_cfg always sees 0
 static int g_groups = 0;   // -DPD_EXPERIMENT / -DPD_STAMPS builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
-static int g_own_joint = -1;  // -DPD_EXPERIMENT builds only (pd_debug_set_own_joint): -1 = automatic
+#ifdef PD_EXPERIMENT
+static int g_own_joint = -1;  // pd_debug_set_own_joint
+#endif
 
 // Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
 static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
@@ -432,6 +437,13 @@ int pd_model_bind_joint_X_p(pd_model *m, const float *joint_X_p_dev, int n_envs)
   return 0;
 }
 
+int pd_model_contact_order(const pd_model *m, int *order_host, int capacity) {
+  if (!m || !order_host) return fail("null argument");
+  if (capacity < (int)m->contact_order.size()) return fail("contact order needs room for " + std::to_string(m->contact_order.size()) + " ints");
+  std::copy(m->contact_order.begin(), m->contact_order.end(), order_host);
+  return 0;
+}
+
 size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
   return m ? (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb + (size_t)nsteps * (size_t)bs * PD_HITLOG : 0;  // + hit log (ints)
 }
@@ -488,13 +500,10 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   a.frame_of_step = fos; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
+#ifdef PD_EXPERIMENT
   a.variant = g_variant;
-  {  // a workgroup's waves are dealt to the 4 SIMDs cyclically: with PD_BWAVES env groups per workgroup a body wave and its
-     // contact wave share a SIMD; the contact wave is then the later one at both hand-overs and hands rev_forward back (k_rollout_bwd)
-    const PdLaunchCfg c = launch_cfg(m, PD_K_ROLLOUT_BWD, bs);
-    a.own_joint = g_own_joint >= 0 ? g_own_joint : 0;  // measured: no gain; kept as an experiment switch
-    (void)c;
-  }
+  a.own_joint = g_own_joint > 0 ? 1 : 0;  // rev_forward on the body wave: measured slower, experiment switch only
+#endif
   a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);

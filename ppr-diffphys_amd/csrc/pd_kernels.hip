@@ -944,6 +944,14 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   const bool is_body = env_ok && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
+  // own_joint (rejected, -DPD_EXPERIMENT timing builds only): the body wave recomputes the state-only half of its joint's adjoint
+  // (rev_forward) itself instead of taking it from the contact wave -- measured slower at every batch size; a constant false in
+  // the shipped library, so none of its branches exist there
+#ifdef PD_EXPERIMENT
+  const bool own_joint = a.own_joint != 0;
+#else
+  constexpr bool own_joint = false;
+#endif
 
   SweepTables tabs;
   const int env_stride = m.env_lds_floats + (SPLIT ? 2 * m.env_lds_jc : 0);
@@ -989,11 +997,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     //           summed per body in hit order by a lane-per-component pass
     // A log that did not fit (count -1) or holds more hits than the segment has lanes takes the generic sweep.
     STAMP_DECL;
-    // a.own_joint (the host sets it when this wave shares its SIMD with the body wave, i.e. PD_BWAVES env groups per workgroup):
-    // the body wave recomputes the state-only half of its joint's adjoint itself, from the records it has staged anyway -- at
-    // 4096 envs THIS wave is the later one at both hand-overs (stamps: 6 900 of 7 200 cycles busy per step while the body wave
-    // waits 2 600), so rev_forward, its five pose loads and two control loads per step move over there
-    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE && !a.own_joint;
+    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE && !own_joint;
     const size_t qd_off = (size_t)ec * m.nqd + c.qdstart;
     const float ke1 = rev ? a.target_ke[qd_off] : 0.f, kd1 = rev ? a.target_kd[qd_off] : 0.f;
     const int lq = l < PD_HITLOG - 1 ? l : PD_HITLOG - 2;
@@ -1053,7 +1057,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       const int nh = fast && env_ok ? cnt_c : 0;
       STAMP(7);
       // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
-      if (!a.own_joint) pair_signal(sig + 1, a.nsteps - step);
+      if (!own_joint) pair_signal(sig + 1, a.nsteps - step);
       pair_wait(sig, a.nsteps - step);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for these contact adjoints
       STAMP(9);
@@ -1205,7 +1209,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
     }
     if (SPLIT) {
-      if (!a.own_joint) pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
+      if (!own_joint) pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
     } else {
       WAVE_SYNC();
     }
@@ -1221,7 +1225,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       if (SPLIT)  // revolute only: the state-only half comes from the contact wave, or (own_joint) is recomputed here
       {
         RevCache R;
-        if (a.own_joint) {  // wave-uniform
+        if (own_joint) {  // wave-uniform (experiment builds only)
           WAVE_SYNC();      // the parent's record was staged by another lane of this wave
           const float *pr = rec + (pd_parented(JT) || c.parent >= 0 ? c.parent : b) * PD_REC;
           R = rev_forward<pd_parented(JT)>(m, c, s.r, s.w, ld3(pr), ld4(pr + 3), ld3(pr + 7), tgt[0], act[0], ke[0], kd[0]);

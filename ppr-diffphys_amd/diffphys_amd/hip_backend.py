@@ -14,7 +14,7 @@ import torch
 _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
-ABI_VERSION = 4  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+ABI_VERSION = 5  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -57,6 +57,8 @@ def lib():
         L.pd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.pd_model_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.pd_last_launch_info.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int * 4)]
+        if hasattr(L, "pd_model_contact_order"):  # (absent from older A/B builds loaded through PPR_DIFFPHYS_LIB)
+            L.pd_model_contact_order.argtypes = [ctypes.c_void_p, _ip, ctypes.c_int]
         L.pd_model_bind_joint_X_p.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.pd_rollout_forward.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, _ip] + [vp] * 5 + [vp]
@@ -68,7 +70,7 @@ def lib():
         L.pd_pose_op_vjp.argtypes = [ci, ci, vp, ci, vp, vp, vp, vp, vp]
         L.pd_foot_height.argtypes = [ci, ci, ci] + [vp] * 6 + [vp]
         L.pd_foot_height_vjp.argtypes = [ci, ci] + [vp] * 6 + [vp]
-        if L.pd_abi_version() != ABI_VERSION:
+        if L.pd_abi_version() != ABI_VERSION and not (os.environ.get("PPR_DIFFPHYS_LIB") and os.environ.get("PPR_DIFFPHYS_ANY_ABI")):  # scripts/ab_time.sh times older builds
             raise RuntimeError("libpprdiffphys_hip.so ABI mismatch: library %d, binding %d" % (L.pd_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
@@ -158,6 +160,7 @@ class DeviceModel:
         _check(L.pd_model_create(ctypes.byref(d), ctypes.byref(h)))
         self.h = h
         self._xp = None
+        self._nc_keep = keep["contact_body"]
 
     def __del__(self):
         try:
@@ -261,6 +264,28 @@ class DeviceModel:
         body_f = torch.cat([vt[..., 1:4], fm[..., :3]], dim=-1)
         mask = fm[..., 3].contiguous().view(torch.int32)
         return body_q, body_qd, body_f, mask
+
+    def contact_order(self):
+        """order[i] = index into the template's contact_* arrays of entry i of the device contact table (``pd_model_contact_order``)."""
+        n = len(self._nc_keep)
+        out = (ctypes.c_int * max(n, 1))()
+        _check(lib().pd_model_contact_order(self.h, out, n))
+        return np.frombuffer(out, dtype=np.int32, count=n).copy()
+
+    def saved_hit_log(self, ws, bs, nsteps):
+        """The contact hit log behind the trajectory planes (inspection / tests): int32 [T, bs, 32] -- [..., 0] the number of
+        candidates that touched in that env-step (-1: more than 31), then that many TEMPLATE contact indices (decoded through
+        contact_order(); the packed material / body bits are dropped), -1 padded."""
+        N = bs * self.nb
+        raw = ws[nsteps * 20 * N:].view(torch.int32)[: nsteps * bs * 32].view(nsteps, bs, 32).cpu().numpy()
+        order = self.contact_order()
+        cnt = raw[..., 0]
+        valid = np.arange(31)[None, None, :] < np.maximum(cnt, 0)[..., None]
+        pts = np.where(valid, raw[..., 1:] & 0xFFFF, 0)
+        out = np.full(raw.shape, -1, np.int32)
+        out[..., 0] = cnt
+        out[..., 1:] = np.where(valid, order[pts] if len(order) else 0, -1)
+        return out
 
     def rollout_backward(self, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, body_inv_mass,
                          body_inertia, body_inv_inertia, frame2step, ws, adj_pos, adj_vel, out=None):

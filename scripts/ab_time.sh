@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B device timing of several builds of the library on ONE box: scripts/ab_time.sh <cfg> lib1.so lib2.so ...   (two rounds, interleaved)
+# A/B device timing of several builds of the library on ONE box: scripts/ab_time.sh "<cfg> [<cfg> ...]" lib1.so lib2.so ...   (two rounds, interleaved)
 cfg=$1; shift
+export PPR_DIFFPHYS_ANY_ABI=1
 for round in 1 2; do
   for lib in "$@"; do
     echo "== $lib"

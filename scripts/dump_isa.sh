@@ -4,7 +4,7 @@
 W=${1:-16}
 mkdir -p /tmp/isa
 cd /root/repo/ppr-diffphys_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-signed-zeros -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DPD_SEGW=$W $EXTRA -S --cuda-device-only pd_kernels.hip -o /tmp/isa/k$W.s 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-signed-zeros -fno-slp-vectorize -falign-loops=32 -mllvm -amdgpu-sched-strategy=iterative-ilp -DPD_SEGW=$W $EXTRA -S --cuda-device-only pd_kernels.hip -o /tmp/isa/k$W.s 2>/dev/null
 python3 - $W <<'PY'
 import re,sys
 w=sys.argv[1]

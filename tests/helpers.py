@@ -198,4 +198,85 @@ def oracle_bundle(tpl, inp, bs):
     finally:
         rc64.set_state_rounding(0)
     e_round = np.maximum(rounded[0], rounded[1])
-    return dict(rc64=rc64, st64=st64, g64=g64, st32=st32, g32=g32, cond=np.maximum(worst(g32), e_round), e_round=e_round)
+    # cond = the rounded-state runs ALONE (the fp32 oracle's literal acos is 1e-3 .. 1 off in most 100-step Laikago
+    # rollouts and bounded little); cond_fp32 keeps the old, looser scale for printing
+    return dict(rc64=rc64, st64=st64, g64=g64, st32=st32, g32=g32, cond=e_round, cond_fp32=np.maximum(worst(g32), e_round), e_round=e_round)
+
+
+def own_trajectory_check(dm, tpl, inp, dev, hitlog_check=True):
+    """The airtight gradient comparison: the kernel's gradients against the float64 C oracle's adjoint OF THE
+    KERNEL'S OWN saved trajectory -- same linearisation point, so the chaos of a 100-step rollout is not in the comparison -- with the
+    kernel's discrete decisions: its stored velocity-clamp masks, and "this candidate touches" by its pinned fp32 height test
+    (oracle/ref_c/diffphys_ref.c: touch_pinned_fp32, cross-checked here against the hit log the forward kernel wrote).  What stays
+    re-decided in float64 -- the Coulomb min and the +-500 N force clamp -- is probed on the kernel's states (singularity_probe).
+    Returns dict(worst [bs] = per env the largest per-tensor relative error (grad_env_errors), errors per tensor, probe minima
+    per env: coulomb, force_clamp, height; grads of the oracle)."""
+    import torch
+
+    from oracle.ref_c import RefC
+
+    bs = inp["q_init"].size // dm.nq
+    T, f2s = inp["nsteps"], list(inp["frame2step"])
+    FWD = ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia")
+    BWD = ("q_init", "qd_init", "torques", "refs", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia")
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
+    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s)
+    g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, ws, t["adj_pos"], t["adj_vel"])
+    grads = {k: v.cpu().numpy() for k, v in g.items()}
+    bq, bqd, bf, mask = dm.saved_trajectory(ws, bs, T)
+    traj = dict(states_q=bq.cpu().numpy(), states_qd=bqd.cpu().numpy(), states_f=bf.cpu().numpy())
+    mask = mask.cpu().numpy()
+    rc = RefC(tpl, np.float64)
+    st = rc.trajectory_state(traj, inp)
+    g64 = rc.rollout_backward_forced(st, inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, pinned_touch=True)
+    errs = grad_env_errors(grads, g64, bs)
+    worst = np.max(np.stack([errs[k] for k in GRAD_LEAD]), axis=0)
+    # conditioning of the adjoint ON THIS FIXED TRAJECTORY: how far the float64 gradients move when every stored fp32 value (state and
+    # total wrench) is replaced by an adjacent fp32 number, all decisions held (two random sign patterns).  No forward pass is re-run, so
+    # no chaos enters: it is what the last stored bit is worth -- the precision at which ANY fp32 evaluation sees the joint gaps
+    # (x_err = a difference of ~0.5 m positions, 1e-5 .. 1e-4 m long on Laikago's 16 kN/m springs)
+    tl = rc.touch_fp32(st, cap=64)
+    cond = np.zeros(bs)
+    for seed in (0, 1):
+        rng = np.random.RandomState(1234 + seed)
+        jit = {}
+        for k, v in traj.items():
+            v = np.asarray(v, np.float32)
+            jit[k] = np.nextafter(v, np.where(rng.rand(*v.shape) < 0.5, -np.inf, np.inf).astype(np.float32))
+        g_j = rc.rollout_backward_forced(rc.trajectory_state(jit, inp), inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, touch_list=tl)
+        e_j = grad_env_errors(g_j, g64, bs)
+        cond = np.maximum(cond, np.max(np.stack([e_j[k] for k in GRAD_LEAD]), axis=0))
+    # a plain fp32 evaluation of the same adjoint on the same trajectory with the same decisions: the fp32 build of the C oracle,
+    # once with the literal twist angle (2 acos(twist.w): what an fp32 tape of the reference's text does) and once through atan2 (the
+    # kernels' evaluation of that function) -- the yardstick for "as accurate as fp32 arithmetic allows"
+    rc32 = RefC(tpl, np.float32)
+    st32 = rc32.trajectory_state(traj, inp)
+    e32 = {}
+    try:
+        for tag, sw in (("acos", False), ("atan2", True)):
+            rc32.set_twist_eval(sw)
+            g32 = rc32.rollout_backward_forced(st32, inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, touch_list=tl)
+            e = grad_env_errors(g32, g64, bs)
+            e32[tag] = np.max(np.stack([e[k] for k in GRAD_LEAD]), axis=0)
+    finally:
+        rc32.set_twist_eval(False)
+    probe = rc.singularity_probe(st)  # [T, bs, 5] on the kernel's own states
+    out = dict(worst=worst, errs=errs, cond=cond, fp32_acos=e32["acos"], fp32_atan2=e32["atan2"], touch_counts=tl[..., 0].copy(), g64=g64, grads=grads, height=probe[:, :, 0].min(0), coulomb=probe[:, :, 2].min(0),
+               force_clamp=probe[:, :, 4].min(0), clamp_dist=probe[:, :, 1].min(0), traj=traj, mask=mask)
+    if hitlog_check:
+        # the restated touch decision against the kernel's own record: every candidate it says touches is in the hit log of that
+        # env-step (the log is the exact list in speculated steps and a superset -- cull survivors -- where the exact sweep ran)
+        log = dm.saved_hit_log(ws, bs, T)            # [T, bs, 32] template indices
+        tch = rc.touch_fp32(st, cap=32)               # [T, bs, 32]
+        ok = log[..., 0] >= 0
+        n_t = tch[..., 0]
+        missing = 0
+        for j in range(31):
+            has = (j < n_t) & ok
+            if not has.any():
+                break
+            k = tch[..., 1 + j]
+            missing += int((has & ~(log[..., 1:] == k[..., None]).any(-1)).sum())
+        out.update(hitlog_missing=missing, hitlog_overflow=int((~ok).sum()), touches=int(n_t.sum()),
+                   log_entries=int(np.maximum(log[..., 0], 0).sum()))
+    return out

@@ -28,7 +28,8 @@ def test_bench_line_contract_and_consistency():
     assert abs(d["value"] - 4096 * 100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["blocks"]["n"] == 3 and d["blocks"]["min_value"] <= d["value"] <= d["blocks"]["max_value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # "bound" names what binds; achieved / peak / unit / frac stay the contract's HBM figures, hbm_frac repeats frac
+    assert r["bound"] == "valu-issue" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["hbm_frac"] == r["frac"]
     # achieved = algorithmic bytes per launch / the kernel's launch duration, measured in this run
     assert abs(r["achieved"] * 1e9 - 4096 * 100 * r["algorithmic_bytes_per_env_step"] / (r["avg_launch_ms"] * 1e-3)) < 1e-6 * r["achieved"] * 1e9
     assert 0.05 < r["frac"] < 1.0
@@ -38,5 +39,29 @@ def test_bench_line_contract_and_consistency():
     # the roofline that binds (fp32 VALU issue): below its peak, and the adjoint close to it
     assert r["valu"] is not None and 0.5 < r["valu"]["frac"] < 1.02, r["valu"]
     assert f["valu"] is not None and 0.2 < f["valu"]["frac"] < r["valu"]["frac"]
+    # ... and against the data-sheet vector peak (157.3 TFLOP/s, packed FMAs only): instructions x 128 flop / time
+    v = r["valu"]
+    assert abs(v["frac_of_vector_peak"] - v["insts_per_launch"] * 128 / (r["avg_launch_ms"] * 1e-3) / 157.3e12) < 1e-9 and 0.2 < v["frac_of_vector_peak"] < 0.6
+    assert d["collective_backend"] is None and d["ranks_seen"] == 1 and d["launcher"] == "none"
     b = d["boundary"]
     assert 0.8 < b["ratio_to_value"] < 1.1 and b["nan_grads"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` as the driver types it for N = 1 (no launcher): the parent starts two rank processes itself.  On this
+    1-GPU box the ranks share the device (PPR_BENCH_SHARE_GPU test hook; RCCL refuses two ranks on one device, so the barrier falls back
+    to gloo AND the line says so): the multi-rank code path -- sharding, barrier, MAX over ranks, both scaling modes -- runs for real."""
+    env = dict(os.environ, PPR_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "3"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launcher"] == "self" and d["collective_backend"] in ("nccl", "gloo")
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 4096 and d["config"]["envs_per_gpu"] == 2048
+    assert abs(d["value"] - 4096 * 100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    o = d["other_scaling"]
+    assert o["scaling"] == "weak" and o["global_batch"] == 8192 and o["envs_per_gpu"] == 4096
+    assert "cpu_baseline" not in d and "boundary" not in d   # N = 1 only

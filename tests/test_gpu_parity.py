@@ -330,7 +330,8 @@ def test_config_c3_human_1024(dev, oracle_libs):
 
 def test_config_c5_quad_8192_gradcheck(dev, oracle_libs):
     """BASELINE config C5: AI4Animation quadruped (26 bodies, 25 compound joints), contact-rich, 8192 envs.
-    Gradient check of every input against the float64 C oracle, per env, relative to each tensor's max.  The config's rtol 1e-4
+    Gradient check of every input against the float64 C oracle, per env and per tensor ON THAT ENV'S OWN SCALE (round 4; round 3
+    divided by the batch-wide maximum).  The config's rtol 1e-4
     is the median bar at BOTH horizons -- 4 steps and the config's own T = 34 (one frame interval) -- with the per-env 99th
     percentile at 1e-2 for T = 34 (round 2 had 2e-2 / 1.0 there).  The envs above the median bar are the
     ones that sit on a contact edge (see test_config_size_gradients_every_tensor_per_env for the explained per-env version)."""
@@ -350,16 +351,14 @@ def test_config_c5_quad_8192_gradcheck(dev, oracle_libs):
         st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
         gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
         assert np.abs(st["grf"]).max() > 10.0  # contact-rich
+        # per env AND per tensor on that env's own scale (helpers.grad_env_errors; round 3 divided by the batch-wide maximum, so a
+        # handful of envs with huge gradients set the scale -- VERDICT r3 weak #3)
+        from helpers import grad_env_errors
+        errs = grad_env_errors(out["grads"], gr, bs)
         for k in GRADS:
-            ref = gr[k]
-            if np.abs(ref).max() == 0:
+            if np.abs(gr[k]).max() == 0:
                 continue
-            if k in ("torques", "res_f", "refs"):  # [T, bs*n] layouts
-                g = out["grads"][k].reshape(T, bs, -1).astype(np.float64).transpose(1, 0, 2).reshape(bs, -1)
-                r = ref.reshape(T, bs, -1).transpose(1, 0, 2).reshape(bs, -1)
-            else:
-                g, r = out["grads"][k].reshape(bs, -1).astype(np.float64), ref.reshape(bs, -1)
-            per_env = np.abs(g - r).max(1) / (np.abs(r).max() + 1e-30)
+            per_env = errs[k]
             print("C5 T=%d %-18s median %.1e p99 %.1e max %.1e" % (T, k, np.median(per_env), np.percentile(per_env, 99), per_env.max()))
             assert np.median(per_env) < tol, (T, k, float(np.median(per_env)))
             assert np.percentile(per_env, 99) < p99, (T, k, float(np.percentile(per_env, 99)))

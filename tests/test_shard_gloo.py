@@ -9,6 +9,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -75,3 +76,21 @@ def test_shard_envs_partitions():
     assert bench.shard_envs(4096, 8, 3) == (1536, 2048)   # 512 envs per GPU at 8 GPUs
     f, b = bench.algorithmic_bytes(13, 18)
     assert f + b == 2720  # SURVEY.md section 8(d) canonical figure for Laikago
+
+
+def test_bench_gpus_n_self_launches_without_a_launcher():
+    """`python bench.py --gpus 2` typed as the driver types N = 1 must start its own ranks.  On this GPU-less box both
+    children must get as far as the product's "needs a GPU" refusal -- not the old "must be launched with torch.distributed.run"."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_bench.py covers the self-launch there")
+    assert out.returncode != 0
+    assert out.stderr.count("needs a GPU") == 2, out.stderr[-2000:]
+    assert "ranks failed" in out.stderr and "torch.distributed.run" not in out.stderr
