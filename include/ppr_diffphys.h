@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 5   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log) */
+#define PD_ABI_VERSION 5   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4) */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -128,6 +128,43 @@ int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
                         float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
                         float *g_body_inv_mass_dev, float *g_body_inertia_dev, float *g_body_inv_inertia_dev,
                         void *stream);
+
+/* The rollout with the trajectory loss evaluated where the frame poses are produced.  Of the reference's
+ * loss terms only loss_traj back-propagates through the rollout (diffphys/dp_model.py:777-779; pos_state / vel_state / distill use
+ * sim_position.detach(), :795,802):   loss_traj = reduce_loss(se3_loss(sim_position, target_position).mean(-1) with outseq entries
+ * zeroed, clip=True)   (se3_loss diffphys/dp_utils.py:113-138, reduce_loss :93-110).
+ * pd_rollout_forward_traj_loss = pd_rollout_forward plus, inside the same rollout launch, at every frame state: se3_loss of each body
+ * pose against target_pos_dev [bs][F][nb][7] (p, real-last quaternion), its UNSCALED gradients to seed_pos_dev [F][bs*nb][7] (the
+ * layout of adj_pos) and seed_gt_dev [bs][F][nb][7] (d / d target; may be NULL), the mean over the env's bodies to
+ * loss_table_dev [bs][F] (0 where outseq_dev [bs][F] bytes are non-zero; outseq_dev may be NULL); then one small launch that does
+ * reduce_loss on the table: reduced_dev[4] = { loss_traj, the clip threshold (10 x the lower median of the positive entries of the
+ * first env that has any; +inf if none), the number of positive entries left, the number of clipped envs } and scale_dev [bs][F] =
+ * d loss_traj / d table entry (0 for entries the clip / outseq assigned zero).  wp_pos / wp_vel / grf / jaf as pd_rollout_forward.
+ * pd_rollout_backward_traj_loss = pd_rollout_backward whose frame seeds are  g_loss_dev[0] * scale[env][frame] / nb * seed_pos
+ * (g_loss_dev: DEVICE scalar, the upstream gradient of loss_traj, e.g. traj_wt) PLUS the rows of adj_pos_dev / adj_vel_dev when
+ * those are given (both or neither; NULL = no other term reaches the poses).  No pose or seed passes through the host framework
+ * between the two launches, no se3_loss launch, no reduce_loss ops. */
+int pd_rollout_forward_traj_loss(const pd_model *m, int bs, int nsteps, float dt,
+                                 const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
+                                 const float *res_f_dev, const float *refs_dev, const float *target_ke_dev,
+                                 const float *target_kd_dev, const float *body_inv_mass_dev,
+                                 const float *body_inertia_dev, const float *body_inv_inertia_dev,
+                                 int nframes, const int *frame2step_host, float *workspace_dev,
+                                 float *wp_pos_dev, float *wp_vel_dev, float *grf_dev, float *jaf_dev,
+                                 const float *target_pos_dev, const unsigned char *outseq_dev, float rot_ratio,
+                                 float *seed_pos_dev, float *seed_gt_dev, float *loss_table_dev, float *reduced_dev,
+                                 float *scale_dev, void *stream);
+int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float dt,
+                                  const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
+                                  const float *refs_dev, const float *target_ke_dev, const float *target_kd_dev,
+                                  const float *body_inv_mass_dev, const float *body_inertia_dev,
+                                  const float *body_inv_inertia_dev, int nframes, const int *frame2step_host,
+                                  const float *workspace_dev, const float *adj_pos_dev, const float *adj_vel_dev,
+                                  const float *seed_pos_dev, const float *scale_dev, const float *g_loss_dev,
+                                  float *g_q_init_dev, float *g_qd_init_dev, float *g_torques_dev, float *g_res_f_dev,
+                                  float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
+                                  float *g_body_inv_mass_dev, float *g_body_inertia_dev, float *g_body_inv_inertia_dev,
+                                  void *stream);
 
 /* n independent articulations: joint_q [n][nq], joint_qd [n][nqd] -> body_q [n][nb][7], body_qd [n][nb][6] */
 int pd_fk_forward(const pd_model *m, int n, const float *joint_q_dev, const float *joint_qd_dev,

@@ -70,6 +70,16 @@ struct RolloutArgs {
   const float *adj_pos, *adj_vel;
   float *g_q_init, *g_qd_init, *g_torques, *g_res_f, *g_refs, *g_ke, *g_kd, *g_inv_mass, *g_inertia, *g_inv_inertia;
   int *hitlog;              // workspace tail: per (step, env) the compacted contact hit list of the forward sweep
+  // trajectory loss evaluated where the frame poses are produced (pd_rollout_forward_traj_loss / _backward_traj_loss; row f4):
+  // forward (LOSS instantiations only): se3_loss of every frame pose against loss_target [bs][F][nb][7], its unscaled gradients to
+  // loss_seed_pos [F][bs*nb][7] (the layout of adj_pos) / loss_seed_gt [bs][F][nb][7] (may be null), the per-frame mean over the
+  // env's bodies to loss_table [bs][F] (0 where loss_outseq [bs][F] is set; may be null)
+  const float *loss_target;
+  const unsigned char *loss_outseq;
+  float loss_rot_ratio;
+  float *loss_seed_pos, *loss_seed_gt, *loss_table;
+  // backward: seeds  seed_gain[0] * seed_scale[env][frame] / nb * seed_pos  are ADDED to those of adj_pos (which may then be null)
+  const float *seed_pos, *seed_scale, *seed_gain;
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
 #ifdef PD_EXPERIMENT        // timing builds only (make experiment): rejected variants, DESIGN.md section 4 / EXPERIMENTS.md
   int own_joint;            // adjoint, 2-role kernel: the body wave recomputes its joint's state-only half itself (measured: slower)

@@ -448,16 +448,25 @@ size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
   return m ? (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb + (size_t)nsteps * (size_t)bs * PD_HITLOG : 0;  // + hit log (ints)
 }
 
-int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+// trajectory-loss extras of the two *_traj_loss entries (null = the plain rollout)
+struct TrajLossFwd { const float *target; const unsigned char *outseq; float rot_ratio; float *seed_pos, *seed_gt, *table, *reduced, *scale; };
+struct TrajLossBwd { const float *seed_pos, *scale, *gain; };
+extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(int bs, int nframes, const float *table, float *reduced, float *scale, hipStream_t st);  // pd_loss.hip; internal
+
+static int rollout_forward_impl(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
                        const float *torques, const float *res_f, const float *refs, const float *target_ke,
                        const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
-                       const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, void *stream) {
+                       const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, const TrajLossFwd *tl,
+                       void *stream) {
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
   const int *fos = nullptr;
   if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;
-  if (bs == 0) return 0;
+  if (bs == 0) {  // nothing to roll out; an empty batch still gets a defined reduced loss (0) from the trajectory-loss entry
+    if (tl && tl->reduced && pd_traj_loss_reduce_launch(0, nframes, tl->table, tl->reduced, tl->scale, (hipStream_t)stream)) return fail("trajectory-loss reduction launch failed");
+    return 0;
+  }
   if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia) return fail("null device pointer");
   if (nsteps > 0 && (!torques || !res_f || !refs || !ws)) return fail("null device pointer");
   if (nframes > 0 && (!wp_pos || !wp_vel)) return fail("null device pointer");
@@ -468,19 +477,45 @@ int pd_rollout_forward(const pd_model *cm, int bs, int nsteps, float dt, const f
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = fos; a.ws = ws; a.wp_pos = wp_pos; a.wp_vel = wp_vel; a.grf = grf; a.jaf = jaf; a.dbg = g_dbg;
   a.hitlog = (int *)(ws + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
+  if (tl) {
+    if (nframes > 0 && (!tl->target || !tl->seed_pos || !tl->table || !tl->reduced || !tl->scale)) return fail("null device pointer (trajectory loss)");
+    a.loss_target = nframes > 0 ? tl->target : nullptr; a.loss_outseq = tl->outseq; a.loss_rot_ratio = tl->rot_ratio;
+    a.loss_seed_pos = tl->seed_pos; a.loss_seed_gt = tl->seed_gt; a.loss_table = tl->table;
+  }
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 0, st);
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, st);
   timing_end(m, 0, st);
-  return e == hipSuccess ? 0 : hip_fail(e, "rollout_forward launch");
+  if (e != hipSuccess) return hip_fail(e, "rollout_forward launch");
+  if (tl && pd_traj_loss_reduce_launch(bs, nframes, tl->table, tl->reduced, tl->scale, st)) return fail("trajectory-loss reduction launch failed");
+  return 0;
 }
 
-int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+int pd_rollout_forward(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                       const float *torques, const float *res_f, const float *refs, const float *target_ke,
+                       const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
+                       const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, void *stream) {
+  return rollout_forward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia,
+                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, nullptr, stream);
+}
+
+int pd_rollout_forward_traj_loss(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                                 const float *torques, const float *res_f, const float *refs, const float *target_ke,
+                                 const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
+                                 const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf,
+                                 const float *target_pos, const unsigned char *outseq, float rot_ratio, float *seed_pos, float *seed_gt,
+                                 float *loss_table, float *reduced, float *scale, void *stream) {
+  const TrajLossFwd tl{target_pos, outseq, rot_ratio, seed_pos, seed_gt, loss_table, reduced, scale};
+  return rollout_forward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia,
+                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, &tl, stream);
+}
+
+static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
                         const float *torques, const float *refs, const float *target_ke, const float *target_kd,
                         const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
                         const float *ws, const float *adj_pos, const float *adj_vel, float *g_q_init, float *g_qd_init,
                         float *g_torques, float *g_res_f, float *g_refs, float *g_ke, float *g_kd, float *g_inv_mass,
-                        float *g_inertia, float *g_inv_inertia, void *stream) {
+                        float *g_inertia, float *g_inv_inertia, const TrajLossBwd *tl, void *stream) {
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
@@ -491,10 +526,13 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
       !g_kd || !g_inv_mass || !g_inertia || !g_inv_inertia)
     return fail("null device pointer");
   if (nsteps > 0 && (!torques || !refs || !ws || !g_torques || !g_res_f || !g_refs)) return fail("null device pointer");
-  if (nframes > 0 && (!adj_pos || !adj_vel)) return fail("null device pointer");
+  if (!tl && nframes > 0 && (!adj_pos || !adj_vel)) return fail("null device pointer");
+  if (tl && ((adj_pos == nullptr) != (adj_vel == nullptr))) return fail("adj_pos and adj_vel come together (both, or neither)");
+  if (tl && nframes > 0 && (!tl->seed_pos || !tl->scale || !tl->gain)) return fail("null device pointer (trajectory loss)");
   if (m->xp_env && m->xp_envs != bs) return fail("joint_X_p is bound for " + std::to_string(m->xp_envs) + " envs, rollout has " + std::to_string(bs));
   RolloutArgs a{};
   a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
+  if (tl && nframes > 0) { a.seed_pos = tl->seed_pos; a.seed_scale = tl->scale; a.seed_gain = tl->gain; }
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = fos; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
@@ -510,6 +548,29 @@ int pd_rollout_backward(const pd_model *cm, int bs, int nsteps, float dt, const 
   hipError_t e = launch(m, PD_K_ROLLOUT_BWD, &a, bs, st);
   timing_end(m, 1, st);
   return e == hipSuccess ? 0 : hip_fail(e, "rollout_backward launch");
+}
+
+int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                        const float *torques, const float *refs, const float *target_ke, const float *target_kd,
+                        const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
+                        const float *ws, const float *adj_pos, const float *adj_vel, float *g_q_init, float *g_qd_init,
+                        float *g_torques, float *g_res_f, float *g_refs, float *g_ke, float *g_kd, float *g_inv_mass,
+                        float *g_inertia, float *g_inv_inertia, void *stream) {
+  return rollout_backward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
+                               frame2step, ws, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs, g_ke, g_kd, g_inv_mass,
+                               g_inertia, g_inv_inertia, nullptr, stream);
+}
+
+int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                                  const float *torques, const float *refs, const float *target_ke, const float *target_kd,
+                                  const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
+                                  const float *ws, const float *adj_pos, const float *adj_vel, const float *seed_pos, const float *scale,
+                                  const float *g_loss, float *g_q_init, float *g_qd_init, float *g_torques, float *g_res_f, float *g_refs,
+                                  float *g_ke, float *g_kd, float *g_inv_mass, float *g_inertia, float *g_inv_inertia, void *stream) {
+  const TrajLossBwd tl{seed_pos, scale, g_loss};
+  return rollout_backward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
+                               frame2step, ws, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs, g_ke, g_kd, g_inv_mass,
+                               g_inertia, g_inv_inertia, &tl, stream);
 }
 
 int pd_fk_forward(const pd_model *m, int n, const float *joint_q, const float *joint_qd, float *body_q, float *body_qd, void *stream) {

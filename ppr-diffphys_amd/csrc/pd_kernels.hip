@@ -7,6 +7,7 @@
 // hand-overs per step through LDS signal words).  See DESIGN.md section 3.
 #include "pd_device.h"
 #include "pd_args.h"
+#include "pd_se3.h"
 
 // In-kernel phase stamps (diagnostic build only, never in the shipped library): cdna_hip_programming.md section 7.
 #ifdef PD_STAMPS
@@ -61,6 +62,29 @@ PD_DEV void stg2(float *ubase, unsigned boff, float2 v) { *(float2 *)((char *)ub
 // (dp_model.py:1294-1384 of the reference), done here at ONE instruction per stored value (pd_math.h grad_post: v_med3_f32)
 // instead of ten passes over the tensors.
 #define NZ(x) grad_post<1>(x)
+
+// Seeds of a frame state in the reverse sweep (dp_model.py:1264-1271): the caller's adj_pos / adj_vel rows (optional since ABI 5) and
+// / or the trajectory-loss seeds the forward kernel left -- d se3_loss / d pose per body, scaled here by the upstream gradient of the
+// reduced loss (a device scalar), the frame's share of reduce_loss (0 where clipped / out of sequence / not positive, else 1 / N_pos)
+// and the 1 / nb of the mean over bodies (dp_model.py:777-779, dp_utils.py:93-110).
+// TL = false is the plain adjoint (pd_rollout_backward): adj_pos / adj_vel are there, nothing else is looked at -- the headline
+// kernel carries none of the trajectory-loss code (with it behind run-time checks the 2-role adjoint went from 252 VGPRs / no spill
+// to 256 / 36 spilled).
+template <bool TL>
+PD_DEV void add_frame_seeds(const RolloutArgs &a, int fr, int N, size_t idx, int ec, int nb, BodyAdj &gn) {
+  if (!TL || a.adj_pos) {
+    const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
+    gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
+    gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+  }
+  if (TL && a.seed_pos) {
+    const float k = a.seed_gain[0] * a.seed_scale[(size_t)ec * a.nframes + fr] / (float)nb;
+    const float *sp = a.seed_pos + ((size_t)fr * N + idx) * 7;
+    if (k != 0.0f) {  // a zero share is an assignment in the reference (loss_seq[i, idx:] = 0): nothing flows, not 0 * inf
+      gn.p += V3(sp[0], sp[1], sp[2]) * k; gn.r += Q4(sp[3], sp[4], sp[5], sp[6]) * k;
+    }
+  }
+}
 
 template <int SEGW>
 struct Seg {
@@ -478,7 +502,11 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // Serving the body wave of the NEXT group instead (contact wave beside an unrelated body wave) was 1 % faster in the forward pass
 // without priorities, is 1 % slower with them, and is 11 % slower in the adjoint: pairs stay on one SIMD.
 #define PD_PRIO_CRITICAL 3
-template <int SEGW, int JT, bool SPLIT>
+// LOSS (pd_rollout_forward_traj_loss): at every frame state the body wave also evaluates se3_loss of the
+// pose it is about to store against the frame's target pose (dp_model.py:777, dp_utils.py:113-138), stores both unscaled gradients
+// and the mean over the env's bodies -- the [bs][F] table reduce_loss works on -- so that no pose makes the round trip through a loss
+// launch and torch before the adjoint can be seeded.  A separate instantiation: the plain rollout kernel is untouched.
+template <int SEGW, int JT, bool SPLIT, bool LOSS = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -733,6 +761,33 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       o[0] = cs.w.x; o[1] = cs.w.y; o[2] = cs.w.z; o[3] = cs.v.x; o[4] = cs.v.y; o[5] = cs.v.z;
     }
   };
+  auto frame_loss = [&](int cfr, const BodyState &cs) {  // cfr >= 0, wave-uniform
+    if constexpr (LOSS) {
+      float lb = 0.f;
+      if (is_body) {
+        const float pose[7] = {cs.p.x, cs.p.y, cs.p.z, cs.r.x, cs.r.y, cs.r.z, cs.r.w};
+        const size_t ot = (((size_t)ec * a.nframes + cfr) * nb + b) * 7;
+        float tg[7], gp[7], gg[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) tg[k] = a.loss_target[ot + k];
+        lb = pd_se3::se3_loss_eval<7>(pose, tg, a.loss_rot_ratio, true, gp, gg);
+        float *o = a.loss_seed_pos + ((size_t)cfr * N + idx) * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = gp[k];
+        if (a.loss_seed_gt) {
+#pragma unroll
+          for (int k = 0; k < 7; ++k) a.loss_seed_gt[ot + k] = gg[k];
+        }
+      }
+      // mean over the env's bodies (dp_model.py:777 .mean(-1)): butterfly over the segment's lanes, idle lanes carry 0
+#pragma unroll
+      for (int w = SEGW / 2; w >= 1; w >>= 1) lb += __shfl_xor(lb, w, SEGW);
+      if (l == 0 && env_ok) {
+        const size_t oe = (size_t)ec * a.nframes + cfr;
+        a.loss_table[oe] = (a.loss_outseq && a.loss_outseq[oe]) ? 0.f : lb / (float)nb;  // loss_traj[outseq_idx] = 0 (:778)
+      }
+    }
+  };
   auto spill_wrench = [&](int step) {  // what the o_* registers hold for `step`
     if (!is_body) return;
     float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
@@ -853,10 +908,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       // against right after hand-over A, and against after the vmcnt wait: -2 % / -0.5 % forward time at 4096 envs)
       spill_state(step, s, fr);
       if (step > 0) spill_wrench(step - 1);
+      if (LOSS && fr >= 0) frame_loss(fr, s);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
     } else {
       spill_state(step, s, fr);
       if (step > 0) spill_wrench(step - 1);
+      if (LOSS && fr >= 0) frame_loss(fr, s);
       WAVE_SYNC();
     }
     if (is_body) {
@@ -911,6 +968,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   {  // a frame may name the state after the last step (state_steps[nsteps], dp_model.py:396,1241-1246); no force
      // snapshot exists for it (the reference appends grf / jaf for step in steps_idx only, :1225-1228): zero rows
     const int fr_last = ld_uniform(a.frame_of_step, a.nsteps);
+    if (LOSS && fr_last >= 0) frame_loss(fr_last, s);
     if (fr_last >= 0 && is_body) {
       float *o = a.wp_pos + ((size_t)fr_last * N + idx) * 7;
       o[0] = s.p.x; o[1] = s.p.y; o[2] = s.p.z; o[3] = s.r.x; o[4] = s.r.y; o[5] = s.r.z; o[6] = s.r.w;
@@ -929,7 +987,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
 // =============================================================================================
 // EARLY (SPLIT only): hand-over A is signalled from inside the adjoint of integrate_bodies, as soon as the wrench adjoint
 // exists (integrate_adj2), instead of after it.
-template <int SEGW, int JT, bool SPLIT, bool EARLY = false>
+template <int SEGW, int JT, bool SPLIT, bool EARLY = false, bool TL = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -1148,9 +1206,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     {  // seeds of state step+1 (dp_model.py:1264-1271)
       const int fr = n_fr;
       if (fr >= 0) {
-        const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
-        gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
-        gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+        add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
       }
     }
     s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
@@ -1292,9 +1348,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   {  // seeds of state 0
     int fr = a.frame_of_step[0];
     if (fr >= 0) {
-      const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
-      gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
-      gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+      add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
     }
   }
   // ---- adjoint of eval_fk: rec holds state 0 (staged in the last loop iteration)
@@ -1359,7 +1413,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 // ROLES = 3: I, C, J waves (<= 168 VGPRs each).  ROLES = 2: the integrate wave also replays the contacts (between its phase 2
 // and the wait for the joint wave) -- compound-joint robots, whose joint adjoint needs more than 168 registers but whose
 // box contacts are a handful of points: two waves per env group, <= 256 VGPRs each.
-template <int SEGW, int JT, int ROLES>
+template <int SEGW, int JT, int ROLES, bool TL = false>
 __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -1731,9 +1785,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   for (int step = a.nsteps - 1; step >= 0; --step) {
     // s, t0, f0, fr and the staged record of `step` are in place (stage_step ran in the previous iteration)
     if (fr >= 0) {  // seeds of state step+1 (dp_model.py:1264-1271)
-      const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
-      gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
-      gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+      add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
     }
     // (ROLES == 2) the forward hit list of this step is replayed inline further down: fetch its length now, far ahead
     int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
@@ -1807,9 +1859,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   {  // seeds of state 0
     int fr = a.frame_of_step[0];
     if (fr >= 0) {
-      const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
-      gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
-      gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
+      add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
     }
   }
   // ---- adjoint of eval_fk: rec holds state 0 (staged in the last loop iteration); the J wave is past its last use of cslot
@@ -1918,7 +1968,12 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
   const size_t lds = cfg.lds;
   switch (kind) {
     case PD_K_ROLLOUT_FWD:
-      if (cfg.kernel == PD_KV_FWD_SPLIT)
+      if (((const RolloutArgs *)args)->loss_target) {  // trajectory loss at the frame states (pd_rollout_forward_traj_loss)
+        if (cfg.kernel == PD_KV_FWD_SPLIT)
+          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        else
+          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+      } else if (cfg.kernel == PD_KV_FWD_SPLIT)
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
       else
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), g, t, lds, st, m, *(const RolloutArgs *)args);
@@ -1935,7 +1990,10 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
           break;
         }
 #endif
-        hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        if (((const RolloutArgs *)args)->seed_pos)  // seeds from the trajectory loss (pd_rollout_backward_traj_loss)
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        else
+          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else {
 #ifdef PD_EXPERIMENT
         if (cfg.kernel == PD_KV_BWD_UNSPLIT) {  // the unsplit round-1 kernel
@@ -1943,7 +2001,10 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
           break;
         }
 #endif
-        hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        if (((const RolloutArgs *)args)->seed_pos)
+          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        else
+          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
       }
       break;
     case PD_K_FK_FWD:
@@ -1963,14 +2024,18 @@ static hipError_t set_lds_jt(int bytes) {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #ifdef PD_EXPERIMENT
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #endif
   } else {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #ifdef PD_EXPERIMENT
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #endif

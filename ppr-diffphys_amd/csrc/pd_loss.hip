@@ -7,113 +7,30 @@
 // One element per lane; HBM-bound by construction (2 * DIM floats in, 1 + 2 * DIM out), launch-latency-bound in practice.
 #include <hip/hip_runtime.h>
 #include "../../include/ppr_diffphys.h"
+#include "pd_se3.h"
 
 namespace {
-
-struct Rot {            // rotation of one input and what its gradient needs
-  float q[4];           // x, y, z, w (as converted from the input)
-  float s;              // 2 / |q|^2
-  float R[9];
-  // axis-angle inputs only:
-  float a[3], theta, sho, dsho;  // vector, |a|, sin(theta/2)/theta (series when small), d sho / d theta
-};
-
-__device__ __forceinline__ void rot_matrix(Rot &r) {
-  const float x = r.q[0], y = r.q[1], z = r.q[2], w = r.q[3];
-  r.s = 2.0f / (x * x + y * y + z * z + w * w);
-  const float s = r.s;
-  r.R[0] = 1.0f - s * (y * y + z * z); r.R[1] = s * (x * y - z * w); r.R[2] = s * (x * z + y * w);
-  r.R[3] = s * (x * y + z * w); r.R[4] = 1.0f - s * (x * x + z * z); r.R[5] = s * (y * z - x * w);
-  r.R[6] = s * (x * z - y * w); r.R[7] = s * (y * z + x * w); r.R[8] = 1.0f - s * (x * x + y * y);
-}
-
-template <int DIM>
-__device__ __forceinline__ Rot load_rot(const float *v) {
-  Rot r;
-  if (DIM == 7) {
-    r.q[0] = v[3]; r.q[1] = v[4]; r.q[2] = v[5]; r.q[3] = v[6];
-  } else {
-    r.a[0] = v[3]; r.a[1] = v[4]; r.a[2] = v[5];
-    r.theta = sqrtf(r.a[0] * r.a[0] + r.a[1] * r.a[1] + r.a[2] * r.a[2]);
-    const float half = 0.5f * r.theta;
-    const bool small = r.theta < 1e-6f;
-    r.sho = small ? 0.5f - r.theta * r.theta / 48.0f : sinf(half) / r.theta;
-    r.dsho = small ? -r.theta / 24.0f : (0.5f * cosf(half) * r.theta - sinf(half)) / (r.theta * r.theta);
-    r.q[0] = r.a[0] * r.sho; r.q[1] = r.a[1] * r.sho; r.q[2] = r.a[2] * r.sho; r.q[3] = cosf(half);
-  }
-  rot_matrix(r);
-  return r;
-}
-
-// d trace(R(q) B^T) / d q  for R(q) = I + s M(q), s = 2 / |q|^2
-__device__ __forceinline__ void trace_grad(const Rot &r, const float *B, float *g) {
-  const float x = r.q[0], y = r.q[1], z = r.q[2], w = r.q[3], s = r.s;
-  const float Q = -(y * y + z * z) * B[0] - (x * x + z * z) * B[4] - (x * x + y * y) * B[8] + (x * y - z * w) * B[1] + (x * z + y * w) * B[2] +
-                  (x * y + z * w) * B[3] + (y * z - x * w) * B[5] + (x * z - y * w) * B[6] + (y * z + x * w) * B[7];
-  const float dQ[4] = {-2.0f * x * (B[4] + B[8]) + y * (B[1] + B[3]) + z * (B[2] + B[6]) + w * (B[7] - B[5]),
-                       -2.0f * y * (B[0] + B[8]) + x * (B[1] + B[3]) + z * (B[5] + B[7]) + w * (B[2] - B[6]),
-                       -2.0f * z * (B[0] + B[4]) + x * (B[2] + B[6]) + y * (B[5] + B[7]) + w * (B[3] - B[1]),
-                       x * (B[7] - B[5]) + y * (B[2] - B[6]) + z * (B[3] - B[1])};
-#pragma unroll
-  for (int k = 0; k < 4; ++k) g[k] = s * dQ[k] - s * s * r.q[k] * Q;
-}
-
-// chain a gradient with respect to the quaternion back to the input rotation (DIM - 3 floats), scaled by k
-template <int DIM>
-__device__ __forceinline__ void store_rot_grad(const Rot &r, const float *gq, float k, float *out) {
-  if (DIM == 7) {
-    out[3] = k * gq[0]; out[4] = k * gq[1]; out[5] = k * gq[2]; out[6] = k * gq[3];
-  } else {
-    const float inv_t = r.theta > 0.0f ? 1.0f / r.theta : 0.0f;  // d |a| / d a = a / |a|, taken as 0 at 0 like torch.norm
-    const float ga = gq[0] * r.a[0] + gq[1] * r.a[1] + gq[2] * r.a[2];
-    const float c = (-0.5f * sinf(0.5f * r.theta) * gq[3] + ga * r.dsho) * inv_t;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) out[3 + i] = k * (r.sho * gq[i] + c * r.a[i]);
-  }
-}
 
 template <int DIM>
 __global__ __launch_bounds__(256) void k_se3_loss(int n, const float *__restrict__ pred, const float *__restrict__ gt, float rot_ratio,
                                                   float *__restrict__ loss, float *__restrict__ g_pred, float *__restrict__ g_gt) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float p[DIM], g[DIM];
-  float sp = 0.f, sg = 0.f;
+  float p[DIM], g[DIM], op[DIM], og[DIM];
 #pragma unroll
-  for (int k = 0; k < DIM; ++k) { p[k] = pred[(size_t)i * DIM + k]; g[k] = gt[(size_t)i * DIM + k]; sp += p[k]; sg += g[k]; }
-  const bool bad = isnan(sp) || isnan(sg);
-  const float d[3] = {p[0] - g[0], p[1] - g[1], p[2] - g[2]};
-  const Rot A = load_rot<DIM>(p), B = load_rot<DIM>(g);
-  float T = 0.f;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) T += A.R[k] * B.R[k];
-  const float eps = 1e-4f, cosv = (T - 1.0f) * 0.5f;
-  const bool inside = cosv > -1.0f + eps && cosv < 1.0f - eps;
-  const float cc = fminf(fmaxf(cosv, -1.0f + eps), 1.0f - eps);
-  const float value = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + rot_ratio * acosf(cc);
-  loss[i] = bad ? 0.0f : value;
-  if (!g_pred && !g_gt) return;
-  // d angle / d T = -1/2 / sqrt(1 - cos^2) inside the clamp, 0 on it (torch.clamp)
-  const float dT = inside ? rot_ratio * (-0.5f / sqrtf(1.0f - cc * cc)) : 0.0f;
-  float gq[4], out[DIM];
+  for (int k = 0; k < DIM; ++k) { p[k] = pred[(size_t)i * DIM + k]; g[k] = gt[(size_t)i * DIM + k]; }
+  loss[i] = pd_se3::se3_loss_eval<DIM>(p, g, rot_ratio, g_pred || g_gt, g_pred ? op : nullptr, g_gt ? og : nullptr);
   if (g_pred) {
-    trace_grad(A, B.R, gq);
-    out[0] = 2.0f * d[0]; out[1] = 2.0f * d[1]; out[2] = 2.0f * d[2];
-    store_rot_grad<DIM>(A, gq, dT, out);
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) g_pred[(size_t)i * DIM + k] = bad ? 0.0f : out[k];  // (0 * NaN would still be NaN)
+    for (int k = 0; k < DIM; ++k) g_pred[(size_t)i * DIM + k] = op[k];
   }
   if (g_gt) {
-    trace_grad(B, A.R, gq);
-    out[0] = -2.0f * d[0]; out[1] = -2.0f * d[1]; out[2] = -2.0f * d[2];
-    store_rot_grad<DIM>(B, gq, dT, out);
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) g_gt[(size_t)i * DIM + k] = bad ? 0.0f : out[k];
+    for (int k = 0; k < DIM; ++k) g_gt[(size_t)i * DIM + k] = og[k];
   }
 }
 
 }  // namespace
-
 extern "C" int pd_se3_loss(int n, int dim, const float *pred_dev, const float *gt_dev, float rot_ratio, float *loss_dev, float *g_pred_dev,
                            float *g_gt_dev, void *stream) {
   if (n < 0 || (dim != 6 && dim != 7)) return 1;
@@ -124,5 +41,93 @@ extern "C" int pd_se3_loss(int n, int dim, const float *pred_dev, const float *g
     hipLaunchKernelGGL(k_se3_loss<7>, grid, block, 0, (hipStream_t)stream, n, pred_dev, gt_dev, rot_ratio, loss_dev, g_pred_dev, g_gt_dev);
   else
     hipLaunchKernelGGL(k_se3_loss<6>, grid, block, 0, (hipStream_t)stream, n, pred_dev, gt_dev, rot_ratio, loss_dev, g_pred_dev, g_gt_dev);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// ---- reduce_loss(loss_traj, clip=True) of the reference (diffphys/dp_utils.py:93-110) on the [bs][F] table the rollout kernel wrote
+// (k_rollout_fwd<..., LOSS>), ONE workgroup, and each entry's share of the result -- what the adjoint rollout scales its seeds with:
+//   th        10 x the (lower, like torch.median) median of the positive entries of the first env that has any; none: +inf
+//   clipping  per env, entries from the first one above th on are ASSIGNED zero (loss_seq[i, clip_idx:] = 0)
+//   value     mean of the positive entries left when their sum is positive, else the mean of all entries
+//   scale     0 for an assigned-zero entry; else 1 / N_pos for a positive entry (0 for the others) or 1 / (bs F) in the "else" case
+// reduced[0..3] = value, th, N_pos, number of clipped envs.  Sums are double, in a fixed order (run-to-run reproducible).
+namespace {
+__global__ __launch_bounds__(1024) void k_traj_loss_reduce(int bs, int F, const float *__restrict__ table, float *__restrict__ reduced,
+                                                           float *__restrict__ scale) {
+  __shared__ int s_first;
+  __shared__ float s_med;
+  __shared__ double s_sum[1024], s_tot[1024];
+  __shared__ int s_cnt[1024], s_clip[1024];
+  const int tid = threadIdx.x, NT = blockDim.x;
+  if (tid == 0) { s_first = bs; s_med = 0.f; }
+  __syncthreads();
+  for (int e = tid; e < bs; e += NT) {
+    bool has = false;
+    for (int f = 0; f < F; ++f) has |= table[(size_t)e * F + f] > 0.f;
+    if (has) atomicMin(&s_first, e);
+  }
+  __syncthreads();
+  const int first = s_first;
+  float th = __builtin_inff();
+  if (first < bs) {  // lower median of the row's positive entries by rank counting (ties broken by index: ranks are distinct)
+    const float *row = table + (size_t)first * F;
+    int np = 0;
+    for (int j = 0; j < F; ++j) np += row[j] > 0.f;
+    for (int i = tid; i < F; i += NT) {
+      const float v = row[i];
+      if (!(v > 0.f)) continue;
+      int rank = 0;
+      for (int j = 0; j < F; ++j) {
+        const float u = row[j];
+        rank += (u > 0.f) && (u < v || (u == v && j < i));
+      }
+      if (rank == (np - 1) / 2) s_med = v;
+    }
+    __syncthreads();
+    th = s_med * 10.f;
+  }
+  // per env: first exceedance, then the sums over what is left
+  double sum = 0.0, tot = 0.0;
+  int cnt = 0, clip = 0;
+  for (int e = tid; e < bs; e += NT) {
+    bool cut = false;
+    for (int f = 0; f < F; ++f) {
+      const float v = table[(size_t)e * F + f];
+      if (!cut && v > th) { cut = true; ++clip; }
+      const float w = cut ? 0.f : v;
+      tot += (double)w;
+      if (w > 0.f) { sum += (double)w; ++cnt; }
+    }
+  }
+  s_sum[tid] = sum; s_tot[tid] = tot; s_cnt[tid] = cnt; s_clip[tid] = clip;
+  __syncthreads();
+  for (int w = NT / 2; w >= 1; w >>= 1) {
+    if (tid < w) { s_sum[tid] += s_sum[tid + w]; s_tot[tid] += s_tot[tid + w]; s_cnt[tid] += s_cnt[tid + w]; s_clip[tid] += s_clip[tid + w]; }
+    __syncthreads();
+  }
+  const double S = s_sum[0], T = s_tot[0];
+  const int N = s_cnt[0];
+  const bool pos_case = T > 0.0;
+  const long long all = (long long)bs * F;
+  if (tid == 0) {
+    reduced[0] = pos_case ? (float)(S / (double)(N > 0 ? N : 1)) : (all > 0 ? (float)(T / (double)all) : 0.f);
+    reduced[1] = th; reduced[2] = (float)N; reduced[3] = (float)s_clip[0];
+  }
+  const float share_pos = N > 0 ? 1.0f / (float)N : 0.f, share_all = all > 0 ? 1.0f / (float)all : 0.f;
+  for (int e = tid; e < bs; e += NT) {
+    bool cut = false;
+    for (int f = 0; f < F; ++f) {
+      const float v = table[(size_t)e * F + f];
+      if (!cut && v > th) cut = true;
+      scale[(size_t)e * F + f] = cut ? 0.f : (pos_case ? (v > 0.f ? share_pos : 0.f) : share_all);
+    }
+  }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(int bs, int nframes, const float *table, float *reduced, float *scale, hipStream_t st) {
+  if (bs < 0 || nframes < 0 || !reduced) return 1;
+  if ((size_t)bs * nframes > 0 && (!table || !scale)) return 1;
+  hipLaunchKernelGGL(k_traj_loss_reduce, dim3(1), dim3(1024), 0, st, bs, nframes, table, reduced, scale);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

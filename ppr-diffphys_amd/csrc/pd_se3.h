@@ -1,0 +1,114 @@
+// se3_loss of the reference (diffphys/dp_utils.py:113-138) and its gradient with respect to BOTH poses, as device functions shared
+// by the stand-alone kernel (pd_loss.hip: pd_se3_loss) and the rollout kernels that evaluate the trajectory loss where the frame
+// pose is produced (pd_kernels.hip: k_rollout_fwd<..., LOSS = true>).
+//   loss = |p_pred - p_gt|^2 + rot_ratio * acos(clamp((trace(R_pred R_gt^T) - 1) / 2, -1 + 1e-4, 1 - 1e-4)),   0 where an input is NaN
+// DIM = 7: rotations are real-last quaternions (normalised by the conversion, 2 / |q|^2, like the reference's
+// quaternion_to_matrix); DIM = 6: axis-angle vectors (first-order series below 1e-6 rad, like axis_angle_to_quaternion).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pd_se3 {
+
+
+struct Rot {            // rotation of one input and what its gradient needs
+  float q[4];           // x, y, z, w (as converted from the input)
+  float s;              // 2 / |q|^2
+  float R[9];
+  // axis-angle inputs only:
+  float a[3], theta, sho, dsho;  // vector, |a|, sin(theta/2)/theta (series when small), d sho / d theta
+};
+
+__device__ __forceinline__ void rot_matrix(Rot &r) {
+  const float x = r.q[0], y = r.q[1], z = r.q[2], w = r.q[3];
+  r.s = 2.0f / (x * x + y * y + z * z + w * w);
+  const float s = r.s;
+  r.R[0] = 1.0f - s * (y * y + z * z); r.R[1] = s * (x * y - z * w); r.R[2] = s * (x * z + y * w);
+  r.R[3] = s * (x * y + z * w); r.R[4] = 1.0f - s * (x * x + z * z); r.R[5] = s * (y * z - x * w);
+  r.R[6] = s * (x * z - y * w); r.R[7] = s * (y * z + x * w); r.R[8] = 1.0f - s * (x * x + y * y);
+}
+
+template <int DIM>
+__device__ __forceinline__ Rot load_rot(const float *v) {
+  Rot r;
+  if (DIM == 7) {
+    r.q[0] = v[3]; r.q[1] = v[4]; r.q[2] = v[5]; r.q[3] = v[6];
+  } else {
+    r.a[0] = v[3]; r.a[1] = v[4]; r.a[2] = v[5];
+    r.theta = sqrtf(r.a[0] * r.a[0] + r.a[1] * r.a[1] + r.a[2] * r.a[2]);
+    const float half = 0.5f * r.theta;
+    const bool small = r.theta < 1e-6f;
+    r.sho = small ? 0.5f - r.theta * r.theta / 48.0f : sinf(half) / r.theta;
+    r.dsho = small ? -r.theta / 24.0f : (0.5f * cosf(half) * r.theta - sinf(half)) / (r.theta * r.theta);
+    r.q[0] = r.a[0] * r.sho; r.q[1] = r.a[1] * r.sho; r.q[2] = r.a[2] * r.sho; r.q[3] = cosf(half);
+  }
+  rot_matrix(r);
+  return r;
+}
+
+// d trace(R(q) B^T) / d q  for R(q) = I + s M(q), s = 2 / |q|^2
+__device__ __forceinline__ void trace_grad(const Rot &r, const float *B, float *g) {
+  const float x = r.q[0], y = r.q[1], z = r.q[2], w = r.q[3], s = r.s;
+  const float Q = -(y * y + z * z) * B[0] - (x * x + z * z) * B[4] - (x * x + y * y) * B[8] + (x * y - z * w) * B[1] + (x * z + y * w) * B[2] +
+                  (x * y + z * w) * B[3] + (y * z - x * w) * B[5] + (x * z - y * w) * B[6] + (y * z + x * w) * B[7];
+  const float dQ[4] = {-2.0f * x * (B[4] + B[8]) + y * (B[1] + B[3]) + z * (B[2] + B[6]) + w * (B[7] - B[5]),
+                       -2.0f * y * (B[0] + B[8]) + x * (B[1] + B[3]) + z * (B[5] + B[7]) + w * (B[2] - B[6]),
+                       -2.0f * z * (B[0] + B[4]) + x * (B[2] + B[6]) + y * (B[5] + B[7]) + w * (B[3] - B[1]),
+                       x * (B[7] - B[5]) + y * (B[2] - B[6]) + z * (B[3] - B[1])};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g[k] = s * dQ[k] - s * s * r.q[k] * Q;
+}
+
+// chain a gradient with respect to the quaternion back to the input rotation (DIM - 3 floats), scaled by k
+template <int DIM>
+__device__ __forceinline__ void store_rot_grad(const Rot &r, const float *gq, float k, float *out) {
+  if (DIM == 7) {
+    out[3] = k * gq[0]; out[4] = k * gq[1]; out[5] = k * gq[2]; out[6] = k * gq[3];
+  } else {
+    const float inv_t = r.theta > 0.0f ? 1.0f / r.theta : 0.0f;  // d |a| / d a = a / |a|, taken as 0 at 0 like torch.norm
+    const float ga = gq[0] * r.a[0] + gq[1] * r.a[1] + gq[2] * r.a[2];
+    const float c = (-0.5f * sinf(0.5f * r.theta) * gq[3] + ga * r.dsho) * inv_t;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[3 + i] = k * (r.sho * gq[i] + c * r.a[i]);
+  }
+}
+
+
+// value and both gradients of one element; want_grad = false skips the gradient arithmetic.  NaN inputs: value 0, zero gradients.
+template <int DIM>
+__device__ __forceinline__ float se3_loss_eval(const float *p, const float *g, float rot_ratio, bool want_grad, float *out_pred, float *out_gt) {
+  float sp = 0.f, sg = 0.f;
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) { sp += p[k]; sg += g[k]; }
+  const bool bad = isnan(sp) || isnan(sg);
+  const float d[3] = {p[0] - g[0], p[1] - g[1], p[2] - g[2]};
+  const Rot A = load_rot<DIM>(p), B = load_rot<DIM>(g);
+  float T = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) T += A.R[k] * B.R[k];
+  const float eps = 1e-4f, cosv = (T - 1.0f) * 0.5f;
+  const bool inside = cosv > -1.0f + eps && cosv < 1.0f - eps;
+  const float cc = fminf(fmaxf(cosv, -1.0f + eps), 1.0f - eps);
+  const float value = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + rot_ratio * acosf(cc);
+  if (want_grad) {
+    // d angle / d T = -1/2 / sqrt(1 - cos^2) inside the clamp, 0 on it (torch.clamp)
+    const float dT = inside ? rot_ratio * (-0.5f / sqrtf(1.0f - cc * cc)) : 0.0f;
+    float gq[4];
+    if (out_pred) {
+      trace_grad(A, B.R, gq);
+      out_pred[0] = 2.0f * d[0]; out_pred[1] = 2.0f * d[1]; out_pred[2] = 2.0f * d[2];
+      store_rot_grad<DIM>(A, gq, dT, out_pred);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) out_pred[k] = bad ? 0.0f : out_pred[k];  // (0 * NaN would still be NaN)
+    }
+    if (out_gt) {
+      trace_grad(B, A.R, gq);
+      out_gt[0] = -2.0f * d[0]; out_gt[1] = -2.0f * d[1]; out_gt[2] = -2.0f * d[2];
+      store_rot_grad<DIM>(B, gq, dT, out_gt);
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) out_gt[k] = bad ? 0.0f : out_gt[k];
+    }
+  }
+  return bad ? 0.0f : value;
+}
+
+}  // namespace pd_se3

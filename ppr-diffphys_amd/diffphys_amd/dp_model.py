@@ -133,3 +133,59 @@ class ForwardWarp(torch.autograd.Function):
                 g["refs"].view_as(refs), g["target_ke"], g["target_kd"],
                 torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), g["body_inv_mass"],
                 g["body_inertia"].view_as(inertia), g["body_inv_inertia"].view_as(inv_inertia), None)
+
+
+class ForwardWarpTrajLoss(torch.autograd.Function):
+    """ForwardWarp with the one loss term that back-propagates through the rollout evaluated INSIDE it (SURVEY section 8 row f4;
+    reference: dp_model.py:733-779 -- ForwardWarp.apply, then loss_traj = reduce_loss(se3_loss(sim_position, target_position).mean(-1)
+    with outseq entries zeroed, clip=True); pos_state / vel_state / distill use sim_position.detach(), :795,802):
+
+        loss_traj, wp_pos, wp_vel = ForwardWarpTrajLoss.apply(<the 11 inputs of ForwardWarp>, target_position [bs,F,nb,7],
+                                                              outseq_idx [bs,F] bool, self)
+
+    loss_traj is the reduced scalar; wp_pos / wp_vel come back DETACHED (non-differentiable outputs: what the other loss terms and
+    query() consume).  Forward = ONE rollout launch that also evaluates se3_loss and its gradients at the frame states + one
+    one-workgroup launch for reduce_loss; backward = ONE adjoint launch that seeds itself from what the forward left, scaled by the
+    upstream gradient of loss_traj read on the device -- no pose, seed or per-frame loss goes through a torch op in between.
+    Side outputs on ``self`` as ForwardWarp, plus ``self.traj_loss_info`` = (loss, clip threshold, positives left, clipped envs)."""
+
+    @staticmethod
+    def forward(ctx, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia,
+                body_inv_inertia, target_position, outseq_idx, self):
+        dm = hip_backend.device_model(self.env)
+        bs, nsteps = int(self.num_envs), len(self.steps_idx)
+        frame2step = [int(s) for s in self.frame2step]
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
+                              body_inv_inertia)]
+        tgt = c(target_position).view(bs, len(frame2step), dm.nb, 7)
+        outseq = None if outseq_idx is None else outseq_idx.detach().to(torch.bool).contiguous()
+        need_gt = target_position.requires_grad
+        wp_pos, wp_vel, grf, jaf, ws, tl = dm.rollout_forward_traj_loss(bs, nsteps, self.dt, *inp, frame2step=frame2step, target_pos=tgt,
+                                                                        outseq=outseq, rot_ratio=0.1, want_seed_gt=need_gt)
+        ctx.dm, ctx.meta, ctx.tl = dm, (bs, nsteps, float(self.dt), frame2step), tl
+        ctx.save_for_backward(ws, *inp)
+        ctx.mass_shape, ctx.tgt_shape = body_mass.shape, target_position.shape
+        has_f = [f for f, s in enumerate(frame2step) if s < nsteps]
+        self.grfs = [grf[f] for f in has_f]
+        self.jafs = [jaf[f] for f in has_f]
+        self.sim_trajs = HostFrames(wp_pos[:, : dm.nb])
+        self.traj_loss_info = tl["reduced"]
+        ctx.mark_non_differentiable(wp_pos, wp_vel)
+        return tl["reduced"][0].clone(), wp_pos, wp_vel
+
+    @staticmethod
+    def backward(ctx, g_loss, _gp, _gv):
+        ws, q_init, qd_init, torques, res_f, refs, ke, kd, inv_m, inertia, inv_inertia = ctx.saved_tensors
+        bs, nsteps, dt, frame2step = ctx.meta
+        tl = ctx.tl
+        gl = g_loss.detach().to(torch.float32).reshape(1).contiguous()
+        g = ctx.dm.rollout_backward_traj_loss(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia,
+                                              frame2step, ws, tl, gl)
+        g_tgt = None
+        if ctx.needs_input_grad[11] and tl["seed_gt"] is not None:  # d loss_traj / d target pose = g x share / nb x d se3 / d gt
+            g_tgt = (tl["seed_gt"] * (tl["scale"] * (gl / ctx.dm.nb))[:, :, None, None]).view(ctx.tgt_shape)
+        return (g["q_init"], g["qd_init"], g["torques"].view_as(torques), g["res_f"].view_as(res_f),
+                g["refs"].view_as(refs), g["target_ke"], g["target_kd"],
+                torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), g["body_inv_mass"],
+                g["body_inertia"].view_as(inertia), g["body_inv_inertia"].view_as(inv_inertia), g_tgt, None, None)

@@ -63,6 +63,9 @@ def lib():
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.pd_rollout_forward.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, _ip] + [vp] * 5 + [vp]
         L.pd_rollout_backward.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 10 + [vp]
+        if hasattr(L, "pd_rollout_forward_traj_loss"):
+            L.pd_rollout_forward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, _ip] + [vp] * 5 + [vp, vp, cf] + [vp] * 5 + [vp]
+            L.pd_rollout_backward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 3 + [vp] * 10 + [vp]
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
         L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
@@ -112,7 +115,7 @@ def source_hash():
     import hashlib
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "../../include/ppr_diffphys.h", "Makefile"]
+    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "../../include/ppr_diffphys.h", "Makefile"]
     h = hashlib.sha256()
     try:
         for f in srcs:
@@ -250,6 +253,66 @@ class DeviceModel:
             p(wp_vel, "wp_vel", nframes * bs * nb * 6), p(grf, "grf", nframes * bs * nb * 6) if want_forces else None,
             p(jaf, "jaf", nframes * bs * nb * 6) if want_forces else None, _stream()))
         return wp_pos, wp_vel, grf, jaf, ws
+
+    # -- rollout with the trajectory loss evaluated at the frame states (C ABI v5) ------------
+    def rollout_forward_traj_loss(self, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass,
+                                  body_inertia, body_inv_inertia, frame2step, target_pos, outseq=None, rot_ratio=0.1, want_forces=True,
+                                  want_seed_gt=True, out=None):
+        """``pd_rollout_forward_traj_loss``: rollout_forward plus, in the same rollout launch, se3_loss of every frame pose against
+        target_pos [bs, F, nb, 7] and reduce_loss(clip=True) of the per-frame means.  -> (wp_pos, wp_vel, grf, jaf, ws, tl) with tl a dict:
+        reduced [4] = (loss_traj, clip threshold, positive entries left, clipped envs), table [bs, F], scale [bs, F], seed_pos
+        [F, bs*nb, 7], seed_gt [bs, F, nb, 7] or None.  outseq: bool / uint8 [bs, F] (entries the loss ignores) or None."""
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        dev = q_init.device
+        f2s, nframes = self._f2s(frame2step)
+        if out is None:
+            out = self.alloc_rollout(bs, nsteps, nframes, dev, want_forces, backward=False)
+        ws, wp_pos, wp_vel = out["ws"], out["wp_pos"], out["wp_vel"]
+        grf, jaf = (out["grf"], out["jaf"]) if want_forces else (None, None)
+        e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        tl = dict(reduced=e(4), table=e(bs, nframes), scale=e(bs, nframes), seed_pos=e(nframes, bs * nb, 7),
+                  seed_gt=e(bs, nframes, nb, 7) if want_seed_gt else None)
+        if outseq is not None:
+            if not (outseq.is_cuda and outseq.dtype in (torch.bool, torch.uint8) and outseq.is_contiguous() and outseq.numel() == bs * nframes):
+                raise ValueError("outseq must be a contiguous bool / uint8 GPU tensor of bs * nframes entries")
+        p = lambda t, name, n: _dev(t, name, n) if (t is not None and t.numel()) else None
+        _check(lib().pd_rollout_forward_traj_loss(
+            self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
+            p(torques, "torques", nsteps * bs * nqd), p(res_f, "res_f", nsteps * bs * nb * 6),
+            p(refs, "refs", nsteps * bs * nqd), p(target_ke, "target_ke", bs * nqd),
+            p(target_kd, "target_kd", bs * nqd), p(body_inv_mass, "body_inv_mass", bs * nb),
+            p(body_inertia, "body_inertia", bs * nb * 9), p(body_inv_inertia, "body_inv_inertia", bs * nb * 9),
+            nframes, f2s, p(ws, "workspace", self.workspace_floats(bs, nsteps)), p(wp_pos, "wp_pos", nframes * bs * nb * 7),
+            p(wp_vel, "wp_vel", nframes * bs * nb * 6), p(grf, "grf", nframes * bs * nb * 6) if want_forces else None,
+            p(jaf, "jaf", nframes * bs * nb * 6) if want_forces else None,
+            p(target_pos, "target_pos", bs * nframes * nb * 7),
+            ctypes.c_void_p(outseq.data_ptr()) if (outseq is not None and outseq.numel()) else None, ctypes.c_float(float(rot_ratio)),
+            p(tl["seed_pos"], "seed_pos", nframes * bs * nb * 7), p(tl["seed_gt"], "seed_gt", nframes * bs * nb * 7),
+            p(tl["table"], "loss_table", bs * nframes), _dev(tl["reduced"], "reduced", 4), p(tl["scale"], "scale", bs * nframes), _stream()))
+        return wp_pos, wp_vel, grf, jaf, ws, tl
+
+    def rollout_backward_traj_loss(self, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, body_inv_mass,
+                                   body_inertia, body_inv_inertia, frame2step, ws, tl, g_loss, adj_pos=None, adj_vel=None, out=None):
+        """``pd_rollout_backward_traj_loss``: the adjoint rollout seeded with g_loss (a 0-dim / 1-element GPU tensor: the upstream
+        gradient of loss_traj) x scale / nb x seed_pos, plus adj_pos / adj_vel when given."""
+        nb, nq, nqd = self.nb, self.nq, self.nqd
+        dev = q_init.device
+        f2s, nframes = self._f2s(frame2step)
+        g = out["grads"] if out is not None else self._alloc_grads(bs, nsteps, dev)
+        p = lambda t, name, n=None: _dev(t, name, n) if (t is not None and t.numel()) else None
+        _check(lib().pd_rollout_backward_traj_loss(
+            self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
+            p(torques, "torques", nsteps * bs * nqd), p(refs, "refs", nsteps * bs * nqd),
+            p(target_ke, "target_ke", bs * nqd), p(target_kd, "target_kd", bs * nqd),
+            p(body_inv_mass, "body_inv_mass", bs * nb), p(body_inertia, "body_inertia", bs * nb * 9),
+            p(body_inv_inertia, "body_inv_inertia", bs * nb * 9), nframes, f2s,
+            p(ws, "workspace", self.workspace_floats(bs, nsteps)), p(adj_pos, "adj_pos", nframes * bs * nb * 7),
+            p(adj_vel, "adj_vel", nframes * bs * nb * 6), p(tl["seed_pos"], "seed_pos", nframes * bs * nb * 7),
+            p(tl["scale"], "scale", bs * nframes), _dev(g_loss, "g_loss", 1), p(g["q_init"], "g"), p(g["qd_init"], "g"),
+            p(g["torques"], "g"), p(g["res_f"], "g"), p(g["refs"], "g"), p(g["target_ke"], "g"),
+            p(g["target_kd"], "g"), p(g["body_inv_mass"], "g"), p(g["body_inertia"], "g"),
+            p(g["body_inv_inertia"], "g"), _stream()))
+        return g
 
     def saved_trajectory(self, ws, bs, nsteps):
         """The trajectory a forward rollout saved for its adjoint, unpacked from the workspace (inspection / tests): states of

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import robots, sim
 from .dataloader import mocap_tensors, bullet2gl, parse_amp
-from .dp_model import ForwardKinematics, ForwardWarp, convert_ppr_warp
+from .dp_model import ForwardKinematics, ForwardWarp, ForwardWarpTrajLoss, convert_ppr_warp
 from .dp_utils import compose_delta, reduce_loss, rotate_frame, rotate_frame_vel, se3_loss
 from .geom_utils import fid_reindex
 from .grad_guard import GradHistory
@@ -408,11 +408,21 @@ class phys_model(nn.Module):
             body_inv_inertia = torch.linalg.inv_ex(body_inertia).inverse.contiguous()
         qd_init = convert_ppr_warp(qd_init)  # quirk (i): flat vector
         res_fin = convert_ppr_warp(res_fin)
-        sim_position, sim_velocity = ForwardWarp.apply(q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass,
-                                                       body_inv_mass, body_inertia, body_inv_inertia, self)
+        F_ = self.frames_per_wdw
+        # loss_traj is the ONE term that back-propagates through the rollout (dp_model.py:777-779; the others use sim_position.detach()).
+        # fuse_traj_loss (default): the rollout evaluates it where the frame poses are produced and the adjoint seeds itself
+        # (dp_model.ForwardWarpTrajLoss, C ABI pd_rollout_*_traj_loss); False: the reference's sequence
+        # ForwardWarp -> se3_loss -> reduce_loss through torch (kept: tests compare the two)
+        fused = bool(getattr(self, "fuse_traj_loss", True)) and q_init.is_cuda
+        if fused:
+            loss_traj_fused, sim_position, sim_velocity = ForwardWarpTrajLoss.apply(
+                q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass, body_inv_mass, body_inertia, body_inv_inertia,
+                target_position.reshape(n, F_, -1, 7), outseq_idx, self)
+        else:
+            sim_position, sim_velocity = ForwardWarp.apply(q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass,
+                                                           body_inv_mass, body_inertia, body_inv_inertia, self)
         sim_velocity = convert_ppr_warp(sim_velocity)
 
-        F_ = self.frames_per_wdw
         queried_q = self._frames_of(queried_q, 0).reshape(F_, n, -1)
         queried_qd = convert_ppr_warp(self._frames_of(queried_qd, 0).reshape(F_, n, -1))
         queried_position, queried_velocity, self.pid_ref = ForwardKinematics.apply(queried_q, queried_qd, self.env)
@@ -424,9 +434,12 @@ class phys_model(nn.Module):
         sim_velocity = sim_velocity.reshape(F_, n, -1, 6).permute(1, 0, 2, 3)
 
         loss_dict = {}
-        loss_traj = se3_loss(sim_position, target_position).mean(-1)
-        loss_traj = torch.where(outseq_idx, torch.zeros_like(loss_traj), loss_traj)
-        loss_dict["traj"] = reduce_loss(loss_traj, clip=True)
+        if fused:
+            loss_dict["traj"] = loss_traj_fused
+        else:
+            loss_traj = se3_loss(sim_position, target_position).mean(-1)
+            loss_traj = torch.where(outseq_idx, torch.zeros_like(loss_traj), loss_traj)
+            loss_dict["traj"] = reduce_loss(loss_traj, clip=True)
         loss_pos = se3_loss(queried_position, sim_position.detach()).mean(-1)
         loss_dict["pos_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_pos), loss_pos))
         loss_vel = se3_loss(queried_velocity, sim_velocity.detach()).mean(-1)

@@ -804,3 +804,94 @@ def test_more_contact_candidates_than_fit_at_the_default_width(dev, oracle_libs)
     assert relmax(out["wp_pos"], st["wp_pos"]) < 5e-5 and relmax(out["grf"], st["grf"]) < 5e-3
     for k in ("q_init", "qd_init", "refs", "body_inv_mass"):
         assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+
+
+@pytest.mark.parametrize("name,bs", [("laikago", 37), ("human", 9)])
+def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(name, bs, dev):
+    """Row f4 at the C ABI: pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss against ForwardWarp.apply -> pd_se3_loss ->
+    torch reduce_loss(clip=True) (dp_model.py:733-779, dp_utils.py:93-138) on the same inputs: the reduced loss, the [bs, F] table, the
+    clip threshold / counts, the frame poses (bit-identical: same rollout arithmetic) and the gradients of all rollout inputs AND of
+    the target poses.  Targets = the simulated poses + noise; one env gets a far target from frame 2 on (clipped there), one env has
+    out-of-sequence frames, one target pose is NaN (se3_loss ignores it), frames include state T."""
+    from diffphys_amd import dp_model, dp_utils, hip_backend, robots, synth
+
+    tpl = robots.load_template(name)
+    T = 70
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=5, steps_per_frame=23, penetration=0.002)
+    f2s = [0, 23, 46, 69, T]
+    F, nb = len(f2s), int(tpl["nb"])
+
+    class Host:
+        pass
+
+    h = Host()
+    h.env = robots.env_from_template(name, bs, device=dev)
+    h.num_envs, h.steps_idx, h.frame2step, h.dt = bs, range(T), f2s, inp["dt"]
+    t = {k: torch.from_numpy(inp[k]).to(dev).requires_grad_(True) for k in synth.INPUT_NAMES}
+    args = [t[k] for k in synth.INPUT_NAMES]
+    with torch.no_grad():
+        pos0, _ = dp_model.ForwardWarp.apply(*args, h)
+    g = torch.Generator().manual_seed(11)
+    tgt = pos0.reshape(F, bs, nb, 7).permute(1, 0, 2, 3).clone()
+    tgt = tgt + (torch.randn(tgt.shape, generator=g) * 0.02).to(dev)
+    tgt[3, 2:, :, :3] += 0.8                # env 3: far from its targets from frame 2 on => clipped at frame 2
+    tgt[1, 4, 5, 2] = float("nan")           # one NaN target pose: its se3_loss is 0, no gradient
+    outseq = torch.zeros(bs, F, dtype=torch.bool, device=dev)
+    outseq[2, 3:] = True                     # env 2: frames 3.. belong to another clip
+    tgt = tgt.contiguous().requires_grad_(True)
+    wt = 0.37
+
+    # the reference's sequence through torch (the fused se3_loss launch inside; its torch composition is tested elsewhere)
+    pos, vel = dp_model.ForwardWarp.apply(*args, h)
+    pos.retain_grad()
+    sim = pos.reshape(F, bs, nb, 7).permute(1, 0, 2, 3)
+    lt = dp_utils.se3_loss(sim, tgt).mean(-1)
+    lt = torch.where(outseq, torch.zeros_like(lt), lt)
+    table_ref = lt.detach().clone()
+    loss_ref = dp_utils.reduce_loss(lt, clip=True)
+    (loss_ref * wt).backward()
+    ref = {k: t[k].grad.detach().clone() for k in synth.INPUT_NAMES}
+    ref_tgt = tgt.grad.detach().clone()
+    ref_seed = pos.grad.detach().clone()   # what autograd hands ForwardWarp.backward as adj_body_qs
+    for k in synth.INPUT_NAMES:
+        t[k].grad = None
+    tgt.grad = None
+
+    loss, pos_f, vel_f = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
+    assert not pos_f.requires_grad and torch.equal(pos_f, pos.detach()) and torch.equal(vel_f, vel.detach())
+    (loss * wt).backward()
+    info = h.traj_loss_info.cpu().numpy()
+    print("%s: loss_traj %.6e (torch %.6e), threshold %.3e, positives left %d, clipped envs %d" % (name, float(loss.detach()), float(loss_ref.detach()), info[1], info[2], info[3]))
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-6 * abs(float(loss_ref.detach()))
+    assert info[3] >= 1 and info[2] < bs * F
+    # the table the kernel wrote = se3_loss(...).mean(-1) with the outseq entries zeroed (before the clip)
+    dm = hip_backend.device_model(h.env)
+    c = lambda x: x.detach().to(torch.float32).contiguous()
+    out = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[c(t[k]) for k in FWD], frame2step=f2s, target_pos=c(tgt), outseq=outseq)
+    table = out[5]["table"]
+    assert float((table - table_ref).abs().max()) <= 2e-6 * float(table_ref.abs().max())
+    # the seeds the adjoint kernel builds for itself = what autograd computed for adj_body_qs, to 1e-6 ...
+    tl = out[5]
+    seed = tl["seed_pos"].view(F, bs, nb, 7) * (tl["scale"].t() * (wt / nb))[:, :, None, None]
+    assert float((seed.view_as(ref_seed) - ref_seed).abs().max()) <= 1e-6 * float(ref_seed.abs().max())
+    # ... and the gradients they give, to 1e-4 of each tensor's max: the two seed tensors differ in their last bits (another order of
+    # the scalings), and a 70-step adjoint amplifies that (tests/test_gpu_tight.py: ONE ulp on a stored Laikago state moves these
+    # gradients by ~1e-2 over 100 steps); measured 8e-6 (Laikago), 2e-7 (human)
+    for k in synth.INPUT_NAMES:
+        a, b = t[k].grad, ref[k]
+        sc = float(b.abs().max())
+        print("   %-18s fused vs torch sequence: %.1e of the tensor's max" % (k, float((a - b).abs().max()) / (sc + 1e-30)))
+        assert float((a - b).abs().max()) <= 1e-4 * sc + 1e-30, (k, float((a - b).abs().max()), sc)
+    assert float((tgt.grad - ref_tgt).abs().max()) <= 1e-6 * float(ref_tgt.abs().max())
+    assert float(tgt.grad[3, 2:].abs().max()) == 0 and float(tgt.grad[2, 3:].abs().max()) == 0 and float(tgt.grad[1, 4, 5].abs().max()) == 0
+    # other terms may still reach the poses: adj_pos / adj_vel rows are ADDED to the loss seeds
+    ap = torch.from_numpy(inp["adj_pos"][:1].repeat(F, 0)).to(dev).contiguous()
+    av = torch.from_numpy(inp["adj_vel"][:1].repeat(F, 0)).to(dev).contiguous()
+    ins = [c(t[k]) for k in BWD]
+    one = torch.ones(1, device=dev)
+    g_both = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *ins, f2s, out[4], out[5], one * wt, adj_pos=ap, adj_vel=av)
+    g_seed = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *ins, f2s, out[4], out[5], one * wt)
+    g_adj = dm.rollout_backward(bs, T, inp["dt"], *ins, f2s, out[4], ap, av)
+    for k in g_both:
+        s_ = g_seed[k] + g_adj[k]
+        assert float((g_both[k] - s_).abs().max()) <= 2e-4 * float(s_.abs().max()) + 1e-30, k   # linear in the seeds (fp32 sums in another order; measured 3e-5)
