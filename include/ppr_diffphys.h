@@ -142,8 +142,9 @@ int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
  * d loss_traj / d table entry (0 for entries the clip / outseq assigned zero).  wp_pos / wp_vel / grf / jaf as pd_rollout_forward.
  * pd_rollout_backward_traj_loss = pd_rollout_backward whose frame seeds are  g_loss_dev[0] * scale[env][frame] / nb * seed_pos
  * (g_loss_dev: DEVICE scalar, the upstream gradient of loss_traj, e.g. traj_wt) PLUS the rows of adj_pos_dev / adj_vel_dev when
- * those are given (both or neither; NULL = no other term reaches the poses).  No pose or seed passes through the host framework
- * between the two launches, no se3_loss launch, no reduce_loss ops. */
+ * those are given (both or neither; NULL = no other term reaches the poses); they are built by a small launch into
+ * seed_work_dev (F * bs * nb * 13 floats of caller-owned scratch) in front of the adjoint rollout launch.  No pose or seed passes
+ * through the host framework between the launches, no se3_loss launch, no reduce_loss ops. */
 int pd_rollout_forward_traj_loss(const pd_model *m, int bs, int nsteps, float dt,
                                  const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
                                  const float *res_f_dev, const float *refs_dev, const float *target_ke_dev,
@@ -161,7 +162,7 @@ int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float d
                                   const float *body_inv_inertia_dev, int nframes, const int *frame2step_host,
                                   const float *workspace_dev, const float *adj_pos_dev, const float *adj_vel_dev,
                                   const float *seed_pos_dev, const float *scale_dev, const float *g_loss_dev,
-                                  float *g_q_init_dev, float *g_qd_init_dev, float *g_torques_dev, float *g_res_f_dev,
+                                  float *seed_work_dev, float *g_q_init_dev, float *g_qd_init_dev, float *g_torques_dev, float *g_res_f_dev,
                                   float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
                                   float *g_body_inv_mass_dev, float *g_body_inertia_dev, float *g_body_inv_inertia_dev,
                                   void *stream);

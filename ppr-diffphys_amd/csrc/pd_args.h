@@ -78,8 +78,6 @@ struct RolloutArgs {
   const unsigned char *loss_outseq;
   float loss_rot_ratio;
   float *loss_seed_pos, *loss_seed_gt, *loss_table;
-  // backward: seeds  seed_gain[0] * seed_scale[env][frame] / nb * seed_pos  are ADDED to those of adj_pos (which may then be null)
-  const float *seed_pos, *seed_scale, *seed_gain;
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
 #ifdef PD_EXPERIMENT        // timing builds only (make experiment): rejected variants, DESIGN.md section 4 / EXPERIMENTS.md
   int own_joint;            // adjoint, 2-role kernel: the body wave recomputes its joint's state-only half itself (measured: slower)

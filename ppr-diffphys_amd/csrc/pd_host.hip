@@ -450,8 +450,10 @@ size_t pd_rollout_workspace_floats(const pd_model *m, int bs, int nsteps) {
 
 // trajectory-loss extras of the two *_traj_loss entries (null = the plain rollout)
 struct TrajLossFwd { const float *target; const unsigned char *outseq; float rot_ratio; float *seed_pos, *seed_gt, *table, *reduced, *scale; };
-struct TrajLossBwd { const float *seed_pos, *scale, *gain; };
+struct TrajLossBwd { const float *seed_pos, *scale, *gain; float *work; };
 extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(int bs, int nframes, const float *table, float *reduced, float *scale, hipStream_t st);  // pd_loss.hip; internal
+extern "C" __attribute__((visibility("hidden"))) int pd_traj_seeds_launch(int bs, int nb, int nframes, const float *seed_pos, const float *scale, const float *gain, const float *adj_pos,
+                                                                         const float *adj_vel, float *work, hipStream_t st);
 
 static int rollout_forward_impl(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
                        const float *torques, const float *res_f, const float *refs, const float *target_ke,
@@ -528,11 +530,15 @@ static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float d
   if (nsteps > 0 && (!torques || !refs || !ws || !g_torques || !g_res_f || !g_refs)) return fail("null device pointer");
   if (!tl && nframes > 0 && (!adj_pos || !adj_vel)) return fail("null device pointer");
   if (tl && ((adj_pos == nullptr) != (adj_vel == nullptr))) return fail("adj_pos and adj_vel come together (both, or neither)");
-  if (tl && nframes > 0 && (!tl->seed_pos || !tl->scale || !tl->gain)) return fail("null device pointer (trajectory loss)");
+  if (tl && nframes > 0 && (!tl->seed_pos || !tl->scale || !tl->gain || !tl->work)) return fail("null device pointer (trajectory loss)");
   if (m->xp_env && m->xp_envs != bs) return fail("joint_X_p is bound for " + std::to_string(m->xp_envs) + " envs, rollout has " + std::to_string(bs));
   RolloutArgs a{};
   a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
-  if (tl && nframes > 0) { a.seed_pos = tl->seed_pos; a.seed_scale = tl->scale; a.seed_gain = tl->gain; }
+  if (tl && nframes > 0) {
+    // the seeds of this sweep, built on the device: work = [F][bs*nb][7] poses then [F][bs*nb][6] twists (pd_loss.hip k_traj_seeds)
+    if (pd_traj_seeds_launch(bs, m->nb, nframes, tl->seed_pos, tl->scale, tl->gain, adj_pos, adj_vel, tl->work, (hipStream_t)stream)) return fail("seed launch failed");
+    adj_pos = tl->work; adj_vel = tl->work + (size_t)nframes * bs * m->nb * 7;
+  }
   a.q_init = q_init; a.qd_init = qd_init; a.torques = torques; a.refs = refs;
   a.target_ke = target_ke; a.target_kd = target_kd; a.inv_mass = inv_mass; a.inertia = inertia; a.inv_inertia = inv_inertia;
   a.frame_of_step = fos; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
@@ -565,9 +571,9 @@ int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float d
                                   const float *torques, const float *refs, const float *target_ke, const float *target_kd,
                                   const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
                                   const float *ws, const float *adj_pos, const float *adj_vel, const float *seed_pos, const float *scale,
-                                  const float *g_loss, float *g_q_init, float *g_qd_init, float *g_torques, float *g_res_f, float *g_refs,
+                                  const float *g_loss, float *seed_work, float *g_q_init, float *g_qd_init, float *g_torques, float *g_res_f, float *g_refs,
                                   float *g_ke, float *g_kd, float *g_inv_mass, float *g_inertia, float *g_inv_inertia, void *stream) {
-  const TrajLossBwd tl{seed_pos, scale, g_loss};
+  const TrajLossBwd tl{seed_pos, scale, g_loss, seed_work};
   return rollout_backward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
                                frame2step, ws, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs, g_ke, g_kd, g_inv_mass,
                                g_inertia, g_inv_inertia, &tl, stream);

@@ -63,27 +63,14 @@ PD_DEV void stg2(float *ubase, unsigned boff, float2 v) { *(float2 *)((char *)ub
 // instead of ten passes over the tensors.
 #define NZ(x) grad_post<1>(x)
 
-// Seeds of a frame state in the reverse sweep (dp_model.py:1264-1271): the caller's adj_pos / adj_vel rows (optional since ABI 5) and
-// / or the trajectory-loss seeds the forward kernel left -- d se3_loss / d pose per body, scaled here by the upstream gradient of the
-// reduced loss (a device scalar), the frame's share of reduce_loss (0 where clipped / out of sequence / not positive, else 1 / N_pos)
-// and the 1 / nb of the mean over bodies (dp_model.py:777-779, dp_utils.py:93-110).
-// TL = false is the plain adjoint (pd_rollout_backward): adj_pos / adj_vel are there, nothing else is looked at -- the headline
-// kernel carries none of the trajectory-loss code (with it behind run-time checks the 2-role adjoint went from 252 VGPRs / no spill
-// to 256 / 36 spilled).
-template <bool TL>
-PD_DEV void add_frame_seeds(const RolloutArgs &a, int fr, int N, size_t idx, int ec, int nb, BodyAdj &gn) {
-  if (!TL || a.adj_pos) {
-    const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
-    gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
-    gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
-  }
-  if (TL && a.seed_pos) {
-    const float k = a.seed_gain[0] * a.seed_scale[(size_t)ec * a.nframes + fr] / (float)nb;
-    const float *sp = a.seed_pos + ((size_t)fr * N + idx) * 7;
-    if (k != 0.0f) {  // a zero share is an assignment in the reference (loss_seq[i, idx:] = 0): nothing flows, not 0 * inf
-      gn.p += V3(sp[0], sp[1], sp[2]) * k; gn.r += Q4(sp[3], sp[4], sp[5], sp[6]) * k;
-    }
-  }
+// Seeds of a frame state in the reverse sweep (dp_model.py:1264-1271).  (pd_rollout_backward_traj_loss builds its seeds into
+// adj_pos / adj_vel with a small launch of its own, pd_loss.hip k_traj_seeds: with the scaling here, behind run-time checks, the
+// 2-role adjoint went from 252 VGPRs / no spill to 256 / 36 spilled, and as a separate instantiation it still ran 0.314 ms
+// against 0.278.)
+PD_DEV void add_frame_seeds(const RolloutArgs &a, int fr, int N, size_t idx, BodyAdj &gn) {
+  const float *gp = a.adj_pos + ((size_t)fr * N + idx) * 7, *gv = a.adj_vel + ((size_t)fr * N + idx) * 6;
+  gn.p += V3(gp[0], gp[1], gp[2]); gn.r += Q4(gp[3], gp[4], gp[5], gp[6]);
+  gn.w += V3(gv[0], gv[1], gv[2]); gn.v += V3(gv[3], gv[4], gv[5]);
 }
 
 template <int SEGW>
@@ -987,7 +974,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
 // =============================================================================================
 // EARLY (SPLIT only): hand-over A is signalled from inside the adjoint of integrate_bodies, as soon as the wrench adjoint
 // exists (integrate_adj2), instead of after it.
-template <int SEGW, int JT, bool SPLIT, bool EARLY = false, bool TL = false>
+template <int SEGW, int JT, bool SPLIT, bool EARLY = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -1206,7 +1193,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     {  // seeds of state step+1 (dp_model.py:1264-1271)
       const int fr = n_fr;
       if (fr >= 0) {
-        add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
+        add_frame_seeds(a, fr, N, idx, gn);
       }
     }
     s.r = Q4(n_s[0].x, n_s[0].y, n_s[0].z, n_s[0].w); s.w = V3(n_s[1].x, n_s[1].y, n_s[1].z);
@@ -1348,7 +1335,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   {  // seeds of state 0
     int fr = a.frame_of_step[0];
     if (fr >= 0) {
-      add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
+      add_frame_seeds(a, fr, N, idx, gn);
     }
   }
   // ---- adjoint of eval_fk: rec holds state 0 (staged in the last loop iteration)
@@ -1413,7 +1400,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 // ROLES = 3: I, C, J waves (<= 168 VGPRs each).  ROLES = 2: the integrate wave also replays the contacts (between its phase 2
 // and the wait for the joint wave) -- compound-joint robots, whose joint adjoint needs more than 168 registers but whose
 // box contacts are a handful of points: two waves per env group, <= 256 VGPRs each.
-template <int SEGW, int JT, int ROLES, bool TL = false>
+template <int SEGW, int JT, int ROLES>
 __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -1785,7 +1772,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   for (int step = a.nsteps - 1; step >= 0; --step) {
     // s, t0, f0, fr and the staged record of `step` are in place (stage_step ran in the previous iteration)
     if (fr >= 0) {  // seeds of state step+1 (dp_model.py:1264-1271)
-      add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
+      add_frame_seeds(a, fr, N, idx, gn);
     }
     // (ROLES == 2) the forward hit list of this step is replayed inline further down: fetch its length now, far ahead
     int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
@@ -1859,7 +1846,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   {  // seeds of state 0
     int fr = a.frame_of_step[0];
     if (fr >= 0) {
-      add_frame_seeds<TL>(a, fr, N, idx, ec, nb, gn);
+      add_frame_seeds(a, fr, N, idx, gn);
     }
   }
   // ---- adjoint of eval_fk: rec holds state 0 (staged in the last loop iteration); the J wave is past its last use of cslot
@@ -1990,10 +1977,7 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
           break;
         }
 #endif
-        if (((const RolloutArgs *)args)->seed_pos)  // seeds from the trajectory loss (pd_rollout_backward_traj_loss)
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-        else
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else {
 #ifdef PD_EXPERIMENT
         if (cfg.kernel == PD_KV_BWD_UNSPLIT) {  // the unsplit round-1 kernel
@@ -2001,10 +1985,7 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
           break;
         }
 #endif
-        if (((const RolloutArgs *)args)->seed_pos)
-          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-        else
-          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
       }
       break;
     case PD_K_FK_FWD:
@@ -2028,14 +2009,12 @@ static hipError_t set_lds_jt(int bytes) {
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #ifdef PD_EXPERIMENT
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #endif
   } else {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #ifdef PD_EXPERIMENT
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #endif

@@ -131,3 +131,35 @@ extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(
   hipLaunchKernelGGL(k_traj_loss_reduce, dim3(1), dim3(1024), 0, st, bs, nframes, table, reduced, scale);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
+// ---- the frame seeds of an adjoint rollout that follows pd_rollout_forward_traj_loss, written where the plain adjoint kernel reads
+// its adj_pos / adj_vel rows:  work_pos [F][bs*nb][7] = gain[0] * scale[env][frame] / nb * seed_pos (+ adj_pos),  work_vel [F][bs*nb][6]
+// = adj_vel or 0.  A zero share is an assignment in the reference (loss_seq[i, idx:] = 0, loss_traj[outseq_idx] = 0): nothing flows
+// through it, not 0 * inf.  A few MB, one pass: ~3 us at the headline size.
+namespace {
+__global__ __launch_bounds__(256) void k_traj_seeds(int bs, int nb, int F, const float *__restrict__ seed_pos, const float *__restrict__ scale,
+                                                    const float *__restrict__ gain, const float *__restrict__ adj_pos,
+                                                    const float *__restrict__ adj_vel, float *__restrict__ work) {
+  const size_t N = (size_t)bs * nb, n_pos = (size_t)F * N * 7, n_all = n_pos + (size_t)F * N * 6;
+  const float g = gain[0] / (float)nb;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_all; i += (size_t)gridDim.x * 256) {
+    if (i < n_pos) {
+      const size_t row = i / 7, f = row / N, e = (row % N) / nb;
+      const float k = g * scale[e * F + f];
+      const float v = k != 0.0f ? k * seed_pos[i] : 0.0f;
+      work[i] = adj_pos ? v + adj_pos[i] : v;
+    } else {
+      work[i] = adj_vel ? adj_vel[i - n_pos] : 0.0f;
+    }
+  }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int pd_traj_seeds_launch(int bs, int nb, int nframes, const float *seed_pos, const float *scale, const float *gain,
+                                                                         const float *adj_pos, const float *adj_vel, float *work, hipStream_t st) {
+  const size_t n = (size_t)nframes * bs * nb * 13;
+  if (n == 0) return 0;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_traj_seeds, dim3(blocks), dim3(256), 0, st, bs, nb, nframes, seed_pos, scale, gain, adj_pos, adj_vel, work);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

@@ -145,8 +145,9 @@ class ForwardWarpTrajLoss(torch.autograd.Function):
 
     loss_traj is the reduced scalar; wp_pos / wp_vel come back DETACHED (non-differentiable outputs: what the other loss terms and
     query() consume).  Forward = ONE rollout launch that also evaluates se3_loss and its gradients at the frame states + one
-    one-workgroup launch for reduce_loss; backward = ONE adjoint launch that seeds itself from what the forward left, scaled by the
-    upstream gradient of loss_traj read on the device -- no pose, seed or per-frame loss goes through a torch op in between.
+    one-workgroup launch for reduce_loss; backward = a few-microsecond launch that builds the seeds from what the forward left, scaled
+    by the upstream gradient of loss_traj read on the device, then the adjoint rollout launch -- no pose, seed or per-frame loss goes
+    through a torch op in between.
     Side outputs on ``self`` as ForwardWarp, plus ``self.traj_loss_info`` = (loss, clip threshold, positives left, clipped envs)."""
 
     @staticmethod

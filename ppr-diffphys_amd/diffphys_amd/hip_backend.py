@@ -65,7 +65,7 @@ def lib():
         L.pd_rollout_backward.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 10 + [vp]
         if hasattr(L, "pd_rollout_forward_traj_loss"):
             L.pd_rollout_forward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, _ip] + [vp] * 5 + [vp, vp, cf] + [vp] * 5 + [vp]
-            L.pd_rollout_backward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 3 + [vp] * 10 + [vp]
+            L.pd_rollout_backward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 4 + [vp] * 10 + [vp]
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
         L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
@@ -299,6 +299,9 @@ class DeviceModel:
         dev = q_init.device
         f2s, nframes = self._f2s(frame2step)
         g = out["grads"] if out is not None else self._alloc_grads(bs, nsteps, dev)
+        work = tl.get("work")
+        if work is None:  # scratch for the seeds of this sweep (adj_pos / adj_vel layout), kept with the forward's outputs
+            work = tl["work"] = torch.empty(nframes * bs * nb * 13, dtype=torch.float32, device=dev)
         p = lambda t, name, n=None: _dev(t, name, n) if (t is not None and t.numel()) else None
         _check(lib().pd_rollout_backward_traj_loss(
             self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
@@ -308,7 +311,8 @@ class DeviceModel:
             p(body_inv_inertia, "body_inv_inertia", bs * nb * 9), nframes, f2s,
             p(ws, "workspace", self.workspace_floats(bs, nsteps)), p(adj_pos, "adj_pos", nframes * bs * nb * 7),
             p(adj_vel, "adj_vel", nframes * bs * nb * 6), p(tl["seed_pos"], "seed_pos", nframes * bs * nb * 7),
-            p(tl["scale"], "scale", bs * nframes), _dev(g_loss, "g_loss", 1), p(g["q_init"], "g"), p(g["qd_init"], "g"),
+            p(tl["scale"], "scale", bs * nframes), _dev(g_loss, "g_loss", 1), p(work, "seed_work", nframes * bs * nb * 13),
+            p(g["q_init"], "g"), p(g["qd_init"], "g"),
             p(g["torques"], "g"), p(g["res_f"], "g"), p(g["refs"], "g"), p(g["target_ke"], "g"),
             p(g["target_kd"], "g"), p(g["body_inv_mass"], "g"), p(g["body_inertia"], "g"),
             p(g["body_inv_inertia"], "g"), _stream()))

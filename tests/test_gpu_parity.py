@@ -892,6 +892,10 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     g_both = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *ins, f2s, out[4], out[5], one * wt, adj_pos=ap, adj_vel=av)
     g_seed = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *ins, f2s, out[4], out[5], one * wt)
     g_adj = dm.rollout_backward(bs, T, inp["dt"], *ins, f2s, out[4], ap, av)
+    # the seeds pd_rollout_backward_traj_loss built on the device for that last sweep = autograd's adj_body_qs, and no twist seeds
+    work = out[5]["work"]
+    assert float((work[: F * bs * nb * 7].view_as(ref_seed) - ref_seed).abs().max()) <= 1e-6 * float(ref_seed.abs().max())
+    assert float(work[F * bs * nb * 7:].abs().max()) == 0
     for k in g_both:
         s_ = g_seed[k] + g_adj[k]
         assert float((g_both[k] - s_).abs().max()) <= 2e-4 * float(s_.abs().max()) + 1e-30, k   # linear in the seeds (fp32 sums in another order; measured 3e-5)

@@ -154,7 +154,7 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert "null model" in err()
     assert lib.pd_rollout_backward(None, 1, 1, ctypes.c_float(5e-4), *([None] * 9), 2, f2s, *([None] * 13), None) != 0
     assert lib.pd_rollout_forward_traj_loss(None, 1, 1, ctypes.c_float(5e-4), *([None] * 10), 2, f2s, *([None] * 5), None, None, ctypes.c_float(0.1), *([None] * 5), None) != 0
-    assert lib.pd_rollout_backward_traj_loss(None, 1, 1, ctypes.c_float(5e-4), *([None] * 9), 2, f2s, *([None] * 16), None) != 0 and "null model" in err()
+    assert lib.pd_rollout_backward_traj_loss(None, 1, 1, ctypes.c_float(5e-4), *([None] * 9), 2, f2s, *([None] * 17), None) != 0 and "null model" in err()
     assert lib.pd_fk_forward(None, 1, None, None, None, None, None) != 0 and "null model" in err()
     # pose algebra / foot height: bad op, negative count, null operands are refused before any launch; n = 0 is a no-op
     assert lib.pd_pose_op(7, 1, None, 0, None, None, None) != 0 and lib.pd_pose_op(0, -1, None, 0, None, None, None) != 0
