@@ -435,6 +435,10 @@ PD_DEV void joint_force_adj(float q, float qd, float target, float ke, float kd,
   else if (q < lo) { adj_q += -lke * adj_limit; if (qd < 0.0f) adj_qd += -lkd * adj_limit; }
 }
 
+// (-fno-signed-zeros, csrc/Makefile: the sign of a zero is not defined in this library.  The one place a value hangs on it is
+// atan2f(+-0, negative) = +-pi below: a compound joint angle of EXACTLY 180 degrees about its first or third axis may come out as
+// +pi or -pi.  Both name the same rotation; the PD term ke (q - target) differs by 2 pi ke there -- a configuration far outside
+// the |second angle| < pi/2 range in which quat_decompose is a chart at all.  Stated in INTEGRATION.md section 4.)
 PD_DEV void quat_decompose(qt q, float *ang, v3 &c0, v3 &c1, v3 &c2) {  // :245-258; also returns the rotated basis
   c0 = qrot(q, V3(1, 0, 0)); c1 = qrot(q, V3(0, 1, 0)); c2 = qrot(q, V3(0, 0, 1));
   ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2f(c1.x, c0.x);

@@ -3,7 +3,6 @@ Same names and semantics as /root/reference/diffphys/dp_utils.py (cited per func
 import torch
 
 from .dataloader import bullet2gl  # noqa: F401  (re-exported like the reference's dp_utils)
-from .geom_utils import axis_angle_to_matrix, quaternion_invert, quaternion_to_matrix, rot_angle, se3_mat2vec, se3_vec2mat
 
 
 class _PoseOpHip(torch.autograd.Function):
@@ -30,21 +29,21 @@ class _PoseOpHip(torch.autograd.Function):
         return None, g_a, g_b
 
 
-def _hip_pose(*ts):
-    """float32 GPU tensors take the HIP kernels (no silent fallback there: a missing library raises); anything else -- the
-    CPU host tests, float64 checks -- runs the torch composition, which is also the kernels' test reference."""
-    return all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in ts)
+def _need_gpu(what, *ts):
+    """The pose algebra and se3_loss run as HIP kernels and nowhere else: float32 GPU tensors, or an error (no CPU / torch fallback;
+    their float64 torch restatement is test infrastructure: oracle/pose_torch.py)."""
+    for t in ts:
+        if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32):
+            raise TypeError("%s needs float32 GPU tensors (the product path has no CPU fallback); got %s" % (
+                what, "%s on %s" % (t.dtype, t.device) if torch.is_tensor(t) else type(t).__name__))
 
 
 def compose_delta(target_q, delta_root):
     """delta (bs,T,6 axis-angle) applied on the left of target (bs,T,7)   dp_utils.py:22-31"""
-    if _hip_pose(target_q, delta_root) and target_q.shape[-1] == 7 and delta_root.shape[-1] == 6 and target_q.shape[:-1] == delta_root.shape[:-1]:
-        return _PoseOpHip.apply(0, target_q, delta_root)
-    return compose_delta_torch(target_q, delta_root)
-
-
-def compose_delta_torch(target_q, delta_root):
-    return se3_mat2vec(se3_vec2mat(delta_root) @ se3_vec2mat(target_q))
+    _need_gpu("compose_delta", target_q, delta_root)
+    if not (target_q.shape[-1] == 7 and delta_root.shape[-1] == 6 and target_q.shape[:-1] == delta_root.shape[:-1]):
+        raise ValueError("compose_delta: target (..., 7) and delta (..., 6) with equal leading shapes; got %s and %s" % (tuple(target_q.shape), tuple(delta_root.shape)))
+    return _PoseOpHip.apply(0, target_q, delta_root)
 
 
 def remove_nan(t, bs=None, clip=False):
@@ -56,46 +55,18 @@ def remove_nan(t, bs=None, clip=False):
 
 def rotate_frame(global_q, target_q):
     """T = T_global @ T_target   dp_utils.py:60-73"""
-    if _hip_pose(global_q, target_q) and global_q.shape == (7,) and target_q.shape[-1] == 7:
-        return _PoseOpHip.apply(1, global_q, target_q)
-    return rotate_frame_torch(global_q, target_q)
-
-
-def rotate_frame_torch(global_q, target_q):
-    gm = se3_vec2mat(global_q)
-    if global_q.dim() == 1:
-        gm = gm[None, None]
-    return se3_mat2vec(gm @ se3_vec2mat(target_q), outdim=target_q.shape[-1])
+    _need_gpu("rotate_frame", global_q, target_q)
+    if not (global_q.shape == (7,) and target_q.shape[-1] == 7):
+        raise ValueError("rotate_frame: one global pose (7,) against targets (..., 7); got %s and %s" % (tuple(global_q.shape), tuple(target_q.shape)))
+    return _PoseOpHip.apply(1, global_q, target_q)
 
 
 def rotate_frame_vel(global_q, target_qd):
     """rotate (linear, angular) halves by the rotation of global_q   dp_utils.py:76-84"""
-    if _hip_pose(global_q, target_qd) and global_q.shape == (7,) and target_qd.shape[-1] == 6:
-        return _PoseOpHip.apply(2, global_q, target_qd)
-    return rotate_frame_vel_torch(global_q, target_qd)
-
-
-def rotate_frame_vel_torch(global_q, target_qd):
-    gq = torch.cat([torch.zeros_like(global_q[..., :3]), global_q[..., 3:]], -1)
-    rev = torch.cat([target_qd[..., 3:], target_qd[..., :3]], -1)
-    return torch.cat([rotate_frame_torch(gq, target_qd)[..., :3], rotate_frame_torch(gq, rev)[..., :3]], -1)
-
-
-def reduce_loss_loop(loss_seq, clip=False, th=0):
-    """The reference's loop, one host synchronisation per env (kept as the test reference of reduce_loss)."""
-    if clip:
-        for i in range(len(loss_seq)):
-            if th == 0:
-                sub = loss_seq[i]
-                pos = sub[sub > 0]
-                th = pos.median() * 10 if pos.numel() > 0 else 0
-            if th != 0:
-                over = loss_seq[i] > th
-                if bool(over.any()):
-                    loss_seq[i, int(over.float().argmax()):] = 0
-    if loss_seq.sum() > 0:
-        return loss_seq[loss_seq > 0].mean()
-    return loss_seq.mean()
+    _need_gpu("rotate_frame_vel", global_q, target_qd)
+    if not (global_q.shape == (7,) and target_qd.shape[-1] == 6):
+        raise ValueError("rotate_frame_vel: one global pose (7,) against twists (..., 6); got %s and %s" % (tuple(global_q.shape), tuple(target_qd.shape)))
+    return _PoseOpHip.apply(2, global_q, target_qd)
 
 
 def reduce_loss(loss_seq, clip=False, th=0):
@@ -141,24 +112,11 @@ class _Se3LossHip(torch.autograd.Function):
 
 def se3_loss(pred, gt, rot_ratio=0.1):
     """|dp|^2 + rot_ratio * angle(R_pred R_gt^T); quaternion (real-last) or axis-angle rotations   dp_utils.py:113-138.
-    float32 GPU tensors take the fused HIP kernel (the library must be built: no silent fallback on the GPU); anything
-    else (the CPU host tests, float64 checks) runs the torch composition below, which is also the kernel's test reference."""
-    if pred.is_cuda and pred.dtype == torch.float32 and gt.dtype == torch.float32 and pred.shape == gt.shape:
-        return _Se3LossHip.apply(pred, gt, rot_ratio)
-    return se3_loss_torch(pred, gt, rot_ratio)
-
-
-def se3_loss_torch(pred, gt, rot_ratio=0.1):
-    nanid = torch.logical_or(pred.sum(-1).isnan(), gt.sum(-1).isnan())
-    trn = (pred[..., :3] - gt[..., :3]).pow(2).sum(-1)
-    rp, rg = pred[..., 3:], gt[..., 3:]
-    if rp.shape[-1] == 3:
-        rp, rgi = axis_angle_to_matrix(rp), axis_angle_to_matrix(rg).transpose(-1, -2)
-    else:
-        rp = quaternion_to_matrix(torch.cat([rp[..., 3:4], rp[..., 0:3]], -1))
-        rgi = quaternion_to_matrix(quaternion_invert(torch.cat([rg[..., 3:4], rg[..., 0:3]], -1)))
-    loss = trn + rot_angle(rp @ rgi) * rot_ratio
-    return torch.where(nanid, torch.zeros_like(loss), loss)
+    One HIP launch for the value and both gradients (``pd_se3_loss``); float32 GPU tensors only."""
+    _need_gpu("se3_loss", pred, gt)
+    if pred.shape != gt.shape:
+        raise ValueError("se3_loss: pred and gt must have the same shape; got %s and %s" % (tuple(pred.shape), tuple(gt.shape)))
+    return _Se3LossHip.apply(pred, gt, rot_ratio)
 
 
 def compute_com(body_q, part_com, part_mass):

@@ -321,17 +321,9 @@ class phys_model(nn.Module):
         """lowest ground-contact candidate per (env, frame); the reference poses the visual meshes instead (dp_model.py:574-579).
         float32 GPU poses: one HIP launch (``pd_foot_height``) and one for the gradient, which reaches the body of the
         lowest candidate only -- the torch composition's gather over 3 838 candidates has a 3.3 ms index_put backward."""
-        if state_body_q.is_cuda and state_body_q.dtype == torch.float32:
-            return _FootHeightHip.apply(state_body_q, self.c_body_i32, self.c_point, self.c_dist)
-        return self.get_foot_height_torch(state_body_q)
-
-    def get_foot_height_torch(self, state_body_q):
-        X = state_body_q[..., self.c_body, :]
-        q, p = X[..., 3:], X[..., :3]
-        qv, w = q[..., :3], q[..., 3:]
-        pt = self.c_point.expand(qv.shape)
-        rot = pt * (2 * w * w - 1) + 2 * w * torch.cross(qv, pt, dim=-1) + 2 * qv * (qv * pt).sum(-1, keepdim=True)
-        return (p[..., 1] + rot[..., 1] - self.c_dist).min(-1)[0]
+        if not (state_body_q.is_cuda and state_body_q.dtype == torch.float32):
+            raise TypeError("get_foot_height needs float32 GPU poses (the product path has no CPU fallback; oracle/pose_torch.py foot_height is the checker)")
+        return _FootHeightHip.apply(state_body_q, self.c_body_i32, self.c_point, self.c_dist)
 
     def compute_frame_start(self):
         fs = torch.tensor(np.random.rand(self.num_envs), device=self.device)

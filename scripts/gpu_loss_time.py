@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ppr-diffphys_amd"))
 import torch
 from diffphys_amd import dp_utils
+from oracle import pose_torch
 
 dev = torch.device("cuda:0")
 for dim in (7, 6):
@@ -12,7 +13,7 @@ for dim in (7, 6):
     g = torch.Generator().manual_seed(0)
     pred = torch.randn(n, dim, generator=g).to(dev).requires_grad_(True)
     gt = (pred.detach() + 0.3 * torch.randn(n, dim, generator=g).to(dev)).requires_grad_(True)
-    for name, fn in (("torch composition", dp_utils.se3_loss_torch), ("fused pd_se3_loss", dp_utils.se3_loss)):
+    for name, fn in (("torch composition", pose_torch.se3_loss), ("fused pd_se3_loss", dp_utils.se3_loss)):
         for it in range(3):
             fn(pred, gt, 0.1).mean().backward()
         torch.cuda.synchronize()

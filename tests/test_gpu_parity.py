@@ -744,6 +744,7 @@ def test_fused_se3_loss_matches_the_torch_composition(dim, dev):
     rotations (clamped acos: zero rotation gradient), NaN entries (loss and gradients 0).  Tolerances: loss 2e-5
     relative to max, gradients 5e-4 relative to max (fp32 acos near the clamp)."""
     from diffphys_amd import dp_utils
+    from oracle import pose_torch
 
     g = torch.Generator().manual_seed(5)
     n = 4099
@@ -762,7 +763,7 @@ def test_fused_se3_loss_matches_the_torch_composition(dim, dev):
     loss = dp_utils.se3_loss(p32, g32, 0.1)
     (loss * w).sum().backward()
     p64, g64 = pred.double().to(dev).requires_grad_(True), gt.double().to(dev).requires_grad_(True)
-    ref = dp_utils.se3_loss_torch(p64, g64, 0.1)
+    ref = pose_torch.se3_loss(p64, g64, 0.1)
     ok = torch.ones(n, dtype=torch.bool, device=dev); ok[50] = False; ok[51] = False
     (ref[ok] * w.double()[ok]).sum().backward()
     assert loss[50].item() == 0.0 and loss[51].item() == 0.0

@@ -1,10 +1,12 @@
 """GPU tests of the pose-algebra kernels (C ABI pd_pose_op / pd_pose_op_vjp / pd_foot_height)
-against the torch compositions they replace (diffphys_amd.dp_utils.*_torch, written after the reference's
+against the torch compositions they replace (oracle/pose_torch.py: test infrastructure, written after the reference's
 diffphys/dp_utils.py:22-31,60-84 and diffphys/geom_utils.py:148-203) -- values in float32 and float64, gradients against
 torch autograd of the float64 composition."""
 import numpy as np
 import pytest
 import torch
+
+from oracle import pose_torch
 
 pytestmark = pytest.mark.gpu
 
@@ -68,9 +70,9 @@ def test_compose_delta_matches_the_torch_composition(dev):
     rng = np.random.RandomState(0)
     n = 4096
     tq, dl = _poses(rng, n), _deltas(rng, n)
-    _check(dp_utils.compose_delta, dp_utils.compose_delta_torch, tq, dl, dev)
+    _check(dp_utils.compose_delta, pose_torch.compose_delta, tq, dl, dev)
     # (bs, T, .) operands as phys_model passes them, and no gradient needed for the target
-    _check(dp_utils.compose_delta, dp_utils.compose_delta_torch, tq.reshape(64, 64, 7), dl.reshape(64, 64, 6), dev, grad_a=False)
+    _check(dp_utils.compose_delta, pose_torch.compose_delta, tq.reshape(64, 64, 7), dl.reshape(64, 64, 6), dev, grad_a=False)
 
 
 def test_rotate_frame_and_rotate_frame_vel_match_the_torch_compositions(dev):
@@ -81,10 +83,10 @@ def test_rotate_frame_and_rotate_frame_vel_match_the_torch_compositions(dev):
     qd = rng.randn(64, 50, 6)
     for gq in ([0.0, -0.3, 0.1, 0.0, 0.0, 0.0, 1.0], [0.2, 0.1, -0.4, 0.3, -0.5, 0.2, 0.9], [0.0, 0.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3]):
         gq = np.asarray(gq)
-        _check(dp_utils.rotate_frame, dp_utils.rotate_frame_torch, gq, tq, dev)
-        _check(dp_utils.rotate_frame, dp_utils.rotate_frame_torch, gq, tq, dev, grad_b=False)  # as in phys_model: mocap rows need no gradient
-        _check(dp_utils.rotate_frame_vel, dp_utils.rotate_frame_vel_torch, gq, qd, dev)
-        _check(dp_utils.rotate_frame_vel, dp_utils.rotate_frame_vel_torch, gq, qd, dev, grad_b=False)
+        _check(dp_utils.rotate_frame, pose_torch.rotate_frame, gq, tq, dev)
+        _check(dp_utils.rotate_frame, pose_torch.rotate_frame, gq, tq, dev, grad_b=False)  # as in phys_model: mocap rows need no gradient
+        _check(dp_utils.rotate_frame_vel, pose_torch.rotate_frame_vel, gq, qd, dev)
+        _check(dp_utils.rotate_frame_vel, pose_torch.rotate_frame_vel, gq, qd, dev, grad_b=False)
 
 
 def test_pose_ops_reject_bad_operands(dev):
@@ -104,7 +106,7 @@ def test_pose_ops_reject_bad_operands(dev):
 
 
 def test_foot_height_matches_the_torch_gather(dev):
-    """pd_foot_height against phys_model.get_foot_height_torch's formula: same heights, the same arg-min candidate wherever the
+    """pd_foot_height against the torch gather over all candidates (oracle/pose_torch.py foot_height states the same formula): same heights, the same arg-min candidate wherever the
     minimum is not (nearly) tied, and the gradient torch.min routes to that candidate's body."""
     from diffphys_amd import hip_backend, robots
 

@@ -235,3 +235,26 @@ def test_fused_traj_loss_equals_the_torch_sequence_on_the_training_window(seq, d
             sc = float(gu[n].abs().max())
             assert float((gf[n] - gu[n]).abs().max()) <= TOL * max(sc, 1e-6) + 1e-12, (variant, n, float((gf[n] - gu[n]).abs().max()), sc)
         assert any(float(g.abs().max()) > 0 for g in gu.values())
+
+
+def test_main_runs_two_rounds(dev, capsys):
+    """main.main() itself (the reference's driver loop, /root/reference/main.py:50-105): 2 rounds x 3 iterations on
+    mi-pace through the HIP rollout -- the evaluation pass over the whole clip at the head of each round, checkpoints, three
+    optimisation iterations per round with accu_steps = 2 windows each -- and what it leaves behind."""
+    import glob
+    import shutil
+
+    logroot = "/tmp/pprdp_main_test/"
+    shutil.rmtree(logroot, ignore_errors=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    _main().main(["--seqname", "mi-pace", "--urdf_template", "laikago", "--num_rounds", "2", "--iters_per_round", "3", "--accu_steps", "2",
+                  "--logroot", logroot, "--logname", "m", "--num_envs", "6", "--frames_per_wdw", "8"])
+    out = capsys.readouterr().out
+    evals = [l for l in out.splitlines() if l.startswith("[eval")]
+    iters = [l for l in out.splitlines() if l.startswith("[iter")]
+    assert len(evals) == 2 and len(iters) == 6, out[-2000:]
+    vals = [float(l.split("total")[1].split()[0]) for l in iters] + [float(l.split("traj loss")[1]) for l in evals]
+    assert all(np.isfinite(v) and v >= 0 for v in vals), vals
+    ck = glob.glob(logroot + "**/ckpt_phys_*.pth", recursive=True)
+    assert any(c.endswith("ckpt_phys_latest.pth") for c in ck) and len(ck) >= 2, ck

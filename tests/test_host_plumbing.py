@@ -1,14 +1,18 @@
-"""CPU tests of the loss / frame utilities and MLP plumbing."""
+"""CPU tests of the loss / frame utilities and MLP plumbing.  The SE(3) / loss formulas are pinned
+to scipy here on BOTH restatements: the product's host helpers (diffphys_amd.geom_utils) and the checker of the HIP pose / loss
+kernels (oracle/pose_torch.py); the kernels themselves are compared with that checker on the GPU (tests/test_gpu_pose.py)."""
 import numpy as np
 import pytest
 import torch
 from scipy.spatial.transform import Rotation as R
 
 from diffphys_amd import dp_utils, geom_utils
+from oracle import pose_torch
 from diffphys_amd.time_mlp import TimeMLPWrapper, interp_wt, match_param_name
 
 
-def test_quaternion_matrix_roundtrip_against_scipy():
+@pytest.mark.parametrize("geom_utils", [geom_utils, pose_torch], ids=["product", "oracle"])
+def test_quaternion_matrix_roundtrip_against_scipy(geom_utils):
     rng = np.random.RandomState(0)
     q_xyzw = rng.randn(50, 4)
     q_xyzw /= np.linalg.norm(q_xyzw, axis=1, keepdims=True)
@@ -24,7 +28,8 @@ def test_quaternion_matrix_roundtrip_against_scipy():
     assert torch.allclose(geom_utils.quaternion_to_axis_angle(geom_utils.axis_angle_to_quaternion(aa)), aa, atol=1e-10)
 
 
-def test_se3_vec_mat_roundtrip_and_rotate_frame():
+@pytest.mark.parametrize("geom_utils", [geom_utils, pose_torch], ids=["product", "oracle"])
+def test_se3_vec_mat_roundtrip_and_rotate_frame(geom_utils):
     rng = np.random.RandomState(1)
     v = torch.tensor(rng.randn(4, 3, 7))
     v[..., 3:] = v[..., 3:] / v[..., 3:].norm(dim=-1, keepdim=True)
@@ -34,19 +39,23 @@ def test_se3_vec_mat_roundtrip_and_rotate_frame():
     sign = torch.sign((v2[..., 3:] * v[..., 3:]).sum(-1, keepdim=True))
     assert torch.allclose(v2[..., :3], v[..., :3]) and torch.allclose(v2[..., 3:] * sign, v[..., 3:], atol=1e-10)
     g = torch.tensor([0.0, -0.3, 0.0, 0.0, 0.0, 0.0, 1.0], dtype=v.dtype)
-    out = dp_utils.rotate_frame(g, v)
+    out = pose_torch.rotate_frame(g, v)
     assert torch.allclose(out[..., 1], v[..., 1] - 0.3) and torch.allclose(out[..., 0], v[..., 0])
     qd = torch.tensor(rng.randn(4, 3, 6))
-    assert torch.allclose(dp_utils.rotate_frame_vel(g, qd), qd, atol=1e-12)  # identity rotation leaves twists alone
+    assert torch.allclose(pose_torch.rotate_frame_vel(g, qd), qd, atol=1e-12)  # identity rotation leaves twists alone
+    # the product's compositions are HIP kernels and nothing else: CPU tensors are refused, not computed somewhere else
+    for fn, args in ((dp_utils.rotate_frame, (g, v)), (dp_utils.rotate_frame_vel, (g, qd)), (dp_utils.compose_delta, (v, qd)), (dp_utils.se3_loss, (v, v))):
+        with pytest.raises(TypeError, match="no CPU fallback"):
+            fn(*args)
 
 
 def test_se3_loss_and_reduce_loss():
     a = torch.tensor([[0.0, 0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
     ang = 0.4
     b = torch.tensor([[1.0, 2.0, 0, 0, np.sin(ang / 2), 0, np.cos(ang / 2)]], dtype=torch.float64)
-    assert abs(float(dp_utils.se3_loss(a, b)) - (5.0 + 0.1 * ang)) < 1e-5
+    assert abs(float(pose_torch.se3_loss(a, b)) - (5.0 + 0.1 * ang)) < 1e-5
     nan = torch.tensor([[float("nan"), 0, 0, 0, 0, 0, 1.0]], dtype=torch.float64)
-    assert float(dp_utils.se3_loss(nan, b)) == 0.0
+    assert float(pose_torch.se3_loss(nan, b)) == 0.0
     seq = torch.tensor([[1.0, 1.1, 0.9, 50.0, 1.0], [1.0, 1.0, 1.0, 1.0, 1.0]])
     red = dp_utils.reduce_loss(seq.clone(), clip=True)
     assert abs(float(red) - np.mean([1.0, 1.1, 0.9] + [1.0] * 5)) < 1e-6  # env 0 truncated where it first exceeds 10x median
@@ -86,7 +95,7 @@ def test_reduce_loss_matches_the_reference_loop():
         for clip in (False, True):
             a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
             a2, b2 = a * 1.0, b * 1.0
-            ra, rb = dp_utils.reduce_loss_loop(a2, clip=clip), dp_utils.reduce_loss(b2, clip=clip)
+            ra, rb = pose_torch.reduce_loss_loop(a2, clip=clip), dp_utils.reduce_loss(b2, clip=clip)
             assert torch.allclose(ra, rb, atol=1e-7) and torch.equal(a2.detach(), b2.detach())
             ra.backward(); rb.backward()
             assert torch.allclose(a.grad, b.grad, atol=1e-7)
