@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 5   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4) */
+#define PD_ABI_VERSION 5   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels) */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -78,6 +78,14 @@ void pd_model_destroy(pd_model *m);
  * (smallest that fits).  64 is the literal "one articulation per wavefront" mapping. */
 int pd_model_set_segment_width(pd_model *m, int lanes);
 int pd_model_get_segment_width(const pd_model *m);
+
+/* Kernel family of the rollout launches.  0 (default): chosen per launch by batch size -- revolute-only robots with at most 16 bodies
+ * (Laikago) run the QUAD-LANE kernels (four lanes per body, one articulation per wavefront: a shorter instruction stream per step,
+ * three times the lane-cycles per env) while the batch fits one workgroup per compute unit (<= 4 x CUs envs = 1 024 on MI355X) and the
+ * lane-per-body kernels above that; 1: lane per body always; 2: quad-lane wherever the robot is eligible (tests, A/B timing).
+ * pd_model_get_kernel_family returns the setting; *eligible (may be NULL) = 1 when the robot has quad-lane kernels at all. */
+int pd_model_set_kernel_family(pd_model *m, int family);
+int pd_model_get_kernel_family(const pd_model *m, int *eligible);
 
 /* Floats of caller-provided workspace that pd_rollout_forward fills and pd_rollout_backward reads:
  * per step the 13-float body state and the 6-float body wrench as five float4 planes [step][plane][bs*nb], followed

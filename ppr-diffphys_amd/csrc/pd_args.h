@@ -26,7 +26,8 @@ constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
 // the specialised instantiations (one joint type) are only launched for PLAIN models: non-FREE joints all hang on a body, child
 // joint frames are not rotated (pd_host.hip)
 constexpr bool pd_parented(int jt) { return jt == PD_JT_REVOLUTE || jt == PD_JT_COMPOUND; }
-enum { PD_KV_FWD_SPLIT = 0, PD_KV_FWD_UNSPLIT, PD_KV_BWD_2ROLE, PD_KV_BWD_2ROLE_EARLY, PD_KV_BWD_3ROLE, PD_KV_BWD3_2ROLE, PD_KV_BWD_UNSPLIT, PD_KV_FK };
+enum { PD_KV_FWD_SPLIT = 0, PD_KV_FWD_UNSPLIT, PD_KV_BWD_2ROLE, PD_KV_BWD_2ROLE_EARLY, PD_KV_BWD_3ROLE, PD_KV_BWD3_2ROLE, PD_KV_BWD_UNSPLIT, PD_KV_FK,
+       PD_KV_FWD_QUAD, PD_KV_BWD_QUAD };  // quad-lane (four lanes per body) small-batch kernels, 64-lane mapping, revolute-only plain models
 struct PdLaunchCfg {
   int kernel;    // PD_KV_*
   int roles;     // waves per env group

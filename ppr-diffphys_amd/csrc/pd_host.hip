@@ -23,6 +23,11 @@ struct pd_model {
   // derived
   int segw = 0, jt = 0;
   std::vector<int> contact_order;  // device contact-table entry -> template candidate (pd_model_contact_order)
+  // second device copy in the 64-lane mapping for the quad-lane (four lanes per body) small-batch kernels: revolute-only plain
+  // models with at most 16 bodies; null otherwise
+  struct Quad { void *blob; PdDevModel dev; size_t lds_tables; int jt; };
+  Quad *quad = nullptr;
+  int family = 0;  // pd_model_set_kernel_family: 0 automatic (by batch size), 1 lane per body always, 2 quad-lane wherever eligible
   void *blob = nullptr;
   PdDevModel dev{};
   size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;  // at PD_BWAVES env groups per workgroup (the maximum)
@@ -92,6 +97,9 @@ static void bound_box(const std::vector<int> &ids, const float *pts, const float
 
 static void free_device(pd_model *m) {
   if (m->blob) { (void)hipFree(m->blob); m->blob = nullptr; }
+}
+static void free_quad(pd_model *m) {
+  if (m->quad) { if (m->quad->blob) (void)hipFree(m->quad->blob); delete m->quad; m->quad = nullptr; }
 }
 
 template <typename T>
@@ -164,7 +172,10 @@ static int build_device(pd_model *m, int segw) {
     body_tiles[b] = make_int2((int)tile_pack.size(), 0);
     if (ids.empty()) continue;
     body_sphere[b] = bound_sphere(ids, m->cpoint.data(), m->cdist.data());
-    kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), segw);
+    // the ORDER of a body's points is that of the 16-lane mapping whatever the segment width (its tiles are then cut segw points at a
+    // time): hit-log entries are indices into this table, and a forward pass in one lane mapping may be followed by an adjoint in
+    // another (the quad-lane forward kernel runs on the 64-lane tables, the lane-per-body adjoint on the 16-lane ones)
+    kd_order(ids, 0, (int)ids.size(), m->cpoint.data(), 16);
     for (size_t t0 = 0; t0 < ids.size(); t0 += segw) {
       std::vector<int> tid(ids.begin() + t0, ids.begin() + std::min(ids.size(), t0 + segw));
       float4 blo, bhi;
@@ -288,6 +299,18 @@ static int build_device(pd_model *m, int segw) {
   return 0;
 }
 
+// The quad-lane kernels' device copy (64-lane mapping).  Eligible: revolute-only PLAIN models (pd_parented: what the specialised
+// instantiation assumes) with at most 16 bodies.  Not an error when the model is not eligible or the copy does not fit: the
+// lane-per-body kernels then serve every batch size.
+static void build_quad(pd_model *m) {
+  free_quad(m);
+  if (m->jt != PD_JT_REVOLUTE || m->nb > 16) return;
+  pd_model tmp = *m;  // host arrays are copied, the device copy is built into the temporary and moved over
+  tmp.blob = nullptr; tmp.quad = nullptr;
+  if (build_device(&tmp, 64) != 0 || tmp.jt != PD_JT_REVOLUTE) { if (tmp.blob) (void)hipFree(tmp.blob); return; }
+  m->quad = new pd_model::Quad{tmp.blob, tmp.dev, tmp.lds_tables, tmp.jt};
+}
+
 static int g_variant = 0;  // -DPD_EXPERIMENT builds only (pd_debug_set_variant); the shipped launch_cfg always sees 0
 static int g_groups = 0;   // -DPD_EXPERIMENT / -DPD_STAMPS builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
 #ifdef PD_EXPERIMENT
@@ -315,7 +338,31 @@ static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
   return c;
 }
 
+// Small batches of an eligible robot take the quad-lane forward kernel: one env per wave pair, so up to PD_BWAVES x CUs envs fill the
+// chip with one workgroup per CU (1 024 on MI355X); beyond that the lane-per-body kernels (four envs per wave) have the throughput.
+static bool use_quad(const pd_model *m, int kind, int n_envs, const void *args) {
+  if (!m->quad || m->family == 1 || (kind != PD_K_ROLLOUT_FWD && kind != PD_K_ROLLOUT_BWD)) return false;
+  if (kind == PD_K_ROLLOUT_FWD && ((const RolloutArgs *)args)->loss_target) return false;  // the trajectory-loss instantiation exists in the lane-per-body form only
+  // forward: while one workgroup per CU holds the batch (4 x CUs envs); adjoint: while every wave has a SIMD to itself (2 x CUs) --
+  // measured: 1 024 envs forward 0.153 ms against 0.184, adjoint 0.273 against 0.244 (two quad pairs per SIMD lose)
+  return m->family == 2 || n_envs <= (kind == PD_K_ROLLOUT_FWD ? PD_BWAVES : PD_BWAVES / 2) * m->quad->dev.cu_count;
+}
+
 static hipError_t launch(const pd_model *m, int kind, const void *args, int n_envs, hipStream_t st) {
+  if (use_quad(m, kind, n_envs, args)) {
+    const PdDevModel &d = m->quad->dev;
+    PdLaunchCfg c{};
+    c.kernel = kind == PD_K_ROLLOUT_FWD ? PD_KV_FWD_QUAD : PD_KV_BWD_QUAD; c.roles = 2;
+    c.groups = g_groups ? g_groups : pd_groups_per_wg(n_envs, d.cu_count);
+    c.nblocks = (n_envs + c.groups - 1) / c.groups;
+    c.threads = c.roles * c.groups * 64;
+    c.lds = kind == PD_K_ROLLOUT_FWD ? m->quad->lds_tables + (size_t)c.groups * d.env_lds_floats * 4   // contact tables in LDS
+                                     : (size_t)c.groups * (d.env_lds_floats + 2 * d.env_lds_jc) * 4;  // adjoint: + joint hand-over records
+    if (c.nblocks == 0) return hipSuccess;
+    int *ll = const_cast<pd_model *>(m)->last_launch[kind];
+    ll[0] = c.nblocks; ll[1] = c.threads; ll[2] = (int)c.lds; ll[3] = c.groups;
+    return pd_launch_seg64(kind, m->quad->jt, d, args, c, st);
+  }
   const PdLaunchCfg c = launch_cfg(m, kind, n_envs);
   if (c.nblocks == 0) return hipSuccess;
   if (kind < 2) {
@@ -407,6 +454,7 @@ int pd_model_create(const pd_model_desc *d, pd_model **out) {
     for (int w = m->nb <= 16 ? 16 : (m->nb <= 32 ? 32 : 64); w <= 64 && rc; w *= 2) rc = build_device(m, w);
     if (rc) { free_device(m); delete m; return 1; }
   }
+  build_quad(m);
   *out = m;
   return 0;
 }
@@ -418,6 +466,7 @@ void pd_model_destroy(pd_model *m) {
       if (m->ev[k][j]) (void)hipEventDestroy(m->ev[k][j]);
   for (auto &e : m->fos) (void)hipFree(e.dev);
   free_device(m);
+  free_quad(m);
   delete m;
 }
 
@@ -425,7 +474,20 @@ void pd_model_destroy(pd_model *m) {
 int pd_model_set_segment_width(pd_model *m, int lanes) {
   if (!m) return fail("null model");
   (void)hipDeviceSynchronize();
-  return build_device(m, lanes);
+  if (build_device(m, lanes)) return 1;
+  build_quad(m);
+  return 0;
+}
+
+int pd_model_set_kernel_family(pd_model *m, int family) {
+  if (!m) return fail("null model");
+  if (family < 0 || family > 2) return fail("kernel family: 0 automatic, 1 lane per body, 2 quad-lane where eligible");
+  m->family = family;
+  return 0;
+}
+int pd_model_get_kernel_family(const pd_model *m, int *eligible) {
+  if (eligible) *eligible = (m && m->quad) ? 1 : 0;
+  return m ? m->family : 0;
 }
 int pd_model_get_segment_width(const pd_model *m) { return m ? m->segw : 0; }
 
@@ -434,6 +496,7 @@ int pd_model_bind_joint_X_p(pd_model *m, const float *joint_X_p_dev, int n_envs)
   if ((joint_X_p_dev == nullptr) != (n_envs == 0) || n_envs < 0) return fail("joint_X_p binding needs a device pointer and n_envs > 0 (or NULL and 0 to unbind)");
   m->xp_env = joint_X_p_dev; m->xp_envs = n_envs;
   m->dev.X_p_env = joint_X_p_dev; m->dev.xp_envs = n_envs;
+  if (m->quad) { m->quad->dev.X_p_env = joint_X_p_dev; m->quad->dev.xp_envs = n_envs; }
   return 0;
 }
 

@@ -8,6 +8,7 @@
 #include "pd_device.h"
 #include "pd_args.h"
 #include "pd_se3.h"
+#include "pd_quad.h"
 
 // In-kernel phase stamps (diagnostic build only, never in the shipped library): cdna_hip_programming.md section 7.
 #ifdef PD_STAMPS
@@ -493,8 +494,12 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // pose it is about to store against the frame's target pose (dp_model.py:777, dp_utils.py:113-138), stores both unscaled gradients
 // and the mean over the env's bodies -- the [bs][F] table reduce_loss works on -- so that no pose makes the round trip through a loss
 // launch and torch before the adjoint can be seeded.  A separate instantiation: the plain rollout kernel is untouched.
-template <int SEGW, int JT, bool SPLIT, bool LOSS = false>
+// QUAD (small batches of revolute-only robots; pd_quad.h): the body wave gives every body FOUR lanes (component-parallel arithmetic),
+// one env per wave, SEGW = 64 so that the contact wave and every LDS table are those of the 64-lane mapping.  Same records, same
+// hand-overs, same trajectory layout: the adjoint kernels run on what it saves.
+template <int SEGW, int JT, bool SPLIT, bool LOSS = false, bool QUAD = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
+  static_assert(!QUAD || (SEGW == 64 && SPLIT && JT == PD_JT_REVOLUTE && !LOSS), "quad-lane body wave: one env per wave, revolute-only plain models");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
@@ -660,6 +665,208 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
     }
     STAMP_FLUSH(a);
+    return;
+  }
+  if constexpr (QUAD) {
+    // ================= body wave, four lanes per body: lane 4 qb + qc holds component qc of body qb of this wave's ONE env
+    const int qb = lane >> 2, qc = lane & 3, bb = qb < nb ? qb : nb - 1, qv = qc < 3 ? qc : 2;
+    const bool qbody = env_ok && qb < nb;
+    const QLane k = q_lane(qc);
+    const size_t qidx = (size_t)ec * nb + bb;
+    QBody B;
+    {
+      const BodyConst cb = load_body_const(m, bb, ec);
+      B.type = cb.type; B.pidx = cb.pidx; B.qdstart = cb.qdstart;
+      B.joint = qbody && cb.type == PD_JOINT_REVOLUTE;
+      B.com = q_pick(k, cb.com); B.com0 = cb.com.x; B.com1 = cb.com.y; B.com2 = cb.com.z;
+      B.axis = q_pick(k, cb.axis); B.ax0 = cb.axis.x; B.ax1 = cb.axis.y; B.ax2 = cb.axis.z; B.alen = cb.alen;
+      B.p_pj = q_pick(k, cb.p_pj); B.q_pj = q_pick(k, cb.q_pj); B.pj = q_perm(k, B.q_pj);
+      B.g = q_pick(k, V3(m.gx, m.gy, m.gz));
+      B.reach = cb.reach; B.sphere_w = cb.sphere.w; B.lim = cb.lim[0];
+      B.inv_m = a.inv_mass[qidx];
+      const bool on = cb.type == PD_JOINT_REVOLUTE;
+      B.ke = on ? a.target_ke[(size_t)ec * m.nqd + cb.qdstart] : 0.f;
+      B.kd = on ? a.target_kd[(size_t)ec * m.nqd + cb.qdstart] : 0.f;
+      const float *Ib = a.inertia + qidx * 9 + qv * 3, *Jb = a.inv_inertia + qidx * 9 + qv * 3;
+      B.I.a = k.isv ? Ib[0] : 0.f; B.I.b = k.isv ? Ib[1] : 0.f; B.I.c = k.isv ? Ib[2] : 0.f;
+      B.invI.a = k.isv ? Jb[0] : 0.f; B.invI.b = k.isv ? Jb[1] : 0.f; B.invI.c = k.isv ? Jb[2] : 0.f;
+    }
+    int qcz[4];  // first four children of body bb, the zero record for a missing one
+    {
+      const unsigned long long ch = m.children[bb];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const int cid = (int)((ch >> (8 * j)) & 0xffull); qcz[j] = (qbody && cid != 0xff) ? cid : nb; }
+    }
+    const unsigned long long q_children = m.children[bb];
+    if (lane < nb) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) facc[lane * PD_W6 + j] = 0.f;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) pcon[nb * PD_W6 + j] = 0.f;
+    }
+    // ---- eval_fk (dp_model.py:1204) in the lane-per-body layout (lanes 0 .. nb-1), once; the records it stages are then read back
+    // component-wise
+    for (int d = 0; d <= m.max_depth; ++d) {
+      if (is_body && c.depth == d) {
+        BodyState s0 = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
+        float Rm0[9];
+        rotm(s0.r, Rm0);
+        stage_record(rec, cull, b, s0, mat_vec(Rm0, c.com), Rm0);
+      }
+      WAVE_SYNC();
+    }
+    QState s;
+    {
+      const float *r = rec + bb * PD_REC;
+      s.p = k.isv ? r[qv] : 0.f; s.r = r[3 + qc]; s.w = k.isv ? r[7 + qv] : 0.f; s.v = k.isv ? r[10 + qv] : 0.f;
+    }
+    QM3 Rr, Rc;
+    q_rotm(k, s.r, Rr, Rc);
+    float rc = q_mvc(Rr, B.com0, B.com1, B.com2);
+    auto q_margin = [&](const QState &x) {  // sink_margin (the speculative contact cull), all four lanes
+      return (float)PD_SPEC_K * (PD_SPEC_SAFETY * a.dt * (Q_BC1(fabsf(x.v)) + q_sum3(fabsf(x.w)) * B.reach) + PD_SPEC_SLACK);
+    };
+    // staging: the record fields are contiguous vectors, lane c writes component c of each; the cull vector (p_y, row 1 of rotm) is
+    // lane 1's: its own p and its row
+    auto q_stage = [&](const QState &x, float rcx, const QM3 &R, float lower, float4 *spec_dst) {
+      if (qbody) {
+        float *r = rec + bb * PD_REC;
+        r[3 + qc] = x.r;
+        if (k.isv) { r[qc] = x.p; r[7 + qc] = x.w; r[10 + qc] = x.v; r[13 + qc] = rcx; }
+        if (qc == 1) {
+          cull[bb] = make_float4(x.p, R.a, R.b, R.c);
+          if (spec_dst) spec_dst[bb] = make_float4(x.p - lower, R.a, R.b, R.c);
+        }
+      }
+    };
+    float margin = q_margin(s), sunk = 0.f;
+    WAVE_SYNC();  // every lane has read the FK records
+    q_stage(s, rc, Rr, margin, spec);  // epoch 0
+    bool spec_failed = true;
+    // controls one step ahead; the trajectory planes are float4 per body: lane c owns float c of each
+    const unsigned boff_qd = (unsigned)((size_t)ec * m.nqd + B.qdstart) * 4u, boff_rf = (unsigned)(qidx * 6 + qv) * 4u;
+    const unsigned boff_tj = (unsigned)(qidx * 4 + qc) * 4u;
+    float n_tgt = 0.f, n_act = 0.f, n_rft = 0.f, n_rff = 0.f;
+    int n_fr = -1;
+    auto load_controls = [&](int step) {
+      const int sc = __builtin_amdgcn_readfirstlane(step < a.nsteps ? step : a.nsteps - 1);
+      n_fr = ld_uniform(a.frame_of_step, sc);
+      const size_t o = (size_t)sc * a.bs * m.nqd;
+      n_tgt = B.joint ? ldg(a.refs + o, boff_qd) : 0.f;
+      n_act = B.joint ? ldg(a.torques + o, boff_qd) : 0.f;
+      const float *rf = a.res_f + (size_t)sc * N * 6;
+      n_rft = ldg(rf, boff_rf); n_rff = ldg(rf + 3, boff_rf);
+    };
+    auto q_frame_out = [&](int cfr, const QState &x) {  // frame gather (dp_model.py:1231-1248)
+      if (qbody) {
+        float *o = a.wp_pos + ((size_t)cfr * N + qidx) * 7;
+        o[3 + qc] = x.r;
+        float *ov = a.wp_vel + ((size_t)cfr * N + qidx) * 6;
+        if (k.isv) { o[qc] = x.p; ov[qc] = x.w; ov[3 + qc] = x.v; }
+      }
+    };
+    float o_p3 = 0.f, o_p4 = 0.f;  // planes 3 / 4 of the previous step (its total wrench and clamp mask), stored one step late
+    if (a.nsteps > 0) load_controls(0);
+    const float ake = m.attach_ke, akd = m.attach_kd;
+    for (int step = 0; step < a.nsteps; ++step) {
+      pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: this step's records are staged
+      PD_WAIT_VMEM();
+      const float tgt = n_tgt, act = n_act;
+      float ft = k.isv ? n_rft : 0.f, ff = k.isv ? n_rff : 0.f;  // clear_forces + wp_add
+      const int fr = n_fr;
+      load_controls(step + 1);
+      // ---- eval_body_joints (while the contact wave sweeps)
+      float wp_t, wc_t, jf_;
+      {
+        const float *pr = rec + B.pidx * PD_REC;
+        const float pp = k.isv ? pr[qv] : 0.f, qp = pr[3 + qc], w_p = k.isv ? pr[7 + qv] : 0.f, v_p = k.isv ? pr[10 + qv] : 0.f,
+                    rc_par = k.isv ? pr[13 + qv] : 0.f;
+        q_joint_fwd(k, B, s, Rr, rc, pp, qp, w_p, v_p, rc_par, tgt, act, ake, akd, wp_t, wc_t, jf_);
+      }
+      wp_t = B.joint ? wp_t : 0.f; wc_t = B.joint ? wc_t : 0.f; jf_ = B.joint ? jf_ : 0.f;
+      if (qbody && k.isv) { pcon[bb * PD_W6 + qc] = wp_t; pcon[bb * PD_W6 + 3 + qc] = jf_; }
+      WAVE_SYNC();
+      float jt = -wc_t, jf = -jf_;  // joint wrench on this body: own joint first, then children in index order
+      {
+        float ct[4], cf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ct[j] = pcon[qcz[j] * PD_W6 + qv]; cf[j] = pcon[qcz[j] * PD_W6 + 3 + qv]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { jt += ct[j]; jf += cf[j]; }
+      }
+      for (int j = 4; j < m.max_children; ++j) {
+        const int cid = (int)((q_children >> (8 * j)) & 0xffull);
+        if (qbody && cid != 0xff) { jt += pcon[cid * PD_W6 + qv]; jf += pcon[cid * PD_W6 + 3 + qv]; }
+      }
+      jt = k.isv ? jt : 0.f; jf = k.isv ? jf : 0.f;
+      // ---- trajectory planes 0-2 of this state, planes 3-4 of the previous step, frame pose: issued where this wave is about to wait
+      // (every DPP read happens with the whole quad active: values are formed first, selected after, stored under the body mask last)
+      const float vx_all = Q_BC0(s.v), vy_all = Q_BC1(s.v);
+      const float pl1 = k.isv ? s.w : vx_all, pl2 = k.isv ? s.p : vy_all;
+      if (qbody) {
+        float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
+        stg(tj, boff_tj, s.r);
+        stg(tj + (size_t)4 * N, boff_tj, pl1);
+        stg(tj + (size_t)8 * N, boff_tj, pl2);
+        if (step > 0) {
+          float *tp = a.ws + (size_t)(step - 1) * (PD_TRAJ_G * 4) * N;
+          stg(tp + (size_t)12 * N, boff_tj, o_p3); stg(tp + (size_t)16 * N, boff_tj, o_p4);
+        }
+      }
+      if (fr >= 0) q_frame_out(fr, s);
+      pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
+      if (qbody && k.isv) {
+        float *f = facc + bb * PD_W6;
+        ft += f[qc]; ff += f[3 + qc];
+        f[qc] = 0.f; f[3 + qc] = 0.f;
+      }
+      const float grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
+      ft += jt; ff += jf;
+      if (fr >= 0 && qbody && k.isv) {  // force snapshots of a frame step
+        if (a.grf) { float *o = a.grf + ((size_t)fr * N + qidx) * 6; o[qc] = grf_t; o[3 + qc] = grf_f; }
+        if (a.jaf) { float *o = a.jaf + ((size_t)fr * N + qidx) * 6; o[qc] = ft - grf_t; o[3 + qc] = ff - grf_f; }
+      }
+      {  // plane 3: (v.z, t)
+        const float vz_all = Q_BC2(s.v), t_sh = q_dpp<PD_QP(0, 0, 1, 2)>(ft);
+        o_p3 = qc == 0 ? vz_all : t_sh;
+      }
+      // ---- integrate_bodies
+      float sink;
+      unsigned mask;
+      {
+        QM3 R1r, R1c;
+        s = q_integrate(k, B, s, Rr, Rc, rc, ft, ff, a.dt, R1r, R1c, rc, sink, mask);
+        Rr = R1r; Rc = R1c;
+      }
+      o_p4 = k.isv ? ff : __uint_as_float(mask);  // plane 4: (f, clamp mask)
+      {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
+        sunk += sink * a.dt;
+        const bool bad = qbody && B.sphere_w >= 0.0f && !(sunk <= 0.98f * margin);
+        spec_failed = __ballot(bad) != 0ull;
+      }
+      WAVE_SYNC();
+      {
+        const bool epoch = (step + 1) % PD_SPEC_K == 0;  // state step+1 opens a speculation epoch
+        if (epoch) { margin = q_margin(s); sunk = 0.f; }
+        q_stage(s, rc, Rr, margin, epoch ? spec + (((step + 1) / PD_SPEC_K) & 1) * nb : nullptr);
+      }
+    }
+    if (a.nsteps > 0 && qbody) {
+      float *tp = a.ws + (size_t)(a.nsteps - 1) * (PD_TRAJ_G * 4) * N;
+      stg(tp + (size_t)12 * N, boff_tj, o_p3); stg(tp + (size_t)16 * N, boff_tj, o_p4);
+    }
+    {  // a frame may name the state after the last step: pose / twist, zero force rows
+      const int fr_last = ld_uniform(a.frame_of_step, a.nsteps);
+      if (fr_last >= 0) {
+        q_frame_out(fr_last, s);
+        if (qbody && k.isv) {
+          if (a.grf) { a.grf[((size_t)fr_last * N + qidx) * 6 + qc] = 0.f; a.grf[((size_t)fr_last * N + qidx) * 6 + 3 + qc] = 0.f; }
+          if (a.jaf) { a.jaf[((size_t)fr_last * N + qidx) * 6 + qc] = 0.f; a.jaf[((size_t)fr_last * N + qidx) * 6 + 3 + qc] = 0.f; }
+        }
+      }
+    }
     return;
   }
   const size_t idx = (size_t)ec * nb + b;  // flat body index (env-major)
@@ -974,7 +1181,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
 // =============================================================================================
 // EARLY (SPLIT only): hand-over A is signalled from inside the adjoint of integrate_bodies, as soon as the wrench adjoint
 // exists (integrate_adj2), instead of after it.
-template <int SEGW, int JT, bool SPLIT, bool EARLY = false>
+// QUAD: the body wave in the four-lanes-per-body form (pd_quad.h), one env per wave, 64-lane mapping -- see k_rollout_fwd.
+template <int SEGW, int JT, bool SPLIT, bool EARLY = false, bool QUAD = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
@@ -1137,6 +1345,241 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       cnt_n = cnt_n2; e_n = e_n2;
     }
     STAMP_FLUSH(a);
+    return;
+  }
+  if constexpr (QUAD) {
+    static_assert(SEGW == 64 && SPLIT && !EARLY && JT == PD_JT_REVOLUTE, "quad-lane body wave: one env per wave, revolute-only plain models");
+    // ================= body wave, four lanes per body (see k_rollout_fwd): the reverse sweep of dp_model.py:1251-1400
+    const int qb = lane >> 2, qc = lane & 3, bb = qb < nb ? qb : nb - 1, qv = qc < 3 ? qc : 2;
+    const bool qbody = env_ok && qb < nb;
+    const QLane k = q_lane(qc);
+    const size_t qidx = (size_t)ec * nb + bb;
+    QBody B;
+    QM3 It, invIt;
+    float com_par0, com_par1, com_par2, p_pj0, p_pj1, p_pj2;
+    QPerm pjc;
+    {
+      const BodyConst cb = load_body_const(m, bb, ec);
+      B.type = cb.type; B.pidx = cb.pidx; B.qdstart = cb.qdstart;
+      B.joint = qbody && cb.type == PD_JOINT_REVOLUTE;
+      B.com = q_pick(k, cb.com); B.com0 = cb.com.x; B.com1 = cb.com.y; B.com2 = cb.com.z;
+      B.axis = q_pick(k, cb.axis); B.ax0 = cb.axis.x; B.ax1 = cb.axis.y; B.ax2 = cb.axis.z; B.alen = cb.alen;
+      B.p_pj = q_pick(k, cb.p_pj); B.q_pj = q_pick(k, cb.q_pj); B.pj = q_perm(k, B.q_pj);
+      pjc = q_perm(k, B.q_pj * k.sc);
+      com_par0 = cb.com_par.x; com_par1 = cb.com_par.y; com_par2 = cb.com_par.z;
+      p_pj0 = cb.p_pj.x; p_pj1 = cb.p_pj.y; p_pj2 = cb.p_pj.z;
+      B.g = q_pick(k, V3(m.gx, m.gy, m.gz));
+      B.reach = cb.reach; B.sphere_w = cb.sphere.w; B.lim = cb.lim[0];
+      B.inv_m = a.inv_mass[qidx];
+      const bool on = cb.type == PD_JOINT_REVOLUTE;
+      B.ke = on ? a.target_ke[(size_t)ec * m.nqd + cb.qdstart] : 0.f;
+      B.kd = on ? a.target_kd[(size_t)ec * m.nqd + cb.qdstart] : 0.f;
+      const float *Ib = a.inertia + qidx * 9, *Jb = a.inv_inertia + qidx * 9;
+      B.I.a = k.isv ? Ib[qv * 3] : 0.f; B.I.b = k.isv ? Ib[qv * 3 + 1] : 0.f; B.I.c = k.isv ? Ib[qv * 3 + 2] : 0.f;
+      B.invI.a = k.isv ? Jb[qv * 3] : 0.f; B.invI.b = k.isv ? Jb[qv * 3 + 1] : 0.f; B.invI.c = k.isv ? Jb[qv * 3 + 2] : 0.f;
+      It.a = k.isv ? Ib[qv] : 0.f; It.b = k.isv ? Ib[3 + qv] : 0.f; It.c = k.isv ? Ib[6 + qv] : 0.f;
+      invIt.a = k.isv ? Jb[qv] : 0.f; invIt.b = k.isv ? Jb[3 + qv] : 0.f; invIt.c = k.isv ? Jb[6 + qv] : 0.f;
+    }
+    int qcz[4];
+    const unsigned long long q_children = m.children[bb];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int cid = (int)((q_children >> (8 * j)) & 0xffull); qcz[j] = (qbody && cid != 0xff) ? cid : nb; }
+    if (lane < PD_ADJ) cslot[nb * PD_ADJ + lane] = 0.f;   // the zero record
+    if (qbody) {
+      float *d = cacc + bb * PD_ADJ;
+      d[3 + qc] = 0.f;
+      if (k.isv) { d[qc] = 0.f; d[7 + qc] = 0.f; d[10 + qc] = 0.f; }
+    }
+    QM3 g_I, g_invI;
+    g_I.a = g_I.b = g_I.c = 0.f; g_invI = g_I;
+    float g_inv_m = 0.f, g_ke = 0.f, g_kd = 0.f;
+    QAdj gn;
+    gn.p = gn.r = gn.w = gn.v = 0.f;
+    // stored state / wrench / controls of the NEXT iteration are prefetched: lane c owns float c of each trajectory plane
+    const unsigned boff_tj = (unsigned)(qidx * 4 + qc) * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + B.qdstart) * 4u;
+    const unsigned boff_rf = (unsigned)(qidx * 6 + qv) * 4u;
+    float n_pl[PD_TRAJ_G], n_tgt = 0.f;
+    int n_fr = -1;
+    auto load_step = [&](int step) {
+      const int sc = __builtin_amdgcn_readfirstlane(step >= 0 ? step : 0);
+      n_fr = a.frame_of_step[sc + 1];
+      const float *tj = a.ws + (size_t)sc * (PD_TRAJ_G * 4) * N;
+#pragma unroll
+      for (int g = 0; g < PD_TRAJ_G; ++g) n_pl[g] = ldg(tj + (size_t)(4 * g) * N, boff_tj);
+      const size_t o = (size_t)sc * a.bs * m.nqd;
+      n_tgt = B.joint ? ldg(a.refs + o, boff_qd) : 0.f;   // (the applied torque enters the adjoint through the contact wave's jf only)
+    };
+    auto q_seeds = [&](int fr) {  // dp_model.py:1264-1271
+      const float *gp = a.adj_pos + ((size_t)fr * N + qidx) * 7, *gv = a.adj_vel + ((size_t)fr * N + qidx) * 6;
+      const float sp = gp[qv], sr = gp[3 + qc], sw = gv[qv], sv = gv[3 + qv];
+      gn.p += k.isv ? sp : 0.f; gn.r += sr; gn.w += k.isv ? sw : 0.f; gn.v += k.isv ? sv : 0.f;
+    };
+    const float ake = m.attach_ke, akd = m.attach_kd;
+    if (a.nsteps > 0) load_step(a.nsteps - 1);
+    for (int step = a.nsteps - 1; step >= 0; --step) {
+      PD_WAIT_VMEM();
+      if (n_fr >= 0) q_seeds(n_fr);
+      // ---- unpack the stored step: planes q | (w, v.x) | (p, v.y) | (v.z, t) | (f, clamp mask)
+      QState s;
+      float t0, f0;
+      unsigned mask;
+      {
+        const float vx = Q_BC3(n_pl[1]), vy = Q_BC3(n_pl[2]), vz = Q_BC0(n_pl[3]);
+        const float tsh = q_dpp<PD_QP(1, 2, 3, 3)>(n_pl[3]);
+        mask = __float_as_uint(Q_BC3(n_pl[4]));
+        s.r = n_pl[0];
+        s.w = k.isv ? n_pl[1] : 0.f; s.p = k.isv ? n_pl[2] : 0.f;
+        s.v = qc == 0 ? vx : (qc == 1 ? vy : (qc == 2 ? vz : 0.f));
+        t0 = k.isv ? tsh : 0.f; f0 = k.isv ? n_pl[4] : 0.f;
+      }
+      const float tgt = n_tgt;
+      const size_t oc = (size_t)step * a.bs * m.nqd;
+      load_step(step - 1);
+      QM3 Rr, Rc;
+      q_rotm(k, s.r, Rr, Rc);
+      const float rc = q_mvc(Rr, B.com0, B.com1, B.com2);
+      if (qbody) {  // staging (stage_record): the contact wave reads records and cull vectors
+        float *r = rec + bb * PD_REC;
+        r[3 + qc] = s.r;
+        if (k.isv) { r[qc] = s.p; r[7 + qc] = s.w; r[10 + qc] = s.v; r[13 + qc] = rc; }
+        if (qc == 1) cull[bb] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
+      }
+      // ---- adjoint of integrate_bodies, phase 1: the wrench adjoint
+      QIntTmp T;
+      QM3 aR;
+      aR.a = aR.b = aR.c = 0.f;
+      float adj_t0, adj_f0;
+      q_integrate_adj_wrench(k, B, s, Rr, Rc, invIt, mask, t0, a.dt, gn, T, adj_t0, adj_f0);
+      if (qbody && k.isv) { adjf[bb * PD_W6 + qc] = adj_t0; adjf[bb * PD_W6 + 3 + qc] = adj_f0; }
+      pair_signal(sig, a.nsteps - step);  // A: records + wrench adjoints are staged
+      if (qbody && k.isv) {
+        float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
+        stg(o, boff_rf, NZ(adj_t0)); stg(o + 3, boff_rf, NZ(adj_f0));
+      }
+      // ---- phase 2 (needs nothing from the other wave)
+      QAdj ga;
+      q_integrate_adj_rest(k, B, s, Rr, It, t0, f0, a.dt, gn, T, ga, aR, g_inv_m, g_I, g_invI);
+      pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
+      // ---- adjoint of eval_body_joints
+      QAdj par;
+      par.p = par.r = par.w = par.v = 0.f;
+      float a_tgt = 0.f, a_act = 0.f, a_ke = 0.f, a_kd = 0.f;
+      {
+        const float *pr = rec + B.pidx * PD_REC, *pa = adjf + B.pidx * PD_W6;
+        const float l_pp = pr[qv], qp = pr[3 + qc], l_wp = pr[7 + qv], l_vp = pr[10 + qv], l_rcp = pr[13 + qv], l_gt = pa[qv], l_gf = pa[3 + qv];
+        const float pp = k.isv ? l_pp : 0.f, w_p = k.isv ? l_wp : 0.f, v_p = k.isv ? l_vp : 0.f, rc_par = k.isv ? l_rcp : 0.f;
+        const float gp_t = k.isv ? l_gt : 0.f, gp_f = k.isv ? l_gf : 0.f;
+        const QRev R = q_rev_load(k, jc + (step & 1) * m.env_lds_jc + bb * PD_JC, qv);
+        QAdj own, pj_;
+        own.p = own.r = own.w = own.v = 0.f;
+        QM3 aRj;
+        aRj.a = aRj.b = aRj.c = 0.f;
+        q_rev_adjoint(k, B, s, rc, pp, qp, w_p, v_p, rc_par, com_par0, com_par1, com_par2, p_pj0, p_pj1, p_pj2, pjc, R, tgt, ake, akd,
+                      adj_t0, adj_f0, gp_t, gp_f, own, pj_, aRj, a_tgt, a_act, a_ke, a_kd);
+        // a body without a joint (the FREE root, idle lanes) computed on the record of body pidx: dropped here
+        if (B.joint) {
+          ga.p += own.p; ga.r += own.r; ga.w += own.w; ga.v += own.v;
+          par = pj_;
+          aR.a += aRj.a; aR.b += aRj.b; aR.c += aRj.c;
+        } else {
+          a_tgt = 0.f; a_act = 0.f; a_ke = 0.f; a_kd = 0.f;
+        }
+      }
+      ga.r += q_rotm_adj(k, s.r, aR);
+      if (qbody) {
+        float *d = cslot + bb * PD_ADJ;
+        d[3 + qc] = par.r;
+        if (k.isv) { d[qc] = par.p; d[7 + qc] = par.w; d[10 + qc] = par.v; }
+        if (qc == 0) {
+          if (B.type == PD_JOINT_REVOLUTE) { stg(a.g_refs + oc, boff_qd, NZ(a_tgt)); stg(a.g_torques + oc, boff_qd, NZ(a_act)); }
+        }
+        // the root's six dof columns are zero (a FREE joint reads no dof, integrator_euler.py:382): lanes 0-5 of the root's quad
+        // and its neighbour write one each
+        if (B.type == PD_JOINT_FREE) {
+          stg(a.g_refs + oc + qc, boff_qd, 0.f); stg(a.g_torques + oc + qc, boff_qd, 0.f);
+          if (qc < 2) { stg(a.g_refs + oc + 4 + qc, boff_qd, 0.f); stg(a.g_torques + oc + 4 + qc, boff_qd, 0.f); }
+        }
+      }
+      g_ke += a_ke; g_kd += a_kd;
+      WAVE_SYNC();
+      {  // children (own joint's contribution went into ga above): all LDS reads in flight together
+        float cp[4], cr[4], cw[4], cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float *src = cslot + qcz[j] * PD_ADJ;
+          cp[j] = src[qv]; cr[j] = src[3 + qc]; cw[j] = src[7 + qv]; cv[j] = src[10 + qv];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ga.p += k.isv ? cp[j] : 0.f; ga.r += cr[j]; ga.w += k.isv ? cw[j] : 0.f; ga.v += k.isv ? cv[j] : 0.f; }
+      }
+      for (int j = 4; j < m.max_children; ++j) {
+        const int cid = (int)((q_children >> (8 * j)) & 0xffull);
+        if (qbody && cid != 0xff) {
+          const float *src = cslot + cid * PD_ADJ;
+          ga.r += src[3 + qc];
+          if (k.isv) { ga.p += src[qc]; ga.w += src[7 + qc]; ga.v += src[10 + qc]; }
+        }
+      }
+      pair_wait(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
+      if (qbody) {
+        float *d = cacc + bb * PD_ADJ;
+        ga.r += d[3 + qc];
+        d[3 + qc] = 0.f;
+        if (k.isv) {
+          ga.p += d[qc]; ga.w += d[7 + qc]; ga.v += d[10 + qc];
+          d[qc] = 0.f; d[7 + qc] = 0.f; d[10 + qc] = 0.f;
+        }
+      }
+      gn = ga;
+    }
+    if (a.frame_of_step[0] >= 0) q_seeds(a.frame_of_step[0]);  // seeds of state 0
+    // ---- adjoint of eval_fk, in the lane-per-body layout: the running adjoint is transposed through LDS
+    WAVE_SYNC();
+    if (qbody) {
+      float *d = cacc + bb * PD_ADJ;
+      d[3 + qc] = gn.r;
+      if (k.isv) { d[qc] = gn.p; d[7 + qc] = gn.w; d[10 + qc] = gn.v; }
+    }
+    WAVE_SYNC();
+    {
+      BodyAdj gs = adj_zero();
+      if (is_body) adj_add_from(gs, cacc + b * PD_ADJ);
+      if (a.nsteps == 0) {
+        for (int d = 0; d <= m.max_depth; ++d) {  // nothing staged yet: rebuild state 0
+          if (is_body && c.depth == d) {
+            BodyState s0 = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
+            stage_record(rec, b, s0, c.com);
+          }
+          WAVE_SYNC();
+        }
+      }
+      for (int d = m.max_depth; d >= 0; --d) {
+        if (is_body && c.depth == d) {
+          for (int j = 0; j < m.max_children; ++j) {
+            int cid = (int)((c.children >> (8 * j)) & 0xffull);
+            if (cid != 0xff) adj_add_from(gs, cslot + cid * PD_ADJ);
+          }
+          BodyAdj pr_ = fk_joint_adj<JT, 1>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
+                                          gs, a.g_q_init + (size_t)ec * m.nq + c.qstart, a.g_qd_init + (size_t)ec * m.nqd + c.qdstart);
+          adj_store(cslot + b * PD_ADJ, pr_);
+        }
+        WAVE_SYNC();
+      }
+    }
+    if (qbody) {
+      if (qc == 0) a.g_inv_mass[qidx] = NZ(g_inv_m);
+      if (k.isv) {
+        float *gi = a.g_inertia + qidx * 9 + qc * 3, *gj = a.g_inv_inertia + qidx * 9 + qc * 3;
+        gi[0] = NZ(g_I.a); gi[1] = NZ(g_I.b); gi[2] = NZ(g_I.c);
+        gj[0] = NZ(g_invI.a); gj[1] = NZ(g_invI.b); gj[2] = NZ(g_invI.c);
+      }
+      const size_t og = (size_t)ec * m.nqd + B.qdstart;
+      if (B.type == PD_JOINT_REVOLUTE && qc == 0) { a.g_ke[og] = NZ(g_ke); a.g_kd[og] = NZ(g_kd); }
+      if (B.type == PD_JOINT_FREE) {
+        a.g_ke[og + qc] = 0.f; a.g_kd[og + qc] = 0.f;
+        if (qc < 2) { a.g_ke[og + 4 + qc] = 0.f; a.g_kd[og + 4 + qc] = 0.f; }
+      }
+    }
     return;
   }
   const size_t idx = (size_t)ec * nb + b;
@@ -1955,6 +2398,14 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
   const size_t lds = cfg.lds;
   switch (kind) {
     case PD_K_ROLLOUT_FWD:
+      if (cfg.kernel == PD_KV_FWD_QUAD) {
+        if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
+          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          break;
+        } else {
+          return hipErrorInvalidValue;
+        }
+      }
       if (((const RolloutArgs *)args)->loss_target) {  // trajectory loss at the frame states (pd_rollout_forward_traj_loss)
         if (cfg.kernel == PD_KV_FWD_SPLIT)
           hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
@@ -1977,6 +2428,14 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
           break;
         }
 #endif
+        if (cfg.kernel == PD_KV_BWD_QUAD) {
+          if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
+            hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+            break;
+          } else {
+            return hipErrorInvalidValue;
+          }
+        }
         hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else {
 #ifdef PD_EXPERIMENT
@@ -2005,10 +2464,16 @@ static hipError_t set_lds_jt(int bytes) {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  }
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
+      if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    }
 #ifdef PD_EXPERIMENT
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;

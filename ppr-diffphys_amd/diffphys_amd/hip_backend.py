@@ -53,6 +53,9 @@ def lib():
         L.pd_model_destroy.argtypes = [ctypes.c_void_p]
         L.pd_model_set_segment_width.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.pd_model_get_segment_width.argtypes = [ctypes.c_void_p]
+        if hasattr(L, "pd_model_set_kernel_family"):
+            L.pd_model_set_kernel_family.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            L.pd_model_get_kernel_family.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         L.pd_last_kernel_ms.restype = ctypes.c_float
         L.pd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.pd_model_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -115,7 +118,7 @@ def source_hash():
     import hashlib
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "../../include/ppr_diffphys.h", "Makefile"]
+    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "../../include/ppr_diffphys.h", "Makefile"]
     h = hashlib.sha256()
     try:
         for f in srcs:
@@ -178,6 +181,15 @@ class DeviceModel:
 
     def segment_width(self):
         return int(lib().pd_model_get_segment_width(self.h))
+
+    def set_kernel_family(self, family):
+        """0 automatic (by batch size), 1 lane per body always, 2 quad-lane (four lanes per body) wherever the robot is eligible."""
+        _check(lib().pd_model_set_kernel_family(self.h, int(family)))
+
+    def kernel_family(self):
+        """(setting, eligible): eligible = the robot has quad-lane kernels (revolute-only, at most 16 bodies)."""
+        el = ctypes.c_int(0)
+        return int(lib().pd_model_get_kernel_family(self.h, ctypes.byref(el))), bool(el.value)
 
     def workspace_floats(self, bs, nsteps):
         return int(lib().pd_rollout_workspace_floats(self.h, bs, nsteps))

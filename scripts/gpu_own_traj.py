@@ -38,7 +38,11 @@ def cfg_inputs(cfg):
 
 for cfg in (sys.argv[1:] or ["C2", "C3", "C4", "C5"]):
     name, tpl, inp = cfg_inputs(cfg)
-    r = own_trajectory_check(hip_backend.DeviceModel(tpl), tpl, inp, dev)
+    dm = hip_backend.DeviceModel(tpl)
+    if "PD_FAMILY" in os.environ:  # 1 = lane per body always, 2 = quad-lane wherever eligible
+        dm.set_kernel_family(int(os.environ["PD_FAMILY"]))
+    r = own_trajectory_check(dm, tpl, inp, dev)
+    print("launch geometry fwd / bwd:", dm.last_launch_info(0), dm.last_launch_info(1))
     w = r["worst"]; bs = len(w)
     print("%s %s: %d envs; worst-tensor error per env: median %.2e p90 %.2e p99 %.2e p99.5 %.2e max %.2e" % (
         cfg, name, bs, np.median(w), np.percentile(w, 90), np.percentile(w, 99), np.percentile(w, 99.5), w.max()))

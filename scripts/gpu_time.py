@@ -26,6 +26,8 @@ for name, bs, segw in cfgs:
     T = 100
     inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=0, seqs=("mi-trot", "mi-spin"))
     dm = hip_backend.DeviceModel(tpl); dm.set_segment_width(segw); dm.set_timing(True)
+    if "PD_FAMILY" in os.environ:  # 1 = lane per body always, 2 = quad-lane wherever eligible (default: by batch size)
+        dm.set_kernel_family(int(os.environ["PD_FAMILY"]))
     t = {k: torch.from_numpy(inp[k]).to(dev) for k in synth.INPUT_NAMES}
     f2s = inp["frame2step"]; fos = list(f2s)
     fa = [t[k] for k in ("q_init","qd_init","torques","res_f","refs","target_ke","target_kd","body_inv_mass","body_inertia","body_inv_inertia")]
@@ -44,5 +46,5 @@ for name, bs, segw in cfgs:
             fs.append(dm.last_kernel_ms(0)); bs_.append(dm.last_kernel_ms(1))
     f, b = np.median(fs), np.median(bs_)
     nb, nqd = int(tpl["nb"]), int(tpl["nqd"]); C = 2 * nqd + 6 * nb; B = 4 * (26 * nb + 3 * C)
-    print("TIMING v%d g%s %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (
-        variant, os.environ.get("PD_GROUPS", "a"), name, bs, segw, f, b, bs * T / ((f + b) * 1e-3), 100 * bs * T / ((f + b) * 1e-3) * B / 8e12, B), flush=True)
+    print("TIMING v%d g%s f%s %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (
+        variant, os.environ.get("PD_GROUPS", "a"), os.environ.get("PD_FAMILY", "a"), name, bs, segw, f, b, bs * T / ((f + b) * 1e-3), 100 * bs * T / ((f + b) * 1e-3) * B / 8e12, B), flush=True)

@@ -126,7 +126,7 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(pd_[A-Za-z0-9_]+)\s*\(", hdr)))
-    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and "pd_build_id" in names and "pd_model_contact_order" in names and "pd_rollout_backward_traj_loss" in names and len(names) == 24
+    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and "pd_build_id" in names and "pd_model_contact_order" in names and "pd_rollout_backward_traj_loss" in names and "pd_model_set_kernel_family" in names and len(names) == 26
     lib = hip_backend.lib()
     for n in names:
         assert hasattr(lib, n), "missing symbol " + n
@@ -164,6 +164,7 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert lib.pd_foot_height_vjp(4, 13, *([None] * 7)) != 0 and lib.pd_foot_height_vjp(0, 13, *([None] * 7)) == 0
     assert lib.pd_model_bind_joint_X_p(None, None, 0) != 0
     assert lib.pd_model_contact_order(None, None, 0) != 0
+    assert lib.pd_model_set_kernel_family(None, 2) != 0 and lib.pd_model_get_kernel_family(None, None) == 0
     assert lib.pd_model_set_timing(None, 1) != 0
     assert lib.pd_last_kernel_ms(None, 0) < 0
     info = (ctypes.c_int * 4)()
