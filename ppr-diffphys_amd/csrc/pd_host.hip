@@ -671,7 +671,9 @@ void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
 // adjoint kernel of revolute-only robots for A/B timing (scripts/gpu_time.py): 0 = shipped (2-role, hand-over A after
 // integrate_adj), 1 = 2-role with the early hand-over, 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 9 = the unsplit kernel
 void pd_debug_set_variant(int v) { g_variant = v; }
+#ifdef PD_EXPERIMENT
 void pd_debug_set_own_joint(int v) { g_own_joint = v; }
+#endif
 void pd_debug_set_groups(int g) { g_groups = g < 0 ? 0 : (g > PD_BWAVES ? PD_BWAVES : g); }
 #endif
 
