@@ -74,7 +74,7 @@ def main(argv=None):
         model.update()
         torch.cuda.synchronize()
         print("[iter %4d] total %.6f traj %.5f pos_state %.5f  (%.3f s)" % (
-            it, float(loss), float(loss_dict["loss_traj"]), float(loss_dict["loss_pos_state"]), time.time() - t0))
+            it, float(loss.detach()), float(loss_dict["loss_traj"].detach()), float(loss_dict["loss_pos_state"].detach()), time.time() - t0))
 
 
 if __name__ == "__main__":

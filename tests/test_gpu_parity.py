@@ -127,15 +127,19 @@ def test_long_rollout_statistics_and_invariants(dev, oracle_libs):
     assert np.abs(out["grads"]["refs"].reshape(T, bs, 18)[:, :, :6]).max() == 0  # FREE joint reads no dof (:382)
 
 
-def test_full_size_properties_and_batch_invariance(dev):
+@pytest.mark.parametrize("family", [1, 2], ids=["lane-per-body", "quad-lane"])
+def test_full_size_properties_and_batch_invariance(family, dev):
     """Headline size (4096 envs x 100 steps): finiteness, clamps, and an env's result does not depend on
-    which other envs share its wavefront / launch (run a 37-env prefix alone, compare bit for bit)."""
+    which other envs share its wavefront / launch (run a 37-env prefix alone, compare bit for bit) -- WITHIN a kernel family: the
+    lane-per-body kernels and the quad-lane kernels (pd_model_set_kernel_family; by default the batch size picks between them, so a
+    batch of <= 512 / 1 024 envs and the same envs inside a larger batch differ by fp32 round-off) each reproduce their own bits."""
     from diffphys_amd import hip_backend, robots, synth
 
     tpl = robots.load_template("laikago")
     bs, T, sub = 4096, 100, 37
     inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=9, seqs=("mi-trot", "mi-spin"))
     dm = hip_backend.DeviceModel(tpl)
+    dm.set_kernel_family(family)
     full = gpu_rollout(dm, inp, dev)
     assert all(np.isfinite(full[k]).all() for k in ("wp_pos", "wp_vel", "grf", "jaf"))
     assert all(np.isfinite(v).all() for v in full["grads"].values())
@@ -645,7 +649,8 @@ def test_many_contacts_overflow_paths(segw, dev, oracle_libs):
 
 
 @pytest.mark.gpu
-def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle_libs):
+@pytest.mark.parametrize("family", [1, 2], ids=["lane-per-body", "quad-lane"])
+def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(family, dev, oracle_libs):
     """The wave-specialised forward culls ground contacts one epoch ahead with a per-body sink margin and must fall back
     to the exact sweep when a body moves further than that.  Downward kicks of 3000 m/s^2 on every body from step 3 on
     (|dv_y| = 1.5 m/s per step: the margin of the epoch's first state is outrun within two steps) force that path;
@@ -663,7 +668,9 @@ def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle
     kick[3:16, ::2] = 3000.0      # every other env: its wave-mates stay calm, the wave must still redo the sweep
     kick[8:20, 1::4] = 1500.0
     rf[..., 4] -= kick[:, :, None] * mass[None]
-    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
+    dm = hip_backend.DeviceModel(tpl)
+    dm.set_kernel_family(family)   # (both families speculate the cull the same way: the contact wave is shared code)
+    out = gpu_rollout(dm, inp, dev)
     rc = RefC(tpl, np.float32)
     st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
     gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
@@ -671,7 +678,16 @@ def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle
     assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-4 and relmax(out["wp_vel"], st["wp_vel"]) < 5e-3
     assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 1e-2
     for k in ("q_init", "qd_init", "res_f", "refs", "body_inv_mass"):
-        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+        # (another fp32 trajectory than the fp32 oracle's through 26 violent steps: 2e-2 measured for the lane-per-body kernels, 2.7e-2 for
+        # the quad-lane ones; the tight per-env gradient check is tests/test_gpu_tight.py's own-trajectory test, run for both families)
+        e_k = relmax(out["grads"][k].reshape(gr[k].shape), gr[k])
+        assert family == 2 or e_k < 2e-2, (k, e_k)
+    # ... and, for both families, against the float64 adjoint of the kernel's OWN trajectory (helpers.own_trajectory_check): no chaos in
+    # that comparison, every env measured (24 envs x 26 violent steps; measured worst env 1.3e-4 / 1.7e-4)
+    from helpers import own_trajectory_check
+    chk = own_trajectory_check(dm, tpl, inp, dev)
+    print("family %d: own-trajectory worst env %.1e (median %.1e), hit-log entries missing %d" % (family, chk["worst"].max(), np.median(chk["worst"]), chk["hitlog_missing"]))
+    assert chk["hitlog_missing"] == 0 and chk["worst"].max() < 1e-3, (float(chk["worst"].max()), chk["hitlog_missing"])
     # batch-composition invariance: the same envs alone (different wave-mates, different redo pattern) give the same bits
     sub = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in inp.items()}
     pick = np.arange(1, bs, 3)
@@ -682,7 +698,9 @@ def test_speculative_sweep_is_redone_when_bodies_outrun_their_margin(dev, oracle
     F = len(inp["frame2step"])
     for k in ("adj_pos", "adj_vel"):
         sub[k] = inp[k].reshape(F, bs, -1)[:, pick].reshape(F, -1)
-    out2 = gpu_rollout(hip_backend.DeviceModel(tpl), sub, dev)
+    dm2 = hip_backend.DeviceModel(tpl)
+    dm2.set_kernel_family(family)
+    out2 = gpu_rollout(dm2, sub, dev)
     assert np.array_equal(out2["wp_pos"].reshape(F, len(pick), -1), out["wp_pos"].reshape(F, bs, -1)[:, pick])
     assert np.array_equal(out2["grads"]["q_init"].reshape(len(pick), -1), out["grads"]["q_init"].reshape(bs, -1)[pick])
 
@@ -828,6 +846,9 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     h = Host()
     h.env = robots.env_from_template(name, bs, device=dev)
     h.num_envs, h.steps_idx, h.frame2step, h.dt = bs, range(T), f2s, inp["dt"]
+    # like with like: the rollout launch that also evaluates the loss exists in the lane-per-body form only, so a small Laikago batch
+    # (which would take the quad-lane kernels in the plain ForwardWarp) is pinned to that family for the comparison
+    hip_backend.device_model(h.env).set_kernel_family(1)
     t = {k: torch.from_numpy(inp[k]).to(dev).requires_grad_(True) for k in synth.INPUT_NAMES}
     args = [t[k] for k in synth.INPUT_NAMES]
     with torch.no_grad():
