@@ -342,7 +342,6 @@ static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
 // chip with one workgroup per CU (1 024 on MI355X); beyond that the lane-per-body kernels (four envs per wave) have the throughput.
 static bool use_quad(const pd_model *m, int kind, int n_envs, const void *args) {
   if (!m->quad || m->family == 1 || (kind != PD_K_ROLLOUT_FWD && kind != PD_K_ROLLOUT_BWD)) return false;
-  if (kind == PD_K_ROLLOUT_FWD && ((const RolloutArgs *)args)->loss_target) return false;  // the trajectory-loss instantiation exists in the lane-per-body form only
   // forward: while one workgroup per CU holds the batch (4 x CUs envs); adjoint: while every wave has a SIMD to itself (2 x CUs) --
   // measured: 1 024 envs forward 0.153 ms against 0.184, adjoint 0.273 against 0.244 (two quad pairs per SIMD lose)
   return m->family == 2 || n_envs <= (kind == PD_K_ROLLOUT_FWD ? PD_BWAVES : PD_BWAVES / 2) * m->quad->dev.cu_count;

@@ -499,7 +499,7 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // hand-overs, same trajectory layout: the adjoint kernels run on what it saves.
 template <int SEGW, int JT, bool SPLIT, bool LOSS = false, bool QUAD = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
-  static_assert(!QUAD || (SEGW == 64 && SPLIT && JT == PD_JT_REVOLUTE && !LOSS), "quad-lane body wave: one env per wave, revolute-only plain models");
+  static_assert(!QUAD || (SEGW == 64 && SPLIT && JT == PD_JT_REVOLUTE), "quad-lane body wave: one env per wave, revolute-only plain models");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
@@ -765,6 +765,35 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         o[3 + qc] = x.r;
         float *ov = a.wp_vel + ((size_t)cfr * N + qidx) * 6;
         if (k.isv) { o[qc] = x.p; ov[qc] = x.w; ov[3 + qc] = x.v; }
+      }
+      if constexpr (LOSS) {
+        // trajectory loss of this frame (see frame_loss of the lane-per-body form): the body's pose is gathered into every lane of
+        // its quad, se3_loss runs redundantly in the four lanes, lane c stores components c and 3 + c of the two gradients
+        const float pose[7] = {Q_BC0(x.p), Q_BC1(x.p), Q_BC2(x.p), Q_BC0(x.r), Q_BC1(x.r), Q_BC2(x.r), Q_BC3(x.r)};
+        float lb = 0.f;
+        const size_t ot = (((size_t)ec * a.nframes + cfr) * nb + bb) * 7;
+        float tg[7], gp[7], gg[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) tg[j] = a.loss_target[ot + j];
+        lb = pd_se3::se3_loss_eval<7>(pose, tg, a.loss_rot_ratio, true, gp, gg);
+        const float gp_v = qc == 0 ? gp[0] : (qc == 1 ? gp[1] : gp[2]), gp_q = qc == 0 ? gp[3] : (qc == 1 ? gp[4] : (qc == 2 ? gp[5] : gp[6]));
+        const float gg_v = qc == 0 ? gg[0] : (qc == 1 ? gg[1] : gg[2]), gg_q = qc == 0 ? gg[3] : (qc == 1 ? gg[4] : (qc == 2 ? gg[5] : gg[6]));
+        if (qbody) {
+          float *o = a.loss_seed_pos + ((size_t)cfr * N + qidx) * 7;
+          o[3 + qc] = gp_q;
+          if (k.isv) o[qc] = gp_v;
+          if (a.loss_seed_gt) {
+            a.loss_seed_gt[ot + 3 + qc] = gg_q;
+            if (k.isv) a.loss_seed_gt[ot + qc] = gg_v;
+          }
+        }
+        lb = (qbody && qc == 0) ? lb : 0.f;   // one lane per body carries the body's loss into the mean over bodies (dp_model.py:777)
+#pragma unroll
+        for (int w = 32; w >= 1; w >>= 1) lb += __shfl_xor(lb, w, 64);
+        if (lane == 0 && env_ok) {
+          const size_t oe = (size_t)ec * a.nframes + cfr;
+          a.loss_table[oe] = (a.loss_outseq && a.loss_outseq[oe]) ? 0.f : lb / (float)nb;
+        }
       }
     };
     float o_p3 = 0.f, o_p4 = 0.f;  // planes 3 / 4 of the previous step (its total wrench and clamp mask), stored one step late
@@ -2400,7 +2429,10 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
     case PD_K_ROLLOUT_FWD:
       if (cfg.kernel == PD_KV_FWD_QUAD) {
         if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
-          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          if (((const RolloutArgs *)args)->loss_target)
+            hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          else
+            hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
           break;
         } else {
           return hipErrorInvalidValue;
@@ -2466,6 +2498,7 @@ static hipError_t set_lds_jt(int bytes) {
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   }
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;

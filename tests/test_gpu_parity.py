@@ -846,9 +846,7 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     h = Host()
     h.env = robots.env_from_template(name, bs, device=dev)
     h.num_envs, h.steps_idx, h.frame2step, h.dt = bs, range(T), f2s, inp["dt"]
-    # like with like: the rollout launch that also evaluates the loss exists in the lane-per-body form only, so a small Laikago batch
-    # (which would take the quad-lane kernels in the plain ForwardWarp) is pinned to that family for the comparison
-    hip_backend.device_model(h.env).set_kernel_family(1)
+    # (a small Laikago batch takes the quad-lane kernels in BOTH paths: their forward kernel has the loss-evaluating instantiation too)
     t = {k: torch.from_numpy(inp[k]).to(dev).requires_grad_(True) for k in synth.INPUT_NAMES}
     args = [t[k] for k in synth.INPUT_NAMES]
     with torch.no_grad():

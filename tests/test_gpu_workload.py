@@ -198,9 +198,7 @@ def test_fused_traj_loss_equals_the_torch_sequence_on_the_training_window(seq, d
 
     model, opts = _model(seq, "f4")
     model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"])
-    # like with like: the loss-evaluating rollout launch is a lane-per-body kernel; the plain ForwardWarp of a 10-env batch would take
-    # the quad-lane forward kernel (another fp32 round-off) -- both paths are pinned to the lane-per-body family here
-    hip_backend.device_model(model.env).set_kernel_family(1)
+    assert hip_backend.device_model(model.env).kernel_family() == (0, True)   # 10 Laikago envs: the quad-lane kernels, in both paths
     NF = model.total_frames
     fs = torch.arange(10, device=model.device) % (NF - 24)
     noise = (torch.randn(10 * 19, generator=torch.Generator().manual_seed(3)) * 0.01).to(model.device)
