@@ -112,6 +112,18 @@ for case in range(ncases):
         unexpl = (excess > 1.0) & (first >= T) & (excess > 30 * ob["cond"] / 1e-3)
         if not unexpl.any():
             ok, note = True, "every env explained (%d of %d off a bar, %d with a branch difference)" % ((excess > 1.0).sum(), bs, (first < T).sum())
+    # round 4: the airtight comparison on top -- the kernel's gradients against the float64 adjoint of the kernel's OWN trajectory with its
+    # decisions forced (tests/helpers.own_trajectory_check): no chaos, every env.  Bar: 1e-2 per env, or no worse than twice the plain
+    # fp32 evaluation of the same adjoint on the same trajectory (violent cases sit on the +-500 N clamps and the Coulomb switch, which
+    # float64 re-decides); every touching candidate the restated decision finds must be in the kernel's hit log
+    from helpers import own_trajectory_check
+    chk = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)   # (seeds are ~1e-3: a gradient below 1e-8 is zero for every purpose)
+    own_w = chk["worst"]
+    own_ok = chk["hitlog_missing"] == 0 and bool(np.all((own_w < 1e-2) | (own_w < 2.0 * chk["fp32_atan2"]) | (chk["coulomb"] < 1e-3) | (chk["force_clamp"] < 2e-2)))
+    if not own_ok:
+        ok = False
+        note += " OWN-TRAJECTORY worst %.1e (fp32 %.1e) missing %d" % (own_w.max(), chk["fp32_atan2"].max(), chk["hitlog_missing"])
+    note += " own %.0e" % own_w.max()
     bad += 0 if ok else 1
     if not ok:  # keep the failing case for offline inspection
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
