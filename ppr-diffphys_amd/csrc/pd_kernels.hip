@@ -529,14 +529,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   int *sig = (int *)(scratch - (size_t)seg * m.env_lds_floats + spec_off + 8 * nb) + 1;  // pair signals: words 1, 2 after the first env's flag
   int *list = spec_bad + 4, *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
-#ifdef PD_CTRL_LDS
-  // experiment: the contact wave fetches the controls of the next step and hands them over through LDS with hand-over B
-  constexpr bool CTL = SPLIT && JT == PD_JT_REVOLUTE && !QUAD;
-#else
-  constexpr bool CTL = false;
-#endif
-  const int cb_off = ((int)(slot - scratch) + 1) & ~1;              // the forward sums by ds_add: slot[] is free
-  const int CS = (2 * m.nqd + 6 * nb + 1) & ~1;                     // floats per generation: refs | torques | res_f
   if (SPLIT) {
     if (lane == 0) { sig[0] = 0; sig[1] = 0; }
     __syncthreads();
@@ -571,44 +563,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     bool two = false;        // wave-uniform: some env has more candidates than lanes (<= 2 SEGW): lane j also keeps candidate SEGW + j
     int c_e = 0, c_e2 = 0;
     float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P, c_P2 = c_P, c_M2 = c_P;
-    // CTL: lane -> (env of the wave, float2 of its controls)
-    float *cbw = scratch - (size_t)seg * m.env_lds_floats + cb_off;
-    unsigned gq = 0u, gr[3] = {0u, 0u, 0u};
-    int dq = 0, dr[3] = {0, 0, 0};
-    bool okq = false, okr[3] = {false, false, false};
-    float2 cq = make_float2(0.f, 0.f), ct = cq, cr[3] = {cq, cq, cq};
-    auto ctl_map = [&](int i, int per, int gstride, int doff, unsigned &goff, int &dst) {
-      const int e = i / per, j = i - e * per;
-      const bool ok = e < EPW;
-      const int ee = ok ? e : 0;
-      int ev = env - seg + ee;
-      ev = ev < a.bs ? ev : a.bs - 1;
-      goff = (unsigned)(ev * gstride + 2 * j) * 4u;
-      dst = ee * m.env_lds_floats + doff + 2 * j;
-      return ok;
-    };
-    auto ctl_load = [&](int step) {
-      const int sc = __builtin_amdgcn_readfirstlane(step < a.nsteps ? step : a.nsteps - 1);
-      const size_t o = (size_t)sc * a.bs * m.nqd;
-      cq = ldg2(a.refs + o, gq); ct = ldg2(a.torques + o, gq);
-      const float *rf = a.res_f + (size_t)sc * N * 6;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cr[k] = ldg2(rf, gr[k]);
-    };
-    auto ctl_write = [&](int gen) {
-      float *d = cbw + gen * CS;
-      if (okq) { *(float2 *)(d + dq) = cq; *(float2 *)(d + dq + m.nqd) = ct; }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) if (okr[k]) *(float2 *)(d + dr[k]) = cr[k];
-    };
-    if constexpr (CTL) {
-      okq = ctl_map(lane, m.nqd >> 1, m.nqd, 0, gq, dq);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) okr[k] = ctl_map(lane + 64 * k, 3 * nb, 6 * nb, 2 * m.nqd, gr[k], dr[k]);
-      ctl_load(1);
-      ctl_write(1);  // published by hand-over B of step 0
-      ctl_load(2);
-    }
     for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
       // A: records + cull vectors of this step are staged, wrench accumulators are zero; bit 30: a body of one of my envs
@@ -674,10 +628,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
       STAMP(12);
       pair_signal(sig + 1, step + 1);  // B: contact wrenches are complete
-      if constexpr (CTL) {  // the controls of step + 2 (fetched a step ago) go out with the NEXT hand-over B; the body wave read this generation at the top of this step
-        ctl_write(step & 1);
-        ctl_load(step + 3);
-      }
       const bool cull_now = step % PD_SPEC_K == 0 && step + 1 < a.nsteps;  // state `step` opened an epoch: cull for the steps it serves
       if (!cull_now) __builtin_amdgcn_s_setprio(0);  // (the cull stays urgent: the next hit pass needs its candidates)
       // the adjoint's log is written off the critical path
@@ -1068,16 +1018,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
   };
   if (a.nsteps > 0) load_controls(0);
-  float *cb = scratch + cb_off;
-  if constexpr (CTL) {  // step 0's controls: fetched here, then every step reads generation step & 1
-    PD_WAIT_VMEM();
-    if (is_body) {
-      if (ndof > 0) { cb[c.qdstart] = n_tgt[0]; cb[m.nqd + c.qdstart] = n_act[0]; }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) cb[2 * m.nqd + 6 * b + k] = n_rf[k];
-    }
-    WAVE_SYNC();
-  }
   // unsplit kernel: the speculated candidates of this wave's envs (see the sweep in the loop)
   int u_since = PD_SPEC_K, u_nh = 0, u_e = 0;
   bool u_have = false, u_owns = false;
@@ -1088,25 +1028,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     // contact wave starts sweeping while this wave still unpacks controls and spills the state
     if (SPLIT) pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: hand this step's records to the contact wave
     STAMP(0);
+    PD_WAIT_VMEM();
     float tgt[ND], act[ND];
-    v3 ft, ff;
-    int fr;
-    if constexpr (CTL) {
-      const float *cg = cb + (step & 1) * CS;
-      tgt[0] = ndof > 0 ? cg[c.qdstart] : 0.f; act[0] = ndof > 0 ? cg[m.nqd + c.qdstart] : 0.f;
-      const float2 r0 = *(const float2 *)(cg + 2 * m.nqd + 6 * b), r1 = *(const float2 *)(cg + 2 * m.nqd + 6 * b + 2),
-                   r2 = *(const float2 *)(cg + 2 * m.nqd + 6 * b + 4);
-      ft = V3(r0.x, r0.y, r1.x); ff = V3(r1.y, r2.x, r2.y);
-      fr = n_fr;
-      n_fr = ld_uniform(a.frame_of_step, __builtin_amdgcn_readfirstlane(step + 1 < a.nsteps ? step + 1 : a.nsteps - 1));
-    } else {
-      PD_WAIT_VMEM();
 #pragma unroll
-      for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
-      ft = V3(n_rf[0], n_rf[1], n_rf[2]); ff = V3(n_rf[3], n_rf[4], n_rf[5]);  // clear_forces + wp_add
-      fr = n_fr;
-      load_controls(step + 1);
-    }
+    for (int k = 0; k < ND; ++k) { tgt[k] = n_tgt[k]; act[k] = n_act[k]; }
+    v3 ft = V3(n_rf[0], n_rf[1], n_rf[2]), ff = V3(n_rf[3], n_rf[4], n_rf[5]);  // clear_forces + wp_add
+    const int fr = n_fr;
+    load_controls(step + 1);
     if (!SPLIT) {
       // Unsplit kernel (compound / generic robots at large batches): the same speculation as the contact wave's, inline (round 3;
       // rounds 1-2 ran the exact three-level sweep here EVERY step: ~38 % of quad's forward step).  Every PD_SPEC_K steps -- or at
