@@ -799,13 +799,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     float o_p3 = 0.f, o_p4 = 0.f;  // planes 3 / 4 of the previous step (its total wrench and clamp mask), stored one step late
     if (a.nsteps > 0) load_controls(0);
     const float ake = m.attach_ke, akd = m.attach_kd;
+    STAMP_DECL;
     for (int step = 0; step < a.nsteps; ++step) {
       pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: this step's records are staged
+      STAMP(0);
       PD_WAIT_VMEM();
       const float tgt = n_tgt, act = n_act;
       float ft = k.isv ? n_rft : 0.f, ff = k.isv ? n_rff : 0.f;  // clear_forces + wp_add
       const int fr = n_fr;
       load_controls(step + 1);
+      STAMP(1);
       // ---- eval_body_joints (while the contact wave sweeps)
       float wp_t, wc_t, jf_;
       {
@@ -816,6 +819,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
       wp_t = B.joint ? wp_t : 0.f; wc_t = B.joint ? wc_t : 0.f; jf_ = B.joint ? jf_ : 0.f;
       if (qbody && k.isv) { pcon[bb * PD_W6 + qc] = wp_t; pcon[bb * PD_W6 + 3 + qc] = jf_; }
+      STAMP(2);
       WAVE_SYNC();
       float jt = -wc_t, jf = -jf_;  // joint wrench on this body: own joint first, then children in index order
       {
@@ -830,6 +834,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         if (qbody && cid != 0xff) { jt += pcon[cid * PD_W6 + qv]; jf += pcon[cid * PD_W6 + 3 + qv]; }
       }
       jt = k.isv ? jt : 0.f; jf = k.isv ? jf : 0.f;
+      STAMP(6);
       // ---- trajectory planes 0-2 of this state, planes 3-4 of the previous step, frame pose: issued where this wave is about to wait
       // (every DPP read happens with the whole quad active: values are formed first, selected after, stored under the body mask last)
       const float vx_all = Q_BC0(s.v), vy_all = Q_BC1(s.v);
@@ -845,7 +850,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         }
       }
       if (fr >= 0) q_frame_out(fr, s);
+      STAMP(8);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
+      STAMP(9);
       if (qbody && k.isv) {
         float *f = facc + bb * PD_W6;
         ft += f[qc]; ff += f[3 + qc];
@@ -861,6 +868,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         const float vz_all = Q_BC2(s.v), t_sh = q_dpp<PD_QP(0, 0, 1, 2)>(ft);
         o_p3 = qc == 0 ? vz_all : t_sh;
       }
+      STAMP(3);
       // ---- integrate_bodies
       float sink;
       unsigned mask;
@@ -870,6 +878,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         Rr = R1r; Rc = R1c;
       }
       o_p4 = k.isv ? ff : __uint_as_float(mask);  // plane 4: (f, clamp mask)
+      STAMP(4);
       {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
         sunk += sink * a.dt;
         const bool bad = qbody && B.sphere_w >= 0.0f && !(sunk <= 0.98f * margin);
@@ -881,7 +890,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         if (epoch) { margin = q_margin(s); sunk = 0.f; }
         q_stage(s, rc, Rr, margin, epoch ? spec + (((step + 1) / PD_SPEC_K) & 1) * nb : nullptr);
       }
+      STAMP(5);
     }
+    STAMP_FLUSH(a);
     if (a.nsteps > 0 && qbody) {
       float *tp = a.ws + (size_t)(a.nsteps - 1) * (PD_TRAJ_G * 4) * N;
       stg(tp + (size_t)12 * N, boff_tj, o_p3); stg(tp + (size_t)16 * N, boff_tj, o_p4);
@@ -1132,7 +1143,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       spill_state(step, s, fr);
       if (step > 0) spill_wrench(step - 1);
       if (LOSS && fr >= 0) frame_loss(fr, s);
+      STAMP(8);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
+      STAMP(9);
     } else {
       spill_state(step, s, fr);
       if (step > 0) spill_wrench(step - 1);

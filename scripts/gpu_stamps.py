@@ -48,8 +48,9 @@ def report(lab, who, r, names):
         print("      %-52s %6.1f%%   %8.0f cycles/step" % (n, 100 * r[:, i].mean() / tot, r[:, i].mean() / T))
 
 
-fn = [(0, "top: controls + spill stores"), (1, "wait at barrier A"), (2, "joints fwd + pcon write"), (6, "child gather"),
-      (3, "wait at barrier B + facc + traj_f/frame stores"), (4, "integrate"), (5, "stage record")]
+fn = [(0, "signal A"), (1, "vmcnt wait, control unpack, next controls issued"), (2, "joints fwd + pcon write"), (6, "child gather"),
+      (8, "trajectory / frame stores issued"), (9, "wait at barrier B"), (3, "facc read + wrench sums + force snapshots"), (4, "integrate"),
+      (5, "stage record")]
 cn = [(7, "wait at barrier A/A1 (idle)"), (8, "L1 body cull"), (9, "L2 tile cull"), (10, "L3 point cull"), (11, "hit pass"), (12, "tail")]
 report("FWD", "body wave", rows(f_all, 0), fn)
 if wf >= 2 * G:

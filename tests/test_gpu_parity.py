@@ -825,7 +825,7 @@ def test_more_contact_candidates_than_fit_at_the_default_width(dev, oracle_libs)
         assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
 
 
-@pytest.mark.parametrize("name,bs", [("laikago", 37), ("human", 9)])
+@pytest.mark.parametrize("name,bs", [("laikago", 37), ("human", 9), ("laikago", 6700)])  # 6700 x 5 entries: the reduce kernel's table no longer fits LDS
 def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(name, bs, dev):
     """Row f4 at the C ABI: pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss against ForwardWarp.apply -> pd_se3_loss ->
     torch reduce_loss(clip=True) (dp_model.py:733-779, dp_utils.py:93-138) on the same inputs: the reduced loss, the [bs, F] table, the
