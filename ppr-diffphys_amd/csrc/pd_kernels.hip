@@ -1458,6 +1458,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     };
     const float ake = m.attach_ke, akd = m.attach_kd;
     if (a.nsteps > 0) load_step(a.nsteps - 1);
+    STAMP_DECL;
     for (int step = a.nsteps - 1; step >= 0; --step) {
       PD_WAIT_VMEM();
       if (n_fr >= 0) q_seeds(n_fr);
@@ -1486,6 +1487,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         if (k.isv) { r[qc] = s.p; r[7 + qc] = s.w; r[10 + qc] = s.v; r[13 + qc] = rc; }
         if (qc == 1) cull[bb] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
       }
+      STAMP(0);
       // ---- adjoint of integrate_bodies, phase 1: the wrench adjoint
       QIntTmp T;
       QM3 aR;
@@ -1494,6 +1496,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       q_integrate_adj_wrench(k, B, s, Rr, Rc, invIt, mask, t0, a.dt, gn, T, adj_t0, adj_f0);
       if (qbody && k.isv) { adjf[bb * PD_W6 + qc] = adj_t0; adjf[bb * PD_W6 + 3 + qc] = adj_f0; }
       pair_signal(sig, a.nsteps - step);  // A: records + wrench adjoints are staged
+      STAMP(1);
       if (qbody && k.isv) {
         float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
         stg(o, boff_rf, NZ(adj_t0)); stg(o + 3, boff_rf, NZ(adj_f0));
@@ -1501,7 +1504,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       // ---- phase 2 (needs nothing from the other wave)
       QAdj ga;
       q_integrate_adj_rest(k, B, s, Rr, It, t0, f0, a.dt, gn, T, ga, aR, g_inv_m, g_I, g_invI);
+      STAMP(5);
       pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
+      STAMP(6);
       // ---- adjoint of eval_body_joints
       QAdj par;
       par.p = par.r = par.w = par.v = 0.f;
@@ -1527,6 +1532,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
           a_tgt = 0.f; a_act = 0.f; a_ke = 0.f; a_kd = 0.f;
         }
       }
+      STAMP(2);
       ga.r += q_rotm_adj(k, s.r, aR);
       if (qbody) {
         float *d = cslot + bb * PD_ADJ;
@@ -1543,6 +1549,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         }
       }
       g_ke += a_ke; g_kd += a_kd;
+      STAMP(7);
       WAVE_SYNC();
       {  // children (own joint's contribution went into ga above): all LDS reads in flight together
         float cp[4], cr[4], cw[4], cv[4];
@@ -1562,7 +1569,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
           if (k.isv) { ga.p += src[qc]; ga.w += src[7 + qc]; ga.v += src[10 + qc]; }
         }
       }
+      STAMP(3);
       pair_wait(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
+      STAMP(8);
       if (qbody) {
         float *d = cacc + bb * PD_ADJ;
         ga.r += d[3 + qc];
@@ -1573,7 +1582,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         }
       }
       gn = ga;
+      STAMP(4);
     }
+    STAMP_FLUSH(a);
     if (a.frame_of_step[0] >= 0) q_seeds(a.frame_of_step[0]);  // seeds of state 0
     // ---- adjoint of eval_fk, in the lane-per-body layout: the running adjoint is transposed through LDS
     WAVE_SYNC();
