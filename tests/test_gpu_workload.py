@@ -108,7 +108,13 @@ def test_reference_training_window_and_eval_pass(seq, dev, oracle_libs):
     got_pos = np.stack([np.asarray(model.sim_trajs[f]) for f in (0, 1)], 0)            # env 0, frames 0 and 1
     assert relmax(got_pos, st["wp_pos"].reshape(2, 10, 13, 7)[:, 0]) < 5e-5
     grf = torch.stack(model.grfs[:2], 0).cpu().numpy()
-    assert relmax(grf, st["grf"]) < 5e-3
+    # contact forces at frame 1 are as well conditioned as the stance: after the 83-step frame intervals of mi-sidesteps / mi-turn a
+    # foot that barely touches carries a force that fp32 rounding moves by percents (measured, relmax against float64: the plain fp32 C
+    # oracle 3.5e-2 on mi-sidesteps, the lane-per-body kernels 3e-3, the quad-lane kernels 2e-2; 1e-4 on the 33-step sequences).
+    # Yardstick = what the fp32 C oracle loses on the same arguments
+    st32 = RefC(tpl, np.float32).rollout_forward(inp34, SPF + 1, [0, SPF], dt)
+    cond = relmax(st32["grf"], st["grf"])
+    assert relmax(grf, st["grf"]) < max(5e-3, 2.0 * cond), (relmax(grf, st["grf"]), cond)
     model.backward(out["total_loss"])
     gd = model.update()
     assert len(gd) > 0 and all(torch.isfinite(v) for v in gd.values())
