@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 5   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels) */
+#define PD_ABI_VERSION 6   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches) */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -174,6 +174,46 @@ int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float d
                                   float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
                                   float *g_body_inv_mass_dev, float *g_body_inertia_dev, float *g_body_inv_inertia_dev,
                                   void *stream);
+
+/* Row f4, second half: the FK of the control reference (ForwardKinematics.apply(queried_q, queried_qd, env), diffphys/dp_model.py:758
+ * of the reference: F x bs chains per iteration, independent of the rollout) without a launch of its own.  The two entries below are
+ * the *_traj_loss entries above with one more argument; with fk != NULL and fk->n > 0
+ *   forward : the small launch that follows the rollout launch runs reduce_loss in its first workgroup and FK forward in the others;
+ *   backward: the small launch in front of the adjoint rollout builds the seeds in its first workgroups and runs FK backward
+ *             (with ForwardKinematics.backward's post-processing, see pd_fk_backward) in the others.
+ * The articulations come FRAME-major, joint_q [F][bs][nq] / joint_qd [F][bs][nqd] (n = F * bs; F need not be the rollout's nframes) --
+ * the layout of ForwardKinematics' rj_q / rj_qd -- and the body rows are ENV-major, [bs][F][nb][7] / [bs][F][nb][6] (what the
+ * reference gets from permute(1, 0, 2, 3) at dp_model.py:1093-1094, and what its losses consume): no permuted copy on either side.
+ * Forward reads joint_q / joint_qd, writes body_q / body_qd; backward reads joint_q / joint_qd / adj_body_q / adj_body_qd, writes
+ * g_joint_q / g_joint_qd; the other fields may be NULL.  fk == NULL or fk->n == 0: exactly the *_traj_loss entries. */
+typedef struct pd_fk_ride {
+  int n, bs;
+  const float *joint_q_dev, *joint_qd_dev;
+  float *body_q_dev, *body_qd_dev;
+  const float *adj_body_q_dev, *adj_body_qd_dev;
+  float *g_joint_q_dev, *g_joint_qd_dev;
+} pd_fk_ride;
+int pd_rollout_forward_traj_loss_fk(const pd_model *m, int bs, int nsteps, float dt,
+                                    const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
+                                    const float *res_f_dev, const float *refs_dev, const float *target_ke_dev,
+                                    const float *target_kd_dev, const float *body_inv_mass_dev,
+                                    const float *body_inertia_dev, const float *body_inv_inertia_dev,
+                                    int nframes, const int *frame2step_host, float *workspace_dev,
+                                    float *wp_pos_dev, float *wp_vel_dev, float *grf_dev, float *jaf_dev,
+                                    const float *target_pos_dev, const unsigned char *outseq_dev, float rot_ratio,
+                                    float *seed_pos_dev, float *seed_gt_dev, float *loss_table_dev, float *reduced_dev,
+                                    float *scale_dev, const pd_fk_ride *fk, void *stream);
+int pd_rollout_backward_traj_loss_fk(const pd_model *m, int bs, int nsteps, float dt,
+                                     const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
+                                     const float *refs_dev, const float *target_ke_dev, const float *target_kd_dev,
+                                     const float *body_inv_mass_dev, const float *body_inertia_dev,
+                                     const float *body_inv_inertia_dev, int nframes, const int *frame2step_host,
+                                     const float *workspace_dev, const float *adj_pos_dev, const float *adj_vel_dev,
+                                     const float *seed_pos_dev, const float *scale_dev, const float *g_loss_dev,
+                                     float *seed_work_dev, float *g_q_init_dev, float *g_qd_init_dev, float *g_torques_dev, float *g_res_f_dev,
+                                     float *g_refs_dev, float *g_target_ke_dev, float *g_target_kd_dev,
+                                     float *g_body_inv_mass_dev, float *g_body_inertia_dev, float *g_body_inv_inertia_dev,
+                                     const pd_fk_ride *fk, void *stream);
 
 /* n independent articulations: joint_q [n][nq], joint_qd [n][nqd] -> body_q [n][nb][7], body_qd [n][nb][6] */
 int pd_fk_forward(const pd_model *m, int n, const float *joint_q_dev, const float *joint_qd_dev,

@@ -1,6 +1,7 @@
 // Kernel argument blocks and launcher prototypes shared by the kernel TUs and the host TU.
 #pragma once
 #include "pd_device.h"
+#include "pd_trajloss.h"
 
 // Rollout kernels: 8 waves per workgroup.  Waves 0..3 ("body waves") own the per-body state of 64/SEGW envs each;
 // wave 4+i ("contact wave") runs the ground-contact sweeps for the envs of wave i, concurrently with wave i's joint
@@ -14,7 +15,12 @@
 // repeating the three cull levels; count -1 = did not fit, the adjoint then culls again for that wave.
 #define PD_HITLOG 32
 
-enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3 };
+enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD = 3,
+       // row f4: the FK of the control reference rides on the trajectory-loss launches that already sit between the rollout launches --
+       // workgroup 0 of PD_K_REDUCE_FK is reduce_loss (pd_trajloss.h), the rest are FK forward workgroups; PD_K_SEEDS_FK = the adjoint's
+       // seeds pass followed by FK backward workgroups
+       PD_K_REDUCE_FK = 4, PD_K_SEEDS_FK = 5 };
+#define PD_REDUCE_BLOCK 1024  // threads of the reduce_loss workgroup; the FK workgroups of that launch run 16 body waves
 
 // Which rollout launches run wave-specialised -- shared by the kernel TUs and the host.
 //   forward : revolute-only robots always; other joint mixes while a CU holds at most one full workgroup (the latency
@@ -94,7 +100,13 @@ struct FkArgs {
   float *body_q, *body_qd;                 // forward outputs [n][nb][7] / [n][nb][6]
   const float *adj_body_q, *adj_body_qd;   // backward inputs
   float *g_joint_q, *g_joint_qd;           // backward outputs
+  // perm_bs > 0: the n = F * perm_bs articulations come frame-major (row f * bs + e, the layout of ForwardKinematics' rj_q [F, bs, nq])
+  // and the body rows (outputs, adjoint inputs) are env-major, row e * F + f -- the [bs, F, nb, .] tensors phys_model.forward uses
+  // (dp_model.py:1093-1094 of the reference permutes and copies)
+  int perm_bs;
 };
+struct ReduceFkArgs { FkArgs fk; TrajReduceArgs red; int in_lds; };
+struct SeedsFkArgs { FkArgs fk; TrajSeedsArgs seeds; };
 
 
 hipError_t pd_launch_seg16(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);

@@ -31,6 +31,7 @@ struct pd_model {
   void *blob = nullptr;
   PdDevModel dev{};
   size_t lds_rollout = 0, lds_rollout_bwd = 0, lds_fk = 0;  // at PD_BWAVES env groups per workgroup (the maximum)
+  size_t lds_max = 0;  // what the kernels' dynamic-LDS attribute is at least set to
   size_t lds_tables = 0;                                      // contact tables, for the kernels that copy them into LDS
   // per-env joint_X_p bound by the caller (pd_model_bind_joint_X_p); null = the template's
   const float *xp_env = nullptr;
@@ -264,7 +265,10 @@ static int build_device(pd_model *m, int segw) {
   const size_t lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
   if (lds_rollout_bwd > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout_bwd) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
   if (lds_rollout > 160 * 1024) return fail("model needs " + std::to_string(lds_rollout) + " B of LDS per workgroup (> 160 KiB); use a wider segment");
-  const int lds_max = (int)std::max(std::max(lds_rollout, lds_rollout_bwd), lds_fk);
+  // (k_reduce_fk runs FK workgroups of PD_REDUCE_BLOCK / 64 body waves: that many times the 4-wave FK workgroup's records)
+  const size_t lds_fk_wide = lds_fk * (PD_REDUCE_BLOCK / 64 / PD_BWAVES);
+  if (lds_fk_wide > 160 * 1024) return fail("model needs " + std::to_string(lds_fk_wide) + " B of LDS per FK workgroup (> 160 KiB); use a wider segment");
+  const int lds_max = (int)std::max(std::max(std::max(lds_rollout, lds_rollout_bwd), lds_fk), lds_fk_wide);
   int dev_id = 0;
   if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0) dev_id = 0;
   int uncached = 0;  // (a device index beyond the table is simply never cached: the attribute is set on every build)
@@ -294,7 +298,7 @@ static int build_device(pd_model *m, int segw) {
   d.small_tiles = (const int *)(base + o_st);
   free_device(m);
   m->blob = blob; m->dev = d;
-  m->lds_rollout = lds_rollout; m->lds_rollout_bwd = lds_rollout_bwd; m->lds_fk = lds_fk; m->lds_tables = lds_tables;
+  m->lds_rollout = lds_rollout; m->lds_rollout_bwd = lds_rollout_bwd; m->lds_fk = lds_fk; m->lds_tables = lds_tables; m->lds_max = (size_t)lds_max;
   m->segw = segw; m->jt = jt; m->contact_order = order;
   return 0;
 }
@@ -517,18 +521,63 @@ extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(
 extern "C" __attribute__((visibility("hidden"))) int pd_traj_seeds_launch(int bs, int nb, int nframes, const float *seed_pos, const float *scale, const float *gain, const float *adj_pos,
                                                                          const float *adj_vel, float *work, hipStream_t st);
 
+// Row f4, second half: the FK of the control reference (and its adjoint) as extra workgroups of the launch that sits between the
+// rollout launches anyway -- k_reduce_fk = [reduce_loss | FK forward ...], k_seeds_fk = [seeds ... | FK backward ...] (pd_kernels.hip)
+static int check_fk_ride(const pd_fk_ride *fk, bool backward) {
+  if (!fk) return 0;
+  if (fk->n < 0 || fk->bs < 0) return fail("negative size (fk ride)");
+  if (fk->n == 0) return 0;
+  if (fk->bs == 0 || fk->n % fk->bs != 0) return fail("fk ride: n = " + std::to_string(fk->n) + " articulations is not frames x bs (bs = " + std::to_string(fk->bs) + ")");
+  if (!fk->joint_q_dev || !fk->joint_qd_dev) return fail("null device pointer (fk ride)");
+  if (!backward && (!fk->body_q_dev || !fk->body_qd_dev)) return fail("null device pointer (fk ride)");
+  if (backward && (!fk->adj_body_q_dev || !fk->adj_body_qd_dev || !fk->g_joint_q_dev || !fk->g_joint_qd_dev)) return fail("null device pointer (fk ride)");
+  return 0;
+}
+static FkArgs fk_ride_args(const pd_fk_ride *fk) {
+  FkArgs f{};
+  f.n = fk->n; f.joint_q = fk->joint_q_dev; f.joint_qd = fk->joint_qd_dev; f.body_q = fk->body_q_dev; f.body_qd = fk->body_qd_dev;
+  f.adj_body_q = fk->adj_body_q_dev; f.adj_body_qd = fk->adj_body_qd_dev; f.g_joint_q = fk->g_joint_q_dev; f.g_joint_qd = fk->g_joint_qd_dev;
+  f.perm_bs = fk->bs;
+  return f;
+}
+// lead_blocks workgroups of the carrying pass (needing lead_lds bytes), then the FK workgroups of fk_n articulations
+static hipError_t launch_ride(const pd_model *m, int kind, const void *args, int fk_n, int lead_blocks, size_t lead_lds, hipStream_t st) {
+  const int epw = 64 / m->segw, n_groups = (fk_n + epw - 1) / epw;
+  PdLaunchCfg c{};
+  c.kernel = PD_KV_FK; c.roles = 1;
+  c.groups = kind == PD_K_REDUCE_FK ? PD_REDUCE_BLOCK / 64 : PD_BWAVES;
+  c.nblocks = lead_blocks + (n_groups + c.groups - 1) / c.groups;
+  c.threads = c.groups * 64;
+  c.lds = std::max(lead_lds, m->lds_fk * (size_t)(c.groups / PD_BWAVES));
+  if (c.nblocks == 0) return hipSuccess;
+  if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, c, st);
+  if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, c, st);
+  return pd_launch_seg64(kind, m->jt, m->dev, args, c, st);
+}
+static int reduce_launch(const pd_model *m, int bs, int nframes, const float *table, float *reduced, float *scale, const pd_fk_ride *fk, hipStream_t st) {
+  if (!fk || fk->n == 0) return pd_traj_loss_reduce_launch(bs, nframes, table, reduced, scale, st) ? fail("trajectory-loss reduction launch failed") : 0;
+  ReduceFkArgs a{};
+  a.fk = fk_ride_args(fk);
+  a.red = TrajReduceArgs{bs, nframes, table, reduced, scale};
+  const size_t bytes = (size_t)bs * nframes * sizeof(float);
+  a.in_lds = bytes <= std::min((size_t)PD_REDUCE_LDS_BYTES, m->lds_max) ? 1 : 0;
+  hipError_t e = launch_ride(m, PD_K_REDUCE_FK, &a, fk->n, 1, a.in_lds ? bytes : 0, st);
+  return e == hipSuccess ? 0 : hip_fail(e, "reduce_loss + fk launch");
+}
+
 static int rollout_forward_impl(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
                        const float *torques, const float *res_f, const float *refs, const float *target_ke,
                        const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
                        const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, const TrajLossFwd *tl,
-                       void *stream) {
+                       const pd_fk_ride *fk, void *stream) {
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
+  if (check_fk_ride(fk, false)) return 1;
   const int *fos = nullptr;
   if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;
   if (bs == 0) {  // nothing to roll out; an empty batch still gets a defined reduced loss (0) from the trajectory-loss entry
-    if (tl && tl->reduced && pd_traj_loss_reduce_launch(0, nframes, tl->table, tl->reduced, tl->scale, (hipStream_t)stream)) return fail("trajectory-loss reduction launch failed");
+    if (tl && tl->reduced) return reduce_launch(m, 0, nframes, tl->table, tl->reduced, tl->scale, fk, (hipStream_t)stream);
     return 0;
   }
   if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia) return fail("null device pointer");
@@ -551,7 +600,7 @@ static int rollout_forward_impl(const pd_model *cm, int bs, int nsteps, float dt
   hipError_t e = launch(m, PD_K_ROLLOUT_FWD, &a, bs, st);
   timing_end(m, 0, st);
   if (e != hipSuccess) return hip_fail(e, "rollout_forward launch");
-  if (tl && pd_traj_loss_reduce_launch(bs, nframes, tl->table, tl->reduced, tl->scale, st)) return fail("trajectory-loss reduction launch failed");
+  if (tl) return reduce_launch(m, bs, nframes, tl->table, tl->reduced, tl->scale, fk, st);
   return 0;
 }
 
@@ -560,7 +609,7 @@ int pd_rollout_forward(const pd_model *m, int bs, int nsteps, float dt, const fl
                        const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
                        const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf, void *stream) {
   return rollout_forward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia,
-                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, nullptr, stream);
+                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, nullptr, nullptr, stream);
 }
 
 int pd_rollout_forward_traj_loss(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
@@ -571,7 +620,18 @@ int pd_rollout_forward_traj_loss(const pd_model *m, int bs, int nsteps, float dt
                                  float *loss_table, float *reduced, float *scale, void *stream) {
   const TrajLossFwd tl{target_pos, outseq, rot_ratio, seed_pos, seed_gt, loss_table, reduced, scale};
   return rollout_forward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia,
-                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, &tl, stream);
+                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, &tl, nullptr, stream);
+}
+
+int pd_rollout_forward_traj_loss_fk(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                                    const float *torques, const float *res_f, const float *refs, const float *target_ke,
+                                    const float *target_kd, const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes,
+                                    const int *frame2step, float *ws, float *wp_pos, float *wp_vel, float *grf, float *jaf,
+                                    const float *target_pos, const unsigned char *outseq, float rot_ratio, float *seed_pos, float *seed_gt,
+                                    float *loss_table, float *reduced, float *scale, const pd_fk_ride *fk, void *stream) {
+  const TrajLossFwd tl{target_pos, outseq, rot_ratio, seed_pos, seed_gt, loss_table, reduced, scale};
+  return rollout_forward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia,
+                              nframes, frame2step, ws, wp_pos, wp_vel, grf, jaf, &tl, fk, stream);
 }
 
 static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
@@ -579,13 +639,22 @@ static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float d
                         const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
                         const float *ws, const float *adj_pos, const float *adj_vel, float *g_q_init, float *g_qd_init,
                         float *g_torques, float *g_res_f, float *g_refs, float *g_ke, float *g_kd, float *g_inv_mass,
-                        float *g_inertia, float *g_inv_inertia, const TrajLossBwd *tl, void *stream) {
+                        float *g_inertia, float *g_inv_inertia, const TrajLossBwd *tl, const pd_fk_ride *fk, void *stream) {
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
+  if (check_fk_ride(fk, true)) return 1;
   const int *fos = nullptr;
   if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;
-  if (bs == 0) return 0;
+  if (bs == 0) {
+    if (fk && fk->n > 0) {  // no rollout, but the FK adjoint that rides along still runs
+      SeedsFkArgs sa{};
+      sa.fk = fk_ride_args(fk);
+      hipError_t e = launch_ride(m, PD_K_SEEDS_FK, &sa, fk->n, 0, 0, (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail(e, "fk backward launch");
+    }
+    return 0;
+  }
   if (!q_init || !qd_init || !target_ke || !target_kd || !inv_mass || !inertia || !inv_inertia || !g_q_init || !g_qd_init || !g_ke ||
       !g_kd || !g_inv_mass || !g_inertia || !g_inv_inertia)
     return fail("null device pointer");
@@ -596,8 +665,16 @@ static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float d
   if (m->xp_env && m->xp_envs != bs) return fail("joint_X_p is bound for " + std::to_string(m->xp_envs) + " envs, rollout has " + std::to_string(bs));
   RolloutArgs a{};
   a.bs = bs; a.nsteps = nsteps; a.nframes = nframes; a.dt = dt;
-  if (tl && nframes > 0) {
-    // the seeds of this sweep, built on the device: work = [F][bs*nb][7] poses then [F][bs*nb][6] twists (pd_loss.hip k_traj_seeds)
+  if (fk && fk->n > 0) {  // seeds pass (if any) + FK backward workgroups in one launch
+    SeedsFkArgs sa{};
+    sa.fk = fk_ride_args(fk);
+    const bool seeds = tl && nframes > 0;
+    if (seeds) sa.seeds = TrajSeedsArgs{bs, m->nb, nframes, tl->seed_pos, tl->scale, tl->gain, adj_pos, adj_vel, tl->work, pd_traj_seeds_blocks(bs, m->nb, nframes)};
+    hipError_t e = launch_ride(m, PD_K_SEEDS_FK, &sa, fk->n, sa.seeds.nblocks, 0, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "seeds + fk backward launch");
+    if (seeds) { adj_pos = tl->work; adj_vel = tl->work + (size_t)nframes * bs * m->nb * 7; }
+  } else if (tl && nframes > 0) {
+    // the seeds of this sweep, built on the device: work = [F][bs*nb][7] poses then [F][bs*nb][6] twists (pd_trajloss.h traj_seeds_block)
     if (pd_traj_seeds_launch(bs, m->nb, nframes, tl->seed_pos, tl->scale, tl->gain, adj_pos, adj_vel, tl->work, (hipStream_t)stream)) return fail("seed launch failed");
     adj_pos = tl->work; adj_vel = tl->work + (size_t)nframes * bs * m->nb * 7;
   }
@@ -626,7 +703,7 @@ int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt, const f
                         float *g_inertia, float *g_inv_inertia, void *stream) {
   return rollout_backward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
                                frame2step, ws, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs, g_ke, g_kd, g_inv_mass,
-                               g_inertia, g_inv_inertia, nullptr, stream);
+                               g_inertia, g_inv_inertia, nullptr, nullptr, stream);
 }
 
 int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
@@ -638,7 +715,20 @@ int pd_rollout_backward_traj_loss(const pd_model *m, int bs, int nsteps, float d
   const TrajLossBwd tl{seed_pos, scale, g_loss, seed_work};
   return rollout_backward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
                                frame2step, ws, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs, g_ke, g_kd, g_inv_mass,
-                               g_inertia, g_inv_inertia, &tl, stream);
+                               g_inertia, g_inv_inertia, &tl, nullptr, stream);
+}
+
+int pd_rollout_backward_traj_loss_fk(const pd_model *m, int bs, int nsteps, float dt, const float *q_init, const float *qd_init,
+                                     const float *torques, const float *refs, const float *target_ke, const float *target_kd,
+                                     const float *inv_mass, const float *inertia, const float *inv_inertia, int nframes, const int *frame2step,
+                                     const float *ws, const float *adj_pos, const float *adj_vel, const float *seed_pos, const float *scale,
+                                     const float *g_loss, float *seed_work, float *g_q_init, float *g_qd_init, float *g_torques, float *g_res_f, float *g_refs,
+                                     float *g_ke, float *g_kd, float *g_inv_mass, float *g_inertia, float *g_inv_inertia, const pd_fk_ride *fk,
+                                     void *stream) {
+  const TrajLossBwd tl{seed_pos, scale, g_loss, seed_work};
+  return rollout_backward_impl(m, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, inv_mass, inertia, inv_inertia, nframes,
+                               frame2step, ws, adj_pos, adj_vel, g_q_init, g_qd_init, g_torques, g_res_f, g_refs, g_ke, g_kd, g_inv_mass,
+                               g_inertia, g_inv_inertia, &tl, fk, stream);
 }
 
 int pd_fk_forward(const pd_model *m, int n, const float *joint_q, const float *joint_qd, float *body_q, float *body_qd, void *stream) {

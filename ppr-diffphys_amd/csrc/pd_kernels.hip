@@ -2378,13 +2378,13 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
 
 // =============================================================================================
 // Batched FK (ForwardKinematics, dp_model.py:1022-1130): n articulations, one per segment.
+// the articulations of workgroup `block` of an FK launch (blockDim.x / 64 body waves per workgroup)
 template <int SEGW, int JT, bool BWD>
-__global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+PD_DEV void fk_chain(const PdDevModel &m, const FkArgs &a, unsigned char *smem, int block) {
   constexpr int EPW = Seg<SEGW>::EPW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int seg = lane / SEGW, l = lane % SEGW;
-  const int env = (blockIdx.x * PD_BWAVES + wave) * EPW + seg;
+  const int env = (block * (int)(blockDim.x >> 6) + wave) * EPW + seg;
   const bool is_body = env < a.n && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1, nb = m.nb;
   const int ec = env < a.n ? env : 0;
@@ -2401,7 +2401,9 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
     }
     WAVE_SYNC();
   }
-  const size_t idx = (size_t)ec * nb + b;
+  // body rows: articulation order, or env-major when the articulations come frame-major (FkArgs::perm_bs)
+  const size_t row = a.perm_bs > 0 ? (size_t)(ec % a.perm_bs) * (size_t)(a.n / a.perm_bs) + (size_t)(ec / a.perm_bs) : (size_t)ec;
+  const size_t idx = row * nb + b;
   if (!BWD) {
     if (is_body) {
       float *o = a.body_q + idx * 7;
@@ -2429,6 +2431,32 @@ __global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
     }
     WAVE_SYNC();
   }
+}
+
+template <int SEGW, int JT, bool BWD>
+__global__ __launch_bounds__(PD_FK_BLOCK) void k_fk(PdDevModel m, FkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  fk_chain<SEGW, JT, BWD>(m, a, smem, blockIdx.x);
+}
+
+// Row f4: reduce_loss of the trajectory loss (workgroup 0) and the FK of the control reference (dp_model.py:758 of the reference; the
+// other workgroups, 16 body waves each) in ONE launch between the two rollout launches -- the FK has no launch of its own any more.
+template <int SEGW, int JT>
+__global__ __launch_bounds__(PD_REDUCE_BLOCK) void k_reduce_fk(PdDevModel m, ReduceFkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (blockIdx.x == 0) {
+    if (a.in_lds) traj_loss_reduce_block<true>(a.red, (float *)smem);
+    else traj_loss_reduce_block<false>(a.red, (float *)smem);
+    return;
+  }
+  fk_chain<SEGW, JT, false>(m, a.fk, smem, blockIdx.x - 1);
+}
+// ... and its adjoint rides on the launch that builds the adjoint rollout's seeds (workgroups seeds.nblocks .. are FK backward)
+template <int SEGW, int JT>
+__global__ __launch_bounds__(PD_FK_BLOCK) void k_seeds_fk(PdDevModel m, SeedsFkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if ((int)blockIdx.x < a.seeds.nblocks) { traj_seeds_block(a.seeds, blockIdx.x); return; }
+  fk_chain<SEGW, JT, true>(m, a.fk, smem, blockIdx.x - a.seeds.nblocks);
 }
 
 // =============================================================================================
@@ -2509,6 +2537,12 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
     case PD_K_FK_BWD:
       hipLaunchKernelGGL((k_fk<PD_SEGW, JT, true>), g, t, lds, st, m, *(const FkArgs *)args);
       break;
+    case PD_K_REDUCE_FK:
+      hipLaunchKernelGGL((k_reduce_fk<PD_SEGW, JT>), g, t, lds, st, m, *(const ReduceFkArgs *)args);
+      break;
+    case PD_K_SEEDS_FK:
+      hipLaunchKernelGGL((k_seeds_fk<PD_SEGW, JT>), g, t, lds, st, m, *(const SeedsFkArgs *)args);
+      break;
     default:
       return hipErrorInvalidValue;
   }
@@ -2542,6 +2576,8 @@ static hipError_t set_lds_jt(int bytes) {
 #endif
   }
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_reduce_fk<PD_SEGW, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_seeds_fk<PD_SEGW, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   return hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 

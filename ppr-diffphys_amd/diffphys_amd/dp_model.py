@@ -153,40 +153,88 @@ class ForwardWarpTrajLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia,
                 body_inv_inertia, target_position, outseq_idx, self):
-        dm = hip_backend.device_model(self.env)
-        bs, nsteps = int(self.num_envs), len(self.steps_idx)
-        frame2step = [int(s) for s in self.frame2step]
-        c = lambda t: t.detach().to(torch.float32).contiguous()
-        inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
-                              body_inv_inertia)]
-        tgt = c(target_position).view(bs, len(frame2step), dm.nb, 7)
-        outseq = None if outseq_idx is None else outseq_idx.detach().to(torch.bool).contiguous()
-        need_gt = target_position.requires_grad
-        wp_pos, wp_vel, grf, jaf, ws, tl = dm.rollout_forward_traj_loss(bs, nsteps, self.dt, *inp, frame2step=frame2step, target_pos=tgt,
-                                                                        outseq=outseq, rot_ratio=0.1, want_seed_gt=need_gt)
-        ctx.dm, ctx.meta, ctx.tl = dm, (bs, nsteps, float(self.dt), frame2step), tl
-        ctx.save_for_backward(ws, *inp)
-        ctx.mass_shape, ctx.tgt_shape = body_mass.shape, target_position.shape
-        has_f = [f for f, s in enumerate(frame2step) if s < nsteps]
-        self.grfs = [grf[f] for f in has_f]
-        self.jafs = [jaf[f] for f in has_f]
-        self.sim_trajs = HostFrames(wp_pos[:, : dm.nb])
-        self.traj_loss_info = tl["reduced"]
-        ctx.mark_non_differentiable(wp_pos, wp_vel)
-        return tl["reduced"][0].clone(), wp_pos, wp_vel
+        return _traj_loss_forward(ctx, (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia,
+                                        body_inv_inertia), target_position, outseq_idx, self, None)
 
     @staticmethod
     def backward(ctx, g_loss, _gp, _gv):
-        ws, q_init, qd_init, torques, res_f, refs, ke, kd, inv_m, inertia, inv_inertia = ctx.saved_tensors
-        bs, nsteps, dt, frame2step = ctx.meta
-        tl = ctx.tl
-        gl = g_loss.detach().to(torch.float32).reshape(1).contiguous()
-        g = ctx.dm.rollout_backward_traj_loss(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia,
-                                              frame2step, ws, tl, gl)
-        g_tgt = None
-        if ctx.needs_input_grad[11] and tl["seed_gt"] is not None:  # d loss_traj / d target pose = g x share / nb x d se3 / d gt
-            g_tgt = (tl["seed_gt"] * (tl["scale"] * (gl / ctx.dm.nb))[:, :, None, None]).view(ctx.tgt_shape)
-        return (g["q_init"], g["qd_init"], g["torques"].view_as(torques), g["res_f"].view_as(res_f),
-                g["refs"].view_as(refs), g["target_ke"], g["target_kd"],
-                torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), g["body_inv_mass"],
-                g["body_inertia"].view_as(inertia), g["body_inv_inertia"].view_as(inv_inertia), g_tgt, None, None)
+        return _traj_loss_backward(ctx, g_loss, None) + (None,)
+
+
+class ForwardWarpTrajLossFK(torch.autograd.Function):
+    """ForwardWarpTrajLoss plus the FK of the control reference (dp_model.py:758 of the reference:
+    ``ForwardKinematics.apply(queried_q, queried_qd, self.env)``) in the SAME launches -- the second half of SURVEY section 8 row f4:
+
+        loss_traj, wp_pos, wp_vel, queried_position [bs,F,nb,7], queried_velocity [bs,F,nb,6], pid_ref =
+            ForwardWarpTrajLossFK.apply(<the 11 inputs of ForwardWarp>, target_position, outseq_idx, queried_q [F,bs,nq], queried_qd [F,bs,nqd], self)
+
+    The FK chains are extra workgroups of the reduce_loss launch that follows the rollout launch, their adjoint (with
+    ForwardKinematics.backward's NaN -> 0 / > 1 -> 1 post-processing) extra workgroups of the seeds launch in front of the adjoint
+    rollout; the kernels write / read the [bs, F, ...] layout directly (the reference permutes and copies, :1093-1094).  Values and
+    gradients are those of ForwardKinematics.apply bit for bit (same device code)."""
+
+    @staticmethod
+    def forward(ctx, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia,
+                body_inv_inertia, target_position, outseq_idx, queried_q, queried_qd, self):
+        return _traj_loss_forward(ctx, (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia,
+                                        body_inv_inertia), target_position, outseq_idx, self, (queried_q, queried_qd))
+
+    @staticmethod
+    def backward(ctx, g_loss, _gp, _gv, g_qpos, g_qvel, _pid):
+        g = _traj_loss_backward(ctx, g_loss, (g_qpos, g_qvel))
+        return g[:13] + g[13:] + (None,)
+
+
+def _traj_loss_forward(ctx, rollout_inputs, target_position, outseq_idx, self, queried):
+    (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_mass, body_inv_mass, body_inertia, body_inv_inertia) = rollout_inputs
+    dm = hip_backend.device_model(self.env)
+    bs, nsteps = int(self.num_envs), len(self.steps_idx)
+    frame2step = [int(s) for s in self.frame2step]
+    c = lambda t: t.detach().to(torch.float32).contiguous()
+    inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
+                          body_inv_inertia)]
+    tgt = c(target_position).view(bs, len(frame2step), dm.nb, 7)
+    outseq = None if outseq_idx is None else outseq_idx.detach().to(torch.bool).contiguous()
+    need_gt = target_position.requires_grad
+    fk = None if queried is None else (c(queried[0]), c(queried[1]))
+    wp_pos, wp_vel, grf, jaf, ws, tl = dm.rollout_forward_traj_loss(bs, nsteps, self.dt, *inp, frame2step=frame2step, target_pos=tgt,
+                                                                    outseq=outseq, rot_ratio=0.1, want_seed_gt=need_gt, fk=fk)
+    ctx.dm, ctx.meta, ctx.tl = dm, (bs, nsteps, float(self.dt), frame2step), tl
+    ctx.save_for_backward(ws, *inp, *(fk or ()))
+    ctx.mass_shape, ctx.tgt_shape = body_mass.shape, target_position.shape
+    has_f = [f for f, s in enumerate(frame2step) if s < nsteps]
+    self.grfs = [grf[f] for f in has_f]
+    self.jafs = [jaf[f] for f in has_f]
+    self.sim_trajs = HostFrames(wp_pos[:, : dm.nb])
+    self.traj_loss_info = tl["reduced"]
+    ctx.mark_non_differentiable(wp_pos, wp_vel)
+    out = (tl["reduced"][0].clone(), wp_pos, wp_vel)
+    if fk is not None:
+        body_q, body_qd = tl["fk_body_q"], tl["fk_body_qd"]
+        out += (body_q, body_qd, HostFrames(body_q[0]))  # env 0, one array per frame (visualisation), as ForwardKinematics
+    return out
+
+
+def _traj_loss_backward(ctx, g_loss, g_queried):
+    ws, q_init, qd_init, torques, res_f, refs, ke, kd, inv_m, inertia, inv_inertia = ctx.saved_tensors[:11]
+    bs, nsteps, dt, frame2step = ctx.meta
+    tl = ctx.tl
+    gl = g_loss.detach().to(torch.float32).reshape(1).contiguous()
+    fk = None
+    if g_queried is not None and (g_queried[0] is not None or g_queried[1] is not None):
+        jq, jqd = ctx.saved_tensors[11:13]
+        aq = torch.zeros_like(tl["fk_body_q"]) if g_queried[0] is None else g_queried[0].to(torch.float32).contiguous()
+        aqd = torch.zeros_like(tl["fk_body_qd"]) if g_queried[1] is None else g_queried[1].to(torch.float32).contiguous()
+        fk = (jq, jqd, aq, aqd)
+    g = ctx.dm.rollout_backward_traj_loss(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia,
+                                          frame2step, ws, tl, gl, fk=fk)
+    g_tgt = None
+    if ctx.needs_input_grad[11] and tl["seed_gt"] is not None:  # d loss_traj / d target pose = g x share / nb x d se3 / d gt
+        g_tgt = (tl["seed_gt"] * (tl["scale"] * (gl / ctx.dm.nb))[:, :, None, None]).view(ctx.tgt_shape)
+    out = (g["q_init"], g["qd_init"], g["torques"].view_as(torques), g["res_f"].view_as(res_f),
+           g["refs"].view_as(refs), g["target_ke"], g["target_kd"],
+           torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), g["body_inv_mass"],
+           g["body_inertia"].view_as(inertia), g["body_inv_inertia"].view_as(inv_inertia), g_tgt, None)
+    if g_queried is not None:
+        out += (g.get("fk_joint_q"), g.get("fk_joint_qd"))
+    return out

@@ -14,7 +14,7 @@ import torch
 _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
-ABI_VERSION = 5  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+ABI_VERSION = 6  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -30,6 +30,11 @@ class _Desc(ctypes.Structure):
         ("shape_materials", _fp), ("gravity", ctypes.c_float * 3),
         ("joint_attach_ke", ctypes.c_float), ("joint_attach_kd", ctypes.c_float),
     ]
+
+
+class _FkRide(ctypes.Structure):  # pd_fk_ride (include/ppr_diffphys.h)
+    _fields_ = [("n", ctypes.c_int), ("bs", ctypes.c_int)] + [(k, ctypes.c_void_p) for k in (
+        "joint_q", "joint_qd", "body_q", "body_qd", "adj_body_q", "adj_body_qd", "g_joint_q", "g_joint_qd")]
 
 
 def lib_path():
@@ -69,6 +74,9 @@ def lib():
         if hasattr(L, "pd_rollout_forward_traj_loss"):
             L.pd_rollout_forward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 10 + [ci, _ip] + [vp] * 5 + [vp, vp, cf] + [vp] * 5 + [vp]
             L.pd_rollout_backward_traj_loss.argtypes = [vp, ci, ci, cf] + [vp] * 9 + [ci, _ip] + [vp] * 3 + [vp] * 4 + [vp] * 10 + [vp]
+        if hasattr(L, "pd_rollout_forward_traj_loss_fk"):
+            L.pd_rollout_forward_traj_loss_fk.argtypes = L.pd_rollout_forward_traj_loss.argtypes[:-1] + [ctypes.POINTER(_FkRide), vp]
+            L.pd_rollout_backward_traj_loss_fk.argtypes = L.pd_rollout_backward_traj_loss.argtypes[:-1] + [ctypes.POINTER(_FkRide), vp]
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
         L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
@@ -118,7 +126,7 @@ def source_hash():
     import hashlib
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "../../include/ppr_diffphys.h", "Makefile"]
+    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "pd_trajloss.h", "../../include/ppr_diffphys.h", "Makefile"]
     h = hashlib.sha256()
     try:
         for f in srcs:
@@ -269,11 +277,13 @@ class DeviceModel:
     # -- rollout with the trajectory loss evaluated at the frame states (C ABI v5) ------------
     def rollout_forward_traj_loss(self, bs, nsteps, dt, q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass,
                                   body_inertia, body_inv_inertia, frame2step, target_pos, outseq=None, rot_ratio=0.1, want_forces=True,
-                                  want_seed_gt=True, out=None):
+                                  want_seed_gt=True, out=None, fk=None):
         """``pd_rollout_forward_traj_loss``: rollout_forward plus, in the same rollout launch, se3_loss of every frame pose against
         target_pos [bs, F, nb, 7] and reduce_loss(clip=True) of the per-frame means.  -> (wp_pos, wp_vel, grf, jaf, ws, tl) with tl a dict:
         reduced [4] = (loss_traj, clip threshold, positive entries left, clipped envs), table [bs, F], scale [bs, F], seed_pos
-        [F, bs*nb, 7], seed_gt [bs, F, nb, 7] or None.  outseq: bool / uint8 [bs, F] (entries the loss ignores) or None."""
+        [F, bs*nb, 7], seed_gt [bs, F, nb, 7] or None.  outseq: bool / uint8 [bs, F] (entries the loss ignores) or None.
+        fk = (joint_q [Ff, bs_f, nq], joint_qd [Ff, bs_f, nqd]): the FK of the control reference rides on the reduce_loss launch
+        (``pd_rollout_forward_traj_loss_fk``); tl then also holds fk_body_q [bs_f, Ff, nb, 7] and fk_body_qd [bs_f, Ff, nb, 6]."""
         nb, nq, nqd = self.nb, self.nq, self.nqd
         dev = q_init.device
         f2s, nframes = self._f2s(frame2step)
@@ -288,7 +298,15 @@ class DeviceModel:
             if not (outseq.is_cuda and outseq.dtype in (torch.bool, torch.uint8) and outseq.is_contiguous() and outseq.numel() == bs * nframes):
                 raise ValueError("outseq must be a contiguous bool / uint8 GPU tensor of bs * nframes entries")
         p = lambda t, name, n: _dev(t, name, n) if (t is not None and t.numel()) else None
-        _check(lib().pd_rollout_forward_traj_loss(
+        ride = None
+        if fk is not None:
+            jq, jqd = fk
+            Ff, bsf = int(jq.shape[0]), int(jq.shape[1])
+            tl["fk_body_q"], tl["fk_body_qd"] = e(bsf, Ff, nb, 7), e(bsf, Ff, nb, 6)
+            ride = _FkRide(Ff * bsf, bsf, p(jq, "fk joint_q", Ff * bsf * nq), p(jqd, "fk joint_qd", Ff * bsf * nqd),
+                           p(tl["fk_body_q"], "fk body_q", None), p(tl["fk_body_qd"], "fk body_qd", None), None, None, None, None)
+        entry = lib().pd_rollout_forward_traj_loss if ride is None else lib().pd_rollout_forward_traj_loss_fk
+        _check(entry(
             self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
             p(torques, "torques", nsteps * bs * nqd), p(res_f, "res_f", nsteps * bs * nb * 6),
             p(refs, "refs", nsteps * bs * nqd), p(target_ke, "target_ke", bs * nqd),
@@ -300,13 +318,17 @@ class DeviceModel:
             p(target_pos, "target_pos", bs * nframes * nb * 7),
             ctypes.c_void_p(outseq.data_ptr()) if (outseq is not None and outseq.numel()) else None, ctypes.c_float(float(rot_ratio)),
             p(tl["seed_pos"], "seed_pos", nframes * bs * nb * 7), p(tl["seed_gt"], "seed_gt", nframes * bs * nb * 7),
-            p(tl["table"], "loss_table", bs * nframes), _dev(tl["reduced"], "reduced", 4), p(tl["scale"], "scale", bs * nframes), _stream()))
+            p(tl["table"], "loss_table", bs * nframes), _dev(tl["reduced"], "reduced", 4), p(tl["scale"], "scale", bs * nframes),
+            *(() if ride is None else (ctypes.byref(ride),)), _stream()))
         return wp_pos, wp_vel, grf, jaf, ws, tl
 
     def rollout_backward_traj_loss(self, bs, nsteps, dt, q_init, qd_init, torques, refs, target_ke, target_kd, body_inv_mass,
-                                   body_inertia, body_inv_inertia, frame2step, ws, tl, g_loss, adj_pos=None, adj_vel=None, out=None):
+                                   body_inertia, body_inv_inertia, frame2step, ws, tl, g_loss, adj_pos=None, adj_vel=None, out=None, fk=None):
         """``pd_rollout_backward_traj_loss``: the adjoint rollout seeded with g_loss (a 0-dim / 1-element GPU tensor: the upstream
-        gradient of loss_traj) x scale / nb x seed_pos, plus adj_pos / adj_vel when given."""
+        gradient of loss_traj) x scale / nb x seed_pos, plus adj_pos / adj_vel when given.
+        fk = (joint_q [Ff, bs_f, nq], joint_qd [Ff, bs_f, nqd], adj_body_q [bs_f, Ff, nb, 7], adj_body_qd [bs_f, Ff, nb, 6]): the FK
+        adjoint rides on the seeds launch (``pd_rollout_backward_traj_loss_fk``); g then also holds fk_joint_q [Ff, bs_f, nq] and
+        fk_joint_qd [Ff, bs_f, nqd] (with ForwardKinematics.backward's post-processing)."""
         nb, nq, nqd = self.nb, self.nq, self.nqd
         dev = q_init.device
         f2s, nframes = self._f2s(frame2step)
@@ -315,7 +337,18 @@ class DeviceModel:
         if work is None:  # scratch for the seeds of this sweep (adj_pos / adj_vel layout), kept with the forward's outputs
             work = tl["work"] = torch.empty(nframes * bs * nb * 13, dtype=torch.float32, device=dev)
         p = lambda t, name, n=None: _dev(t, name, n) if (t is not None and t.numel()) else None
-        _check(lib().pd_rollout_backward_traj_loss(
+        ride = None
+        if fk is not None:
+            jq, jqd, aq, aqd = fk
+            Ff, bsf = int(jq.shape[0]), int(jq.shape[1])
+            g = dict(g)
+            g["fk_joint_q"] = torch.empty(Ff, bsf, nq, dtype=torch.float32, device=dev)
+            g["fk_joint_qd"] = torch.empty(Ff, bsf, nqd, dtype=torch.float32, device=dev)
+            ride = _FkRide(Ff * bsf, bsf, p(jq, "fk joint_q", Ff * bsf * nq), p(jqd, "fk joint_qd", Ff * bsf * nqd), None, None,
+                           p(aq, "fk adj_body_q", Ff * bsf * nb * 7), p(aqd, "fk adj_body_qd", Ff * bsf * nb * 6),
+                           p(g["fk_joint_q"], "g"), p(g["fk_joint_qd"], "g"))
+        entry = lib().pd_rollout_backward_traj_loss if ride is None else lib().pd_rollout_backward_traj_loss_fk
+        _check(entry(
             self.h, bs, nsteps, float(dt), p(q_init, "q_init", bs * nq), p(qd_init, "qd_init", bs * nqd),
             p(torques, "torques", nsteps * bs * nqd), p(refs, "refs", nsteps * bs * nqd),
             p(target_ke, "target_ke", bs * nqd), p(target_kd, "target_kd", bs * nqd),
@@ -327,7 +360,7 @@ class DeviceModel:
             p(g["q_init"], "g"), p(g["qd_init"], "g"),
             p(g["torques"], "g"), p(g["res_f"], "g"), p(g["refs"], "g"), p(g["target_ke"], "g"),
             p(g["target_kd"], "g"), p(g["body_inv_mass"], "g"), p(g["body_inertia"], "g"),
-            p(g["body_inv_inertia"], "g"), _stream()))
+            p(g["body_inv_inertia"], "g"), *(() if ride is None else (ctypes.byref(ride),)), _stream()))
         return g
 
     def saved_trajectory(self, ws, bs, nsteps):

@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import robots, sim
 from .dataloader import mocap_tensors, bullet2gl, parse_amp
-from .dp_model import ForwardKinematics, ForwardWarp, ForwardWarpTrajLoss, convert_ppr_warp
+from .dp_model import ForwardKinematics, ForwardWarp, ForwardWarpTrajLossFK, convert_ppr_warp
 from .dp_utils import compose_delta, reduce_loss, rotate_frame, rotate_frame_vel, se3_loss
 from .geom_utils import fid_reindex
 from .grad_guard import GradHistory
@@ -406,18 +406,19 @@ class phys_model(nn.Module):
         # (dp_model.ForwardWarpTrajLoss, C ABI pd_rollout_*_traj_loss); False: the reference's sequence
         # ForwardWarp -> se3_loss -> reduce_loss through torch (kept: tests compare the two)
         fused = bool(getattr(self, "fuse_traj_loss", True)) and q_init.is_cuda
+        queried_q = self._frames_of(queried_q, 0).reshape(F_, n, -1)
+        queried_qd = convert_ppr_warp(self._frames_of(queried_qd, 0).reshape(F_, n, -1))
         if fused:
-            loss_traj_fused, sim_position, sim_velocity = ForwardWarpTrajLoss.apply(
+            # ... and the FK of the control reference (dp_model.py:758) rides on the two small launches of that path: no FK launch,
+            # no permuted copies (dp_model.ForwardWarpTrajLossFK, C ABI pd_rollout_*_traj_loss_fk)
+            loss_traj_fused, sim_position, sim_velocity, queried_position, queried_velocity, self.pid_ref = ForwardWarpTrajLossFK.apply(
                 q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass, body_inv_mass, body_inertia, body_inv_inertia,
-                target_position.reshape(n, F_, -1, 7), outseq_idx, self)
+                target_position.reshape(n, F_, -1, 7), outseq_idx, queried_q, queried_qd, self)
         else:
             sim_position, sim_velocity = ForwardWarp.apply(q_init, qd_init, torques, res_fin, ref_ja, target_ke, target_kd, body_mass,
                                                            body_inv_mass, body_inertia, body_inv_inertia, self)
+            queried_position, queried_velocity, self.pid_ref = ForwardKinematics.apply(queried_q, queried_qd, self.env)
         sim_velocity = convert_ppr_warp(sim_velocity)
-
-        queried_q = self._frames_of(queried_q, 0).reshape(F_, n, -1)
-        queried_qd = convert_ppr_warp(self._frames_of(queried_qd, 0).reshape(F_, n, -1))
-        queried_position, queried_velocity, self.pid_ref = ForwardKinematics.apply(queried_q, queried_qd, self.env)
         queried_velocity = convert_ppr_warp(queried_velocity)
         foot_height = self.get_foot_height(queried_position)
 

@@ -29,6 +29,13 @@ for cfg in (sys.argv[1:] or ["laikago:4096", "laikago:512", "human:1024"]):
     outseq = torch.zeros(bs, F, dtype=torch.bool, device=dev)
     dm = hip_backend.device_model(h.env)
 
+    # the control reference whose FK the reference evaluates beside the rollout (dp_model.py:758): F x bs chains
+    nq, nqd = int(tpl["nq"]), int(tpl["nqd"])
+    qq = (torch.from_numpy(inp["q_init"]).view(1, bs, nq) + 0.05 * torch.randn(F, bs, nq)).to(dev).requires_grad_(True)
+    qqd = (0.1 * torch.randn(F, bs, nqd)).to(dev).requires_grad_(True)
+    w_q, w_qd = torch.randn(bs, F, nb, 7, device=dev) * 1e-3, torch.randn(bs, F, nb, 6, device=dev) * 1e-3
+    args_fk = args + [qq, qqd]
+
     def seq_torch():
         pos, vel = dp_model.ForwardWarp.apply(*args, h)
         lt = dp_utils.se3_loss(pos.reshape(F, bs, nb, 7).permute(1, 0, 2, 3), tgt).mean(-1)
@@ -39,8 +46,17 @@ for cfg in (sys.argv[1:] or ["laikago:4096", "laikago:512", "human:1024"]):
         loss, _, _ = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
         (loss * 0.1).backward()
 
+    def seq_fused_fk_apart():   # loss inside the rollout, ForwardKinematics as its own launches (+ its permuted copies)
+        loss, _, _ = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
+        qp, qv, _ = dp_model.ForwardKinematics.apply(qq, qqd, h.env)
+        (loss * 0.1 + (qp * w_q).sum() + (qv * w_qd).sum()).backward()
+
+    def seq_fused_fk_riding():  # ForwardWarpTrajLossFK: the FK chains ride on the reduce / seeds launches
+        loss, _, _, qp, qv, _ = dp_model.ForwardWarpTrajLossFK.apply(*args, tgt, outseq, qq, qqd, h)
+        (loss * 0.1 + (qp * w_q).sum() + (qv * w_qd).sum()).backward()
+
     res = {}
-    for tag, fn in (("torch sequence", seq_torch), ("fused", seq_fused), ("torch sequence", seq_torch), ("fused", seq_fused)):
+    for tag, fn in (("torch sequence", seq_torch), ("fused", seq_fused), ("fused + FK apart", seq_fused_fk_apart), ("fused + FK riding", seq_fused_fk_riding)) * 2:
         for _ in range(10):
             fn()
         torch.cuda.synchronize()
@@ -49,11 +65,11 @@ for cfg in (sys.argv[1:] or ["laikago:4096", "laikago:512", "human:1024"]):
         n = 50
         e0.record()
         for _ in range(n):
-            for v in args: v.grad = None
+            for v in args_fk: v.grad = None
             fn()
         e1.record(); torch.cuda.synchronize()
         res.setdefault(tag, []).append((e0.elapsed_time(e1) / n, dm.last_kernel_ms(0), dm.last_kernel_ms(1)))
         dm.set_timing(False)
     for tag, v in res.items():
         it, kf, kb = np.min([x[0] for x in v]), np.min([x[1] for x in v]), np.min([x[2] for x in v])
-        print("F4TIME %-8s bs=%-5d %-15s iteration %.3f ms   (rollout forward launch %.3f ms, adjoint launch %.3f ms)" % (name, bs, tag, it, kf, kb), flush=True)
+        print("F4TIME %-8s bs=%-5d %-18s iteration %.3f ms   (rollout forward launch %.3f ms, adjoint launch %.3f ms)" % (name, bs, tag, it, kf, kb), flush=True)

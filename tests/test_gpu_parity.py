@@ -919,3 +919,82 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     for k in g_both:
         s_ = g_seed[k] + g_adj[k]
         assert float((g_both[k] - s_).abs().max()) <= 2e-4 * float(s_.abs().max()) + 1e-30, k   # linear in the seeds (fp32 sums in another order; measured 3e-5)
+
+
+@pytest.mark.parametrize("name,bs", [("laikago", 37), ("human", 9), ("laikago", 6700), ("laikago", 2100)])
+def test_fk_of_the_control_reference_rides_on_the_traj_loss_launches(name, bs, dev):
+    """Row f4, second half: ForwardWarpTrajLossFK = ForwardWarpTrajLoss + ForwardKinematics.apply(queried_q, queried_qd, env)
+    (dp_model.py:758 of the reference) with the FK chains as extra workgroups of the reduce_loss launch and their adjoint as extra
+    workgroups of the seeds launch (C ABI pd_rollout_*_traj_loss_fk).  Same device code as the separate launches: poses, twists, the
+    loss and EVERY gradient must be bit-identical, including ForwardKinematics.backward's NaN -> 0 / > 1 -> 1 post-processing; the
+    [bs, F, ...] layout comes straight out of the kernel.  6700 envs: the reduce table does not fit LDS; 2100: lane-per-body kernels."""
+    from diffphys_amd import dp_model, hip_backend, robots, synth
+
+    tpl = robots.load_template(name)
+    T = 40
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=6, steps_per_frame=13, penetration=0.002)
+    f2s = [0, 13, 26, 39]
+    F, nb, nq, nqd = len(f2s), int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+
+    class Host:
+        pass
+
+    h = Host()
+    h.env = robots.env_from_template(name, bs, device=dev)
+    h.num_envs, h.steps_idx, h.frame2step, h.dt = bs, range(T), f2s, inp["dt"]
+    t = {k: torch.from_numpy(inp[k]).to(dev).requires_grad_(True) for k in synth.INPUT_NAMES}
+    args = [t[k] for k in synth.INPUT_NAMES]
+    with torch.no_grad():
+        pos0, _ = dp_model.ForwardWarp.apply(*args, h)
+    g = torch.Generator().manual_seed(12)
+    tgt = (pos0.reshape(F, bs, nb, 7).permute(1, 0, 2, 3) + (torch.randn(bs, F, nb, 7, generator=g) * 0.02).to(dev)).contiguous()
+    outseq = torch.zeros(bs, F, dtype=torch.bool, device=dev)
+    # the control reference: the initial joint state of every env, perturbed per frame
+    q0 = torch.from_numpy(inp["q_init"]).view(bs, nq)
+    qq = (q0[None] + 0.1 * torch.randn(F, bs, nq, generator=g)).to(dev).requires_grad_(True)
+    qqd = (0.5 * torch.randn(F, bs, nqd, generator=g)).to(dev).requires_grad_(True)
+    w_q = (torch.randn(bs, F, nb, 7, generator=g) * 3.0).to(dev)   # some FK gradients land above 1: the clamp of :1109-1110 acts
+    w_q[0, 1, 2, 0] = float("nan")                                   # ... and one is NaN -> 0
+    w_qd = torch.randn(bs, F, nb, 6, generator=g).to(dev)
+    leaves = args + [qq, qqd]
+
+    def grads():
+        out = [x.grad.detach().clone() for x in leaves]
+        for x in leaves:
+            x.grad = None
+        return out
+
+    # the separate launches
+    loss, pos, vel = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
+    qp, qv, pid = dp_model.ForwardKinematics.apply(qq, qqd, h.env)
+    (loss * 0.37 + (qp * w_q).sum() + (qv * w_qd).sum()).backward()
+    ref = grads()
+    # riding along
+    loss2, pos2, vel2, qp2, qv2, pid2 = dp_model.ForwardWarpTrajLossFK.apply(*args, tgt, outseq, qq, qqd, h)
+    assert qp2.shape == (bs, F, nb, 7) and qv2.shape == (bs, F, nb, 6) and qp2.is_contiguous()
+    assert torch.equal(qp2, qp) and torch.equal(qv2, qv) and torch.equal(pos2, pos) and torch.equal(vel2, vel) and torch.equal(loss2, loss)
+    assert np.array_equal(np.stack(pid2, 0), np.stack(pid, 0))
+    (loss2 * 0.37 + (qp2 * w_q).sum() + (qv2 * w_qd).sum()).backward()
+    got = grads()
+    names = list(synth.INPUT_NAMES) + ["queried_q", "queried_qd"]
+    for k, a, b in zip(names, got, ref):
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
+    assert float(ref[-2].max()) == 1.0 and bool(torch.isfinite(ref[-2]).all())   # the clamp acted, the NaN weight left no NaN
+    # only one of the two FK outputs used downstream: the other adjoint is zero
+    loss3, _, _, qp3, qv3, _ = dp_model.ForwardWarpTrajLossFK.apply(*args, tgt, outseq, qq, qqd, h)
+    (qv3 * w_qd).sum().backward()
+    g3 = grads()
+    qp4, qv4, _ = dp_model.ForwardKinematics.apply(qq, qqd, h.env)
+    (qv4 * w_qd).sum().backward()
+    assert torch.equal(g3[-1], qqd.grad) and torch.equal(g3[-2], qq.grad)
+    # the C ABI takes any F x bs of chains, not only the rollout's: 3 frames of 5 envs beside this rollout, and beside an EMPTY rollout
+    dm = hip_backend.device_model(h.env)
+    c = lambda x: x.detach().to(torch.float32).contiguous()
+    jq, jqd = c(qq[:3, :5]), c(qqd[:3, :5])
+    want_q, want_qd = dm.fk_forward(jq.view(15, nq), jqd.view(15, nqd))
+    out = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[c(t[k]) for k in FWD], frame2step=f2s, target_pos=c(tgt), outseq=outseq, fk=(jq, jqd))
+    assert torch.equal(out[5]["fk_body_q"], want_q.view(3, 5, nb, 7).permute(1, 0, 2, 3)) and torch.equal(out[5]["fk_body_qd"], want_qd.view(3, 5, nb, 6).permute(1, 0, 2, 3))
+    e = lambda *s: torch.zeros(*s, device=dev)
+    out0 = dm.rollout_forward_traj_loss(0, T, inp["dt"], e(0), e(0), e(T, 0), e(T, 0, 6), e(T, 0), e(0), e(0), e(0), e(0, 3, 3), e(0, 3, 3),
+                                        frame2step=f2s, target_pos=e(0, F, nb, 7), fk=(jq, jqd))
+    assert torch.equal(out0[5]["fk_body_q"], out[5]["fk_body_q"]) and float(out0[5]["reduced"][0]) == 0.0
