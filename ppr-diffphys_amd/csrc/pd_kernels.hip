@@ -766,10 +766,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         float *ov = a.wp_vel + ((size_t)cfr * N + qidx) * 6;
         if (k.isv) { o[qc] = x.p; ov[qc] = x.w; ov[3 + qc] = x.v; }
       }
+    };
+    auto q_frame_loss = [&](int cfr, float x_p, float x_r) {  // after the step loop, on the poses read back (see the lane-per-body form)
       if constexpr (LOSS) {
         // trajectory loss of this frame (see frame_loss of the lane-per-body form): the body's pose is gathered into every lane of
         // its quad, se3_loss runs redundantly in the four lanes, lane c stores components c and 3 + c of the two gradients
-        const float pose[7] = {Q_BC0(x.p), Q_BC1(x.p), Q_BC2(x.p), Q_BC0(x.r), Q_BC1(x.r), Q_BC2(x.r), Q_BC3(x.r)};
+        const float pose[7] = {Q_BC0(x_p), Q_BC1(x_p), Q_BC2(x_p), Q_BC0(x_r), Q_BC1(x_r), Q_BC2(x_r), Q_BC3(x_r)};
         float lb = 0.f;
         const size_t ot = (((size_t)ec * a.nframes + cfr) * nb + bb) * 7;
         float tg[7], gp[7], gg[7];
@@ -905,6 +907,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
           if (a.grf) { a.grf[((size_t)fr_last * N + qidx) * 6 + qc] = 0.f; a.grf[((size_t)fr_last * N + qidx) * 6 + 3 + qc] = 0.f; }
           if (a.jaf) { a.jaf[((size_t)fr_last * N + qidx) * 6 + qc] = 0.f; a.jaf[((size_t)fr_last * N + qidx) * 6 + 3 + qc] = 0.f; }
         }
+      }
+    }
+    if constexpr (LOSS) {  // every lane reads back the pose components it stored itself; the quad gathers them by DPP
+      for (int f = 0; f < a.nframes; ++f) {
+        const float *o = a.wp_pos + ((size_t)f * N + qidx) * 7;
+        const float l_p = o[qv], l_r = o[3 + qc];
+        q_frame_loss(f, k.isv ? l_p : 0.f, l_r);
       }
     }
     return;
@@ -1142,14 +1151,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       // against right after hand-over A, and against after the vmcnt wait: -2 % / -0.5 % forward time at 4096 envs)
       spill_state(step, s, fr);
       if (step > 0) spill_wrench(step - 1);
-      if (LOSS && fr >= 0) frame_loss(fr, s);
       STAMP(8);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
       STAMP(9);
     } else {
       spill_state(step, s, fr);
       if (step > 0) spill_wrench(step - 1);
-      if (LOSS && fr >= 0) frame_loss(fr, s);
       WAVE_SYNC();
     }
     if (is_body) {
@@ -1204,7 +1211,6 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   {  // a frame may name the state after the last step (state_steps[nsteps], dp_model.py:396,1241-1246); no force
      // snapshot exists for it (the reference appends grf / jaf for step in steps_idx only, :1225-1228): zero rows
     const int fr_last = ld_uniform(a.frame_of_step, a.nsteps);
-    if (LOSS && fr_last >= 0) frame_loss(fr_last, s);
     if (fr_last >= 0 && is_body) {
       float *o = a.wp_pos + ((size_t)fr_last * N + idx) * 7;
       o[0] = s.p.x; o[1] = s.p.y; o[2] = s.p.z; o[3] = s.r.x; o[4] = s.r.y; o[5] = s.r.z; o[6] = s.r.w;
@@ -1215,6 +1221,19 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         if (a.grf) a.grf[((size_t)fr_last * N + idx) * 6 + k] = 0.f;
         if (a.jaf) a.jaf[((size_t)fr_last * N + idx) * 6 + k] = 0.f;
       }
+    }
+  }
+  if constexpr (LOSS) {
+    // The trajectory loss, AFTER the step loop: every lane reads back the frame poses it stored and evaluates se3_loss on them.  Inside
+    // the loop (at the 4 frame steps of 100) the loss code cost the loop its register allocation on EVERY step: 188 VGPRs / 55 spilled
+    // SGPRs against 159 / 28, 0.222-0.224 ms against 0.211.
+    for (int f = 0; f < a.nframes; ++f) {
+      BodyState cs = s;
+      if (is_body) {
+        const float *o = a.wp_pos + ((size_t)f * N + idx) * 7;
+        cs.p = V3(o[0], o[1], o[2]); cs.r = Q4(o[3], o[4], o[5], o[6]);
+      }
+      frame_loss(f, cs);
     }
   }
   STAMP_FLUSH(a);
