@@ -96,6 +96,13 @@ def _check(rc):
 
 
 def _dev(t, name, shape_numel=None):
+    """Device pointer of a contiguous float32 GPU tensor (an int: ctypes converts it for the c_void_p parameters); anything else raises
+    -- no silent copy, no CPU fallback.  The checks run on every call of every entry point: one fast path, messages on the slow one."""
+    try:
+        if t.is_cuda and t.dtype is torch.float32 and t.is_contiguous() and (shape_numel is None or t.numel() == shape_numel):
+            return t.data_ptr()
+    except AttributeError:
+        pass
     if not torch.is_tensor(t):
         raise TypeError("%s must be a torch tensor" % name)
     if not t.is_cuda:
@@ -104,13 +111,17 @@ def _dev(t, name, shape_numel=None):
         raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
     if not t.is_contiguous():
         raise ValueError("%s must be contiguous" % name)
-    if shape_numel is not None and t.numel() != shape_numel:
-        raise ValueError("%s has %d elements, expected %d" % (name, t.numel(), shape_numel))
-    return ctypes.c_void_p(t.data_ptr())
+    raise ValueError("%s has %d elements, expected %d" % (name, t.numel(), shape_numel))
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream as a raw handle (torch.cuda.current_stream() builds a Stream object: ~7 us per call)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def build_id():

@@ -46,7 +46,9 @@ for cfg in (sys.argv[1:] or ["laikago:512", "laikago:4096"]):
         loss, _, _ = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
         loss.backward()
 
-    for tag, fn in (("raw backend calls", raw), ("ForwardWarp autograd", autograd), ("ForwardWarpTrajLoss", fused)):
+    for tag, fn, mt in (("raw backend calls", raw, True), ("ForwardWarp autograd", autograd, True), ("ForwardWarpTrajLoss", fused, True),
+                        ("ForwardWarp, 1 thread", autograd, False), ("TrajLoss, 1 thread", fused, False)):
+        torch.autograd.set_multithreading_enabled(mt)   # False: backward runs on the calling thread (no hand-over to the device thread)
         for _ in range(20): fn()
         torch.cuda.synchronize()
         n = 200
