@@ -998,3 +998,47 @@ def test_fk_of_the_control_reference_rides_on_the_traj_loss_launches(name, bs, d
     out0 = dm.rollout_forward_traj_loss(0, T, inp["dt"], e(0), e(0), e(T, 0), e(T, 0, 6), e(T, 0), e(0), e(0), e(0), e(0, 3, 3), e(0, 3, 3),
                                         frame2step=f2s, target_pos=e(0, F, nb, 7), fk=(jq, jqd))
     assert torch.equal(out0[5]["fk_body_q"], out[5]["fk_body_q"]) and float(out0[5]["reduced"][0]) == 0.0
+
+
+@pytest.mark.parametrize("family", [1, 2], ids=["lane-per-body", "quad-lane"])
+def test_revolute_tree_with_six_children_on_the_root(family, dev, oracle_libs):
+    """Both kernel families gather the first four children of a body with unrolled reads and the rest in a loop that no shipped robot
+    enters (Laikago's root has exactly four).  A re-parented Laikago -- the root carries six revolute children (bodies 1, 2, 4, 5, 7,
+    10), three chains of depth 2-3 hang below -- is still a revolute-only PLAIN model (quad-lane eligible) and must match the C oracle:
+    poses, forces and all gradients at a short horizon, forward and adjoint."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = dict(robots.load_template("laikago"))
+    parent = np.array([-1, 0, 0, 2, 0, 0, 5, 0, 7, 8, 0, 10, 11], np.int32)
+    tpl["joint_parent"] = parent
+    bs, T = 21, 24
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=9, steps_per_frame=11, penetration=0.004)
+    rng = np.random.RandomState(9)
+    inp["torques"] = (rng.randn(*inp["torques"].shape) * 0.2).astype(np.float32)
+    inp["res_f"] = (rng.randn(*inp["res_f"].shape) * 0.2).astype(np.float32)
+    dm = hip_backend.DeviceModel(tpl)
+    dm.set_kernel_family(family)
+    out = gpu_rollout(dm, inp, dev)
+    info = dm.last_launch_info(0)
+    assert info["envs_per_wg"] * 128 // info["threads_per_wg"] == (1 if family == 2 else 4)   # envs per wave pair: which family ran
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert np.abs(st["grf"]).max() > 1.0 and np.abs(st["jaf"]).max() > 1.0
+    # (the re-parented joints start far from their anchors: the attach springs throw the bodies around, twists run into the +-10
+    # clamps -- bars a few times looser than the robots'; a child missing from a gather is an O(1) error)
+    errs = {k: relmax(out[k], st[k]) for k in ("wp_pos", "wp_vel", "grf", "jaf")}
+    errs.update({"g_" + k: relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) for k in GRADS})
+    print("six children, family %d: " % family + "  ".join("%s %.1e" % kv for kv in errs.items()))
+    assert errs["wp_pos"] < 2e-5 and errs["wp_vel"] < 5e-3 and errs["grf"] < 2e-2 and errs["jaf"] < 2e-2, errs
+    for k in GRADS:
+        assert np.isfinite(out["grads"][k]).all(), k
+        assert errs["g_" + k] < 5e-2, (k, errs)
+    # the tight bar: the float64 adjoint of the kernel's OWN trajectory (no rollout divergence in it), every env
+    from helpers import own_trajectory_check
+
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
+    print("   own trajectory: worst env %.1e, median %.1e (one-ulp conditioning median %.1e, plain fp32 %.1e)" % (
+        own["worst"].max(), np.median(own["worst"]), np.median(own["cond"]), np.median(own["fp32_atan2"])))
+    assert own["worst"].max() < 1e-3, own["worst"]   # measured 1.7e-5 (both families)
