@@ -50,6 +50,12 @@ class HostFrames:
         return iter(self._get())
 
 
+def _f32c(t):
+    """detached, float32, contiguous -- without touching a tensor that already is (the usual case; three tensor ops saved per input)"""
+    t = t.detach()
+    return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
 class ForwardKinematics(torch.autograd.Function):
     """rj_q [T,bs,nq], rj_qd [T,bs,nqd], env -> body_q [bs,T,nb,7], body_qd [bs,T,nb,6], body_q_numpy."""
 
@@ -104,7 +110,7 @@ class ForwardWarp(torch.autograd.Function):
         nsteps = len(self.steps_idx)
         frame2step = list(self.frame2step)
         dev = q_init.device
-        c = lambda t: t.detach().to(torch.float32).contiguous()
+        c = _f32c
         inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
                               body_inv_inertia)]
         frame2step = [int(s) for s in frame2step]
@@ -190,7 +196,7 @@ def _traj_loss_forward(ctx, rollout_inputs, target_position, outseq_idx, self, q
     dm = hip_backend.device_model(self.env)
     bs, nsteps = int(self.num_envs), len(self.steps_idx)
     frame2step = [int(s) for s in self.frame2step]
-    c = lambda t: t.detach().to(torch.float32).contiguous()
+    c = _f32c
     inp = [c(t) for t in (q_init, qd_init, torques, res_f, refs, target_ke, target_kd, body_inv_mass, body_inertia,
                           body_inv_inertia)]
     tgt = c(target_position).view(bs, len(frame2step), dm.nb, 7)

@@ -1042,3 +1042,46 @@ def test_revolute_tree_with_six_children_on_the_root(family, dev, oracle_libs):
     print("   own trajectory: worst env %.1e, median %.1e (one-ulp conditioning median %.1e, plain fp32 %.1e)" % (
         own["worst"].max(), np.median(own["worst"]), np.median(own["cond"]), np.median(own["fp32_atan2"])))
     assert own["worst"].max() < 1e-3, own["worst"]   # measured 1.7e-5 (both families)
+
+
+@pytest.mark.parametrize("family", [1, 2], ids=["lane-per-body", "quad-lane"])
+def test_revolute_joint_limits_engage(family, dev, oracle_libs):
+    """The shipped robots run with limit_ke = limit_kd = 0 (dp_model.py:144-145 of the reference), so eval_joint_force's limit branch
+    (integrator_euler.py:261-286) is dead for them.  Laikago with +-0.15 rad limits and limit_ke = 60, limit_kd = 1.5 on every revolute
+    joint, started beyond the limits on most joints: forward and adjoint of both kernel families against the C oracle (short horizon)
+    and the float64 adjoint of the kernel's own trajectory."""
+    from diffphys_amd import hip_backend, robots, synth
+    from helpers import own_trajectory_check
+    from oracle.ref_c import RefC
+
+    tpl = dict(robots.load_template("laikago"))
+    nqd = int(tpl["nqd"])
+    lo, up, lke, lkd = (np.array(tpl[k], np.float32).copy() for k in ("joint_limit_lower", "joint_limit_upper", "joint_limit_ke", "joint_limit_kd"))
+    lo[6:], up[6:], lke[6:], lkd[6:] = -0.15, 0.15, 60.0, 1.5
+    tpl.update(joint_limit_lower=lo, joint_limit_upper=up, joint_limit_ke=lke, joint_limit_kd=lkd)
+    bs, T = 19, 30
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=10, steps_per_frame=14, penetration=0.003)
+    dm = hip_backend.DeviceModel(tpl)
+    dm.set_kernel_family(family)
+    out = gpu_rollout(dm, inp, dev)
+    q0 = inp["q_init"].reshape(bs, -1)[:, 7:]
+    assert (np.abs(q0) > 0.15).mean() > 0.3                      # the limits are engaged from the first step on
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    rc0 = RefC(dict(tpl, joint_limit_ke=np.zeros(nqd, np.float32), joint_limit_kd=np.zeros(nqd, np.float32)), np.float32)
+    st0 = rc0.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    assert relmax(st0["jaf"], st["jaf"]) > 1e-2                  # ... and they matter
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 2e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 1e-3
+    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 5e-3
+    # against the oracle's own rollout: per-env medians (a joint angle within rounding of its limit takes the other branch in one of
+    # the two rollouts: single envs legitimately disagree); the tight bar is the own-trajectory check below
+    for k in GRADS:
+        assert np.isfinite(out["grads"][k]).all(), k
+        g, r = out["grads"][k].astype(np.float64), gr[k].astype(np.float64)
+        g, r = (g.reshape(T, bs, -1).transpose(1, 0, 2).reshape(bs, -1), r.reshape(T, bs, -1).transpose(1, 0, 2).reshape(bs, -1)) if k in ("torques", "res_f", "refs") else (g.reshape(bs, -1), r.reshape(bs, -1))
+        per_env = np.abs(g - r).max(1) / (np.abs(r).max(1) + 1e-12)
+        assert np.median(per_env) < 2e-2, (k, np.sort(per_env))
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
+    print("limits, family %d: own trajectory worst env %.1e, median %.1e" % (family, own["worst"].max(), np.median(own["worst"])))
+    assert own["worst"].max() < 1e-3, own["worst"]
