@@ -2152,7 +2152,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
           n_act[k] = on ? ldg(a.torques + o + k, boff_qd) : 0.f;
         }
       };
-      load_next(a.nsteps - 1);
+      if (a.nsteps > 0) load_next(a.nsteps - 1);  // (a zero-step rollout has no controls: null pointers)
       for (int step = a.nsteps - 1; step >= 0; --step) {
         PD_WAIT_VMEM();
         float tgt[ND], act[ND];

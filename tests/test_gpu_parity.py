@@ -1085,3 +1085,42 @@ def test_revolute_joint_limits_engage(family, dev, oracle_libs):
     own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
     print("limits, family %d: own trajectory worst env %.1e, median %.1e" % (family, own["worst"].max(), np.median(own["worst"])))
     assert own["worst"].max() < 1e-3, own["worst"]
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("human", 0)])
+def test_zero_step_rollout_is_fk_and_its_adjoint(name, family, dev, oracle_libs):
+    """nsteps = 0 with a frame at state 0: the forward is eval_fk of (q_init, qd_init) (dp_model.py:1204), the backward its adjoint
+    (:1294-1306) -- the path where the adjoint kernels have no staged records and rebuild state 0 themselves."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template(name)
+    bs, nb = 5, int(tpl["nb"])
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=1, seed=13, penetration=0.002)
+    for k in ("torques", "res_f", "refs"):
+        inp[k] = inp[k][:0]
+    inp["nsteps"] = 0
+    rng = np.random.RandomState(1)
+    inp["frame2step"] = [0]
+    inp["qd_init"] = (rng.randn(*inp["qd_init"].shape) * 0.3).astype(np.float32)
+    inp["adj_pos"] = (rng.randn(1, bs * nb, 7) * 1e-2).astype(np.float32)
+    inp["adj_vel"] = (rng.randn(1, bs * nb, 6) * 1e-2).astype(np.float32)
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, 0, [0], inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-6 and relmax(out["wp_vel"], st["wp_vel"]) < 1e-5
+    assert np.abs(out["grf"]).max() == 0 and np.abs(out["jaf"]).max() == 0          # no step, no force snapshot: zero rows
+    for k in ("q_init", "qd_init"):
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 1e-4, k
+    for k in ("target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia"):
+        assert np.abs(out["grads"][k]).max() == 0, k
+    # ... and they are what the FK entry points give
+    jq = torch.from_numpy(inp["q_init"]).to(dev).view(bs, -1)
+    jqd = torch.from_numpy(inp["qd_init"]).to(dev).view(bs, -1)
+    bq, bqd = dm.fk_forward(jq, jqd)
+    # (to the last place or two: the FK inside the rollout kernels and k_fk contract their products differently)
+    assert relmax(bq.cpu().numpy().reshape(1, bs * nb, 7), out["wp_pos"]) < 1e-6 and relmax(bqd.cpu().numpy().reshape(1, bs * nb, 6), out["wp_vel"]) < 1e-6
