@@ -1124,3 +1124,47 @@ def test_zero_step_rollout_is_fk_and_its_adjoint(name, family, dev, oracle_libs)
     bq, bqd = dm.fk_forward(jq, jqd)
     # (to the last place or two: the FK inside the rollout kernels and k_fk contract their products differently)
     assert relmax(bq.cpu().numpy().reshape(1, bs * nb, 7), out["wp_pos"]) < 1e-6 and relmax(bqd.cpu().numpy().reshape(1, bs * nb, 6), out["wp_vel"]) < 1e-6
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("human", 0), ("quad", 0)])
+def test_edge_shapes_every_robot(name, family, dev, oracle_libs):
+    """Shapes at the edges for every robot / kernel family: one env and one step with the only frame at the FINAL state; no frame at
+    all (nothing to output, all-zero gradients); no force snapshots requested; a batch one env past a wave's worth."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template(name)
+    nb = int(tpl["nb"])
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    rc = RefC(tpl, np.float32)
+    rng = np.random.RandomState(2)
+    for bs, T, f2s in ((1, 1, [1]), (2, 3, []), (5, 4, [2, 4, 0])):
+        inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=14, penetration=0.002)
+        F = len(f2s)
+        inp["frame2step"] = f2s
+        inp["adj_pos"] = (rng.randn(F, bs * nb, 7) * 1e-3).astype(np.float32)
+        inp["adj_vel"] = (rng.randn(F, bs * nb, 6) * 1e-3).astype(np.float32)
+        out = gpu_rollout(dm, inp, dev)
+        assert out["wp_pos"].shape == (F, bs * nb, 7) and out["grf"].shape == (F, bs * nb, 6)
+        if F == 0:
+            for k, v in out["grads"].items():
+                assert np.abs(v).max() == 0, (k, bs, T)
+            continue
+        st = rc.rollout_forward(inp, T, f2s, inp["dt"])
+        gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+        assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 5e-3, (bs, T)   # (velocities of 1e-2 m/s after 1-4 steps: fp32 round-off of the 16 kN/m attach springs)
+        for k in ("q_init", "qd_init", "refs", "res_f", "body_inertia", "body_inv_mass"):
+            ref = gr[k]
+            if np.abs(ref).max() > 0:
+                assert relmax(out["grads"][k].reshape(ref.shape), ref) < 2e-2, (k, bs, T)
+            else:
+                assert np.abs(out["grads"][k]).max() == 0, (k, bs, T)
+    # no force snapshots: same poses, no grf / jaf buffers touched
+    inp = synth.make_inputs(tpl, name, bs=3, nsteps=5, seed=15, penetration=0.002)
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in FWD}
+    a = dm.rollout_forward(3, 5, inp["dt"], *[t[k] for k in FWD], frame2step=[0, 5])
+    b = dm.rollout_forward(3, 5, inp["dt"], *[t[k] for k in FWD], frame2step=[0, 5], want_forces=False)
+    assert b[2] is None and b[3] is None and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float(a[2][1].abs().max()) == 0.0   # the frame at state T has no force snapshot (dp_model.py:1225-1228): zero rows
