@@ -1168,3 +1168,48 @@ def test_edge_shapes_every_robot(name, family, dev, oracle_libs):
     b = dm.rollout_forward(3, 5, inp["dt"], *[t[k] for k in FWD], frame2step=[0, 5], want_forces=False)
     assert b[2] is None and b[3] is None and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert float(a[2][1].abs().max()) == 0.0   # the frame at state T has no force snapshot (dp_model.py:1225-1228): zero rows
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("human", 0)])
+def test_every_state_is_a_frame(name, family, dev, oracle_libs):
+    """frame2step = 0 .. T (every state gathered, seeds at every step of the reverse sweep, the final state included), in a
+    shuffled order -- the frame paths of the loops run on every iteration instead of 4 in 100."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template(name)
+    nb, bs, T = int(tpl["nb"]), 7, 12
+    rng = np.random.RandomState(3)
+    f2s = [int(x) for x in rng.permutation(T + 1)]
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=16, penetration=0.003)
+    inp["frame2step"] = f2s
+    inp["adj_pos"] = (rng.randn(T + 1, bs * nb, 7) * 1e-3).astype(np.float32)
+    inp["adj_vel"] = (rng.randn(T + 1, bs * nb, 6) * 1e-3).astype(np.float32)
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, f2s, inp["dt"])
+    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 5e-3
+    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 5e-3
+    for k in GRADS:
+        assert relmax(out["grads"][k].reshape(gr[k].shape), gr[k]) < 2e-2, k
+    # the same through the loss-evaluating entries: table = se3_loss of every state's poses, seeds at every step
+    from diffphys_amd import dp_utils
+
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in FWD}
+    F = T + 1
+    pos = torch.from_numpy(out["wp_pos"]).to(dev)
+    tgt = (pos.view(F, bs, nb, 7).permute(1, 0, 2, 3) + 0.01 * torch.randn(bs, F, nb, 7, device=dev)).contiguous()
+    o = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s, target_pos=tgt)
+    assert torch.equal(o[0], pos)
+    want = dp_utils.se3_loss(pos.view(F, bs, nb, 7).permute(1, 0, 2, 3).contiguous(), tgt).mean(-1)
+    assert float((o[5]["table"] - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    one = torch.ones(1, device=dev)
+    g = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], o[5], one)
+    seeds = o[5]["seed_pos"].view(F, bs, nb, 7) * (o[5]["scale"].t() / nb)[:, :, None, None]
+    g2 = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], seeds.reshape(F, bs * nb, 7).contiguous(), torch.zeros(F, bs * nb, 6, device=dev))
+    for k in g2:
+        assert float((g[k] - g2[k]).abs().max()) <= 1e-5 * float(g2[k].abs().max()) + 1e-30, k
