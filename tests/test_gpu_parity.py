@@ -1213,3 +1213,38 @@ def test_every_state_is_a_frame(name, family, dev, oracle_libs):
     g2 = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], seeds.reshape(F, bs * nb, 7).contiguous(), torch.zeros(F, bs * nb, 6, device=dev))
     for k in g2:
         assert float((g[k] - g2[k]).abs().max()) <= 1e-5 * float(g2[k].abs().max()) + 1e-30, k
+
+
+def test_mixed_families_between_the_two_thresholds(dev, oracle_libs):
+    """Between 2 x CUs and 4 x CUs envs (513 .. 1024 on MI355X) the automatic choice runs the quad-lane FORWARD kernel and the
+    lane-per-body ADJOINT on the trajectory and hit log it saved.  640 envs: the forward is bit-identical to family 2's, the gradients
+    pass the own-trajectory check and equal family 1's adjoint of that same workspace."""
+    from diffphys_amd import hip_backend, robots, synth
+    from helpers import own_trajectory_check
+
+    tpl = robots.load_template("laikago")
+    bs, T = 640, 40
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=17, steps_per_frame=13, penetration=0.003)
+    dm = hip_backend.DeviceModel(tpl)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if not (2 * cus < bs <= 4 * cus):
+        pytest.skip("batch is not between the two thresholds on this device")
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
+    f2s = list(inp["frame2step"])
+    fwd = lambda: dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s)
+    bwd = lambda ws: dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, ws, t["adj_pos"], t["adj_vel"])
+    auto = fwd()
+    info_f = dm.last_launch_info(0)
+    g_auto = bwd(auto[4])
+    info_b = dm.last_launch_info(1)
+    assert info_f["envs_per_wg"] * 128 // info_f["threads_per_wg"] == 1 and info_b["envs_per_wg"] * 128 // info_b["threads_per_wg"] == 4
+    dm.set_kernel_family(2)
+    q = fwd()
+    assert all(torch.equal(a, b) for a, b in zip(auto[:4], q[:4])) and torch.equal(auto[4], q[4])
+    dm.set_kernel_family(1)
+    g1 = bwd(auto[4])                      # family 1's adjoint on the quad-lane forward's workspace
+    assert all(torch.equal(g_auto[k], g1[k]) for k in g1)
+    dm.set_kernel_family(0)
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
+    print("mixed families, 640 envs: own trajectory worst env %.1e, median %.1e" % (own["worst"].max(), np.median(own["worst"])))
+    assert (own["worst"] <= np.maximum(1e-3, own["cond"])).all()
