@@ -1248,3 +1248,45 @@ def test_mixed_families_between_the_two_thresholds(dev, oracle_libs):
     own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
     print("mixed families, 640 envs: own trajectory worst env %.1e, median %.1e" % (own["worst"].max(), np.median(own["worst"])))
     assert (own["worst"] <= np.maximum(1e-3, own["cond"])).all()
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("human", 0), ("quad", 0)])
+def test_traj_loss_and_fk_ride_at_the_edges(name, family, dev):
+    """The row-f4 entries at the edges: a zero-step rollout (the loss is se3_loss of FK(q_init) against the target, its gradient goes
+    through the FK adjoint), and a rollout without frames (loss 0, zero gradients) -- both with FK chains riding along, whose results
+    must still be those of pd_fk_forward / pd_fk_backward."""
+    from diffphys_amd import dp_utils, hip_backend, robots, synth
+
+    tpl = robots.load_template(name)
+    nb, nq, nqd, bs = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"]), 6
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    g = torch.Generator().manual_seed(21)
+    for T, f2s in ((0, [0]), (3, [])):
+        inp = synth.make_inputs(tpl, name, bs=bs, nsteps=max(T, 1), seed=18, penetration=0.002)
+        for k in ("torques", "res_f", "refs"):
+            inp[k] = inp[k][:T]
+        t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in FWD}
+        F = len(f2s)
+        jq = (t["q_init"].view(1, bs, nq) + 0.1 * torch.randn(2, bs, nq, generator=g).to(dev)).contiguous()
+        jqd = (0.3 * torch.randn(2, bs, nqd, generator=g)).to(dev).contiguous()
+        tgt = torch.randn(bs, F, nb, 7, generator=g).to(dev)
+        o = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s, target_pos=tgt, fk=(jq, jqd))
+        wq, wqd = dm.fk_forward(jq.view(2 * bs, nq), jqd.view(2 * bs, nqd))
+        assert torch.equal(o[5]["fk_body_q"], wq.view(2, bs, nb, 7).permute(1, 0, 2, 3)) and torch.equal(o[5]["fk_body_qd"], wqd.view(2, bs, nb, 6).permute(1, 0, 2, 3))
+        aq = torch.randn(bs, 2, nb, 7, generator=g).to(dev)
+        aqd = torch.randn(bs, 2, nb, 6, generator=g).to(dev)
+        gr = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], o[5], torch.ones(1, device=dev), fk=(jq, jqd, aq, aqd))
+        wgq, wgqd = dm.fk_backward(jq.view(2 * bs, nq), jqd.view(2 * bs, nqd), aq.permute(1, 0, 2, 3).contiguous(), aqd.permute(1, 0, 2, 3).contiguous())
+        assert torch.equal(gr["fk_joint_q"].view(2 * bs, nq), wgq) and torch.equal(gr["fk_joint_qd"].view(2 * bs, nqd), wgqd)
+        red = o[5]["reduced"].cpu().numpy()
+        if F == 0:
+            assert red[0] == 0.0 and all(float(gr[k].abs().max()) == 0.0 for k in ("q_init", "qd_init", "refs", "target_ke", "body_inertia"))
+        else:
+            pose0, _ = dm.fk_forward(t["q_init"].view(bs, nq), t["qd_init"].view(bs, nqd))
+            assert float((o[0].view(bs, nb, 7) - pose0).abs().max()) <= 1e-6 * float(pose0.abs().max())
+            want = dp_utils.se3_loss(o[0].view(1, bs, nb, 7).permute(1, 0, 2, 3).contiguous(), tgt).mean(-1)
+            assert float((o[5]["table"] - want).abs().max()) <= 2e-6 * float(want.abs().max())
+            assert np.isfinite(red[0]) and red[0] > 0 and float(gr["q_init"].abs().max()) > 0 and bool(torch.isfinite(gr["q_init"]).all())
+            assert float(gr["refs"].numel()) == 0 and float(gr["target_ke"].abs().max()) == 0.0
