@@ -1292,16 +1292,16 @@ def test_traj_loss_and_fk_ride_at_the_edges(name, family, dev):
             assert float(gr["refs"].numel()) == 0 and float(gr["target_ke"].abs().max()) == 0.0
 
 
-def test_forty_link_chain(dev, oracle_libs, tmp_path):
-    """A serial chain of 40 bodies (root FREE + 39 revolute joints, alternating axes, box collisions): the deepest tree a 64-lane
-    segment can hold comfortably -- 40 FK levels, one env per wave, every body's parent is its neighbour lane -- through the model
+@pytest.mark.parametrize("n", [40, 64])
+def test_forty_link_chain(n, dev, oracle_libs, tmp_path):
+    """A serial chain of 40 / 64 bodies (root FREE + revolute joints, alternating axes, box collisions): the deepest trees a 64-lane
+    segment can hold (64 = every lane a body) -- n FK levels, one env per wave, every body's parent is its neighbour lane -- through the model
     compiler and the revolute kernels, against the C oracle and the float64 adjoint of the kernel's own trajectory."""
     from diffphys_amd import hip_backend, sim
     from diffphys_amd.import_urdf import parse_urdf
     from helpers import build_template, own_trajectory_check
     from oracle.ref_c import RefC
 
-    n = 40
     links = "".join('<link name="l%d"><collision><origin xyz="0.05 0 0"/><geometry><box size="0.10 0.05 0.05"/></geometry></collision></link>\n' % i for i in range(n))
     joints = "".join('<joint name="j%d" type="continuous"><parent link="l%d"/><child link="l%d"/><axis xyz="%s"/><origin xyz="0.10 0 0" rpy="0 0 0"/>'
                      '<limit effort="1" velocity="1"/></joint>\n' % (i, i - 1, i, "0 0 1" if i % 2 else "0 1 0") for i in range(1, n))
@@ -1341,6 +1341,7 @@ def test_forty_link_chain(dev, oracle_libs, tmp_path):
     for k in GRADS:
         assert np.isfinite(out["grads"][k]).all(), k
     own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
-    print("40-link chain: own trajectory worst env %.1e, median %.1e; vs oracle rollout q_init %.1e" % (
-        own["worst"].max(), np.median(own["worst"]), relmax(out["grads"]["q_init"].reshape(gr["q_init"].shape), gr["q_init"])))
-    assert own["worst"].max() < 1e-3, own["worst"]
+    print("%d-link chain: own trajectory worst env %.1e, median %.1e; vs oracle rollout q_init %.1e" % (
+        n, own["worst"].max(), np.median(own["worst"]), relmax(out["grads"]["q_init"].reshape(gr["q_init"].shape), gr["q_init"])))
+    # per env: 1e-3, or three times what a plain fp32 evaluation of the same adjoint on the same trajectory loses (64 coupled joints)
+    assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), (own["worst"], own["fp32_atan2"])
