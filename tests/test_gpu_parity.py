@@ -1345,3 +1345,58 @@ def test_forty_link_chain(n, dev, oracle_libs, tmp_path):
         n, own["worst"].max(), np.median(own["worst"]), relmax(out["grads"]["q_init"].reshape(gr["q_init"].shape), gr["q_init"])))
     # per env: 1e-3, or three times what a plain fp32 evaluation of the same adjoint on the same trajectory loses (64 coupled joints)
     assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), (own["worst"], own["fp32_atan2"])
+
+
+@pytest.mark.parametrize("n", [30, 45])
+def test_thirty_compound_joints_in_a_chain(n, dev, oracle_libs, tmp_path):
+    """31 bodies joined by 30 COMPOUND joints in series (the *_R / *_P / *_Y triples of the reference's URDF convention,
+    import_urdf.py:177-196): the compound kernels (k_rollout_fwd unsplit / split, k_rollout_bwd3) on a 64-lane segment with a deep tree
+    -- the shipped compound robots have 19 and 26 bodies at depth <= 5."""
+    from diffphys_amd import hip_backend, sim
+    from diffphys_amd.import_urdf import parse_urdf
+    from helpers import build_template, own_trajectory_check
+    from oracle.ref_c import RefC
+
+    box = '<collision><origin xyz="0.05 0 0"/><geometry><box size="0.10 0.05 0.05"/></geometry></collision>'
+    links = '<link name="base">%s</link>\n' % box
+    joints = ""
+    for i in range(n):
+        par = "base" if i == 0 else "s%d_Y" % (i - 1)
+        links += '<link name="s%d_R"/>\n<link name="s%d_P"/>\n<link name="s%d_Y">%s</link>\n' % (i, i, i, box)
+        joints += ('<joint name="j%d_R" type="revolute"><parent link="%s"/><child link="s%d_R"/><axis xyz="1 0 0"/><origin xyz="0.10 0 0"/><limit lower="-1.5" upper="1.5" effort="1" velocity="1"/></joint>\n'
+                   '<joint name="j%d_P" type="revolute"><parent link="s%d_R"/><child link="s%d_P"/><axis xyz="0 1 0"/></joint>\n'
+                   '<joint name="j%d_Y" type="revolute"><parent link="s%d_P"/><child link="s%d_Y"/><axis xyz="0 0 1"/></joint>\n') % (i, par, i, i, i, i, i, i, i)
+    (tmp_path / "worm.urdf").write_text('<?xml version="1.0"?>\n<robot name="worm">\n' + links + joints + "</robot>\n")
+    b = sim.ModelBuilder()
+    parse_urdf(str(tmp_path / "worm.urdf"), b, xform=sim.transform((0, 0.05, 0), sim.quat_identity()), floating=True, density=1000.0,
+               armature=0.001, stiffness=20.0, damping=0.2, shape_ke=1e4, shape_kd=0.0, shape_kf=1e2, shape_mu=1.0, limit_ke=0.0, limit_kd=0.0)
+    tpl = build_template(b, attach_ke=4000.0, attach_kd=40.0)
+    nb, nq, nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+    assert nb == n + 1 and sorted(set(int(t) for t in tpl["joint_type"])) == [4, 5] and nqd == 6 + 3 * n
+    bs, T = 5, 20
+    rng = np.random.RandomState(8)
+    q = np.tile(tpl["joint_q"].astype(np.float64), (bs, 1))
+    q[:, 1] = 0.021 + rng.rand(bs) * 0.004
+    q[:, 7:] = rng.uniform(-0.01, 0.01, (bs, nq - 7))
+    mass = np.tile(tpl["body_mass"].astype(np.float64), bs)
+    inertia = np.tile(tpl["body_inertia"].astype(np.float64), (bs, 1, 1))
+    ke = np.tile(np.r_[np.zeros(6), np.full(nqd - 6, 20.0)], bs)
+    inp = dict(q_init=q.reshape(-1), qd_init=rng.randn(bs * nqd) * 0.02, torques=rng.randn(T, bs * nqd) * 0.02,
+               res_f=rng.randn(T, bs * nb, 6) * 0.02, refs=rng.uniform(-0.05, 0.05, (T, bs * nqd)), target_ke=ke, target_kd=ke * 0.01,
+               body_mass=mass, body_inv_mass=1 / mass, body_inertia=inertia, body_inv_inertia=np.linalg.inv(inertia),
+               adj_pos=rng.randn(3, bs * nb, 7) * 1e-3, adj_vel=rng.randn(3, bs * nb, 6) * 1e-3)
+    inp = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inp.items()}
+    inp.update(frame2step=[0, 9, 20], nsteps=T, dt=5e-4)
+    dm = hip_backend.DeviceModel(tpl)
+    out = gpu_rollout(dm, inp, dev)
+    st = RefC(tpl, np.float32).rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    st64 = RefC(tpl, np.float64).rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    assert np.abs(st["grf"]).max() > 0.1 and np.abs(st["jaf"]).max() > 0.1
+    for k, floor in (("wp_pos", 2e-5), ("wp_vel", 5e-3), ("grf", 1e-2), ("jaf", 1e-2)):
+        e, y = relmax(out[k], st64[k]), relmax(st[k], st64[k])
+        assert e < max(floor, 3.0 * y), (k, e, y)
+    for k in GRADS:
+        assert np.isfinite(out["grads"][k]).all(), k
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
+    print("%d compound joints: segw %d, own trajectory worst env %.1e, median %.1e" % (n, dm.segment_width(), own["worst"].max(), np.median(own["worst"])))
+    assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), (own["worst"], own["fp32_atan2"])
