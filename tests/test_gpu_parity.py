@@ -1240,7 +1240,9 @@ def test_mixed_families_between_the_two_thresholds(dev, oracle_libs):
     assert info_f["envs_per_wg"] * 128 // info_f["threads_per_wg"] == 1 and info_b["envs_per_wg"] * 128 // info_b["threads_per_wg"] == 4
     dm.set_kernel_family(2)
     q = fwd()
-    assert all(torch.equal(a, b) for a, b in zip(auto[:4], q[:4])) and torch.equal(auto[4], q[4])
+    assert all(torch.equal(a, b) for a, b in zip(auto[:4], q[:4]))
+    # (the saved trajectory, decoded: the raw workspace also holds hit-log slots past each count, which nobody writes)
+    assert all(torch.equal(a, b) for a, b in zip(dm.saved_trajectory(auto[4], bs, T), dm.saved_trajectory(q[4], bs, T)))
     dm.set_kernel_family(1)
     g1 = bwd(auto[4])                      # family 1's adjoint on the quad-lane forward's workspace
     assert all(torch.equal(g_auto[k], g1[k]) for k in g1)
