@@ -1402,3 +1402,38 @@ def test_thirty_compound_joints_in_a_chain(n, dev, oracle_libs, tmp_path):
     own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
     print("%d compound joints: segw %d, own trajectory worst env %.1e, median %.1e" % (n, dm.segment_width(), own["worst"].max(), np.median(own["worst"])))
     assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), (own["worst"], own["fp32_atan2"])
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("human", 0)])
+def test_bodies_without_inverse_mass(name, family, dev, oracle_libs):
+    """integrate_bodies switches gravity off for a body whose inverse mass is zero (integrator_euler.py:61-62: g * nonzero(inv_m)) --
+    no shipped configuration has one.  The root of every second env gets inv_mass = 0 and inv_inertia = 0 (a pinned base that the
+    joint and contact forces cannot move), one limb body inv_mass = 0 only: forward and gradients against the C oracle and the
+    own-trajectory adjoint."""
+    from diffphys_amd import hip_backend, robots, synth
+    from helpers import own_trajectory_check
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template(name)
+    nb, bs, T = int(tpl["nb"]), 8, 20
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=19, steps_per_frame=9, penetration=0.003)
+    im = inp["body_inv_mass"].reshape(bs, nb).copy()
+    ii = inp["body_inv_inertia"].reshape(bs, nb, 3, 3).copy()
+    im[::2, 0] = 0.0
+    ii[::2, 0] = 0.0
+    im[1::2, 3] = 0.0
+    inp["body_inv_mass"], inp["body_inv_inertia"] = im.reshape(-1), ii.reshape(bs * nb, 3, 3)
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    pos = out["wp_pos"].reshape(-1, bs, nb, 7)
+    assert np.abs(pos[-1, ::2, 0, :3] - pos[0, ::2, 0, :3]).max() < 1e-6            # the pinned roots did not move ((x + R com) - R com: an ulp)
+    assert np.abs(pos[-1, 1::2, 0, :3] - pos[0, 1::2, 0, :3]).max() > 0.0
+    assert relmax(out["wp_pos"], st["wp_pos"]) < 2e-5 and relmax(out["wp_vel"], st["wp_vel"]) < 5e-3
+    assert relmax(out["grf"], st["grf"]) < 5e-3 and relmax(out["jaf"], st["jaf"]) < 5e-3
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
+    print("%s family %d, zero inverse masses: own trajectory worst env %.1e" % (name, family, own["worst"].max()))
+    assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), own["worst"]
