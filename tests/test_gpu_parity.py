@@ -1437,3 +1437,45 @@ def test_bodies_without_inverse_mass(name, family, dev, oracle_libs):
     own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
     print("%s family %d, zero inverse masses: own trajectory worst env %.1e" % (name, family, own["worst"].max()))
     assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), own["worst"]
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("quad", 0)])
+def test_other_model_constants(name, family, dev, oracle_libs):
+    """Model constants away from the shipped robots' values: tilted gravity, a twice longer time step, contact damping (kd > 0: the
+    `fd = min(vn, 0) kd step(c)` term is identically zero for every shipped robot), weaker friction (mu = 0.4, kf = 40, different per
+    shape), softer attach springs, contact thickness (contact_dist) on half the points."""
+    from diffphys_amd import hip_backend, robots, synth
+    from helpers import own_trajectory_check
+    from oracle.ref_c import RefC
+
+    tpl = dict(robots.load_template(name))
+    nb, bs, T = int(tpl["nb"]), 9, 16
+    rng = np.random.RandomState(20)
+    tpl["gravity"] = np.array([1.5, -7.0, -2.0], np.float32)
+    mats = np.array(tpl["shape_materials"], np.float32).copy()
+    mats[:, 1] = 30.0 + 10.0 * rng.rand(len(mats))          # kd
+    mats[:, 2] = 40.0 + 20.0 * rng.rand(len(mats))          # kf
+    mats[:, 3] = 0.4 + 0.2 * rng.rand(len(mats))            # mu
+    tpl["shape_materials"] = mats
+    tpl["joint_attach_ke"], tpl["joint_attach_kd"] = np.float32(5000.0), np.float32(60.0)
+    cd = np.array(tpl["contact_dist"], np.float32).copy()
+    cd[::2] += 0.002
+    tpl["contact_dist"] = cd
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=21, steps_per_frame=7, penetration=0.003)
+    inp["dt"] = 1e-3
+    inp["qd_init"] = (rng.randn(*inp["qd_init"].shape) * 0.3).astype(np.float32)   # normal velocities into the ground: the damping term acts
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    out = gpu_rollout(dm, inp, dev)
+    rc = RefC(tpl, np.float32)
+    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    st64 = RefC(tpl, np.float64).rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    base = RefC(robots.load_template(name), np.float32).rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    assert relmax(base["grf"], st["grf"]) > 5e-2 and relmax(base["wp_pos"], st["wp_pos"]) > 1e-4     # the constants matter
+    for k, floor in (("wp_pos", 2e-5), ("wp_vel", 5e-3), ("grf", 5e-3), ("jaf", 5e-3)):
+        e, y = relmax(out[k], st64[k]), relmax(st[k], st64[k])
+        assert e < max(floor, 3.0 * y), (k, e, y)
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
+    print("%s family %d, other constants: own trajectory worst env %.1e" % (name, family, own["worst"].max()))
+    assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), own["worst"]
