@@ -199,3 +199,65 @@ def test_convert_and_lazy_host_frames():
     assert hf[1].shape == (3, 7) and hf[1][0, 0] == 21.0 and np.stack(hf, 0).shape == (2, 3, 7)
     x = torch.arange(8.0)
     assert convert_ppr_warp(x).tolist() == [3, 4, 5, 0, 1, 2, 6, 7]
+
+
+def test_traj_loss_fk_function_bookkeeping_with_a_fake_backend(monkeypatch):
+    """The autograd plumbing of ForwardWarpTrajLoss / ForwardWarpTrajLossFK (16 inputs, 6 outputs, 16 gradient slots, which tensors are
+    saved and handed to which backend call) with the device model replaced by a recorder on CPU tensors -- no kernel runs; the numerics
+    are the GPU tests' business."""
+    import torch
+    from diffphys_amd import dp_model, hip_backend
+
+    bs, T, F, nb, nq, nqd = 3, 5, 2, 4, 10, 9
+    calls = {}
+
+    class Fake:
+        def __init__(self):
+            self.nb, self.nq, self.nqd = nb, nq, nqd
+
+        def rollout_forward_traj_loss(self, bs_, nsteps, dt, *inp, frame2step, target_pos, outseq, rot_ratio, want_seed_gt, fk=None):
+            calls["fwd"] = dict(n_inp=len(inp), fk=None if fk is None else [tuple(x.shape) for x in fk], tgt=tuple(target_pos.shape), f2s=list(frame2step))
+            z = lambda *s: torch.zeros(*s)
+            tl = dict(reduced=torch.tensor([0.5, 1.0, 2.0, 0.0]), table=z(bs, F), scale=torch.full((bs, F), 0.25), seed_pos=z(F, bs * nb, 7),
+                      seed_gt=torch.ones(bs, F, nb, 7) if want_seed_gt else None)
+            if fk is not None:
+                tl["fk_body_q"], tl["fk_body_qd"] = z(bs, F, nb, 7).requires_grad_(False), z(bs, F, nb, 6)
+            return z(F, bs * nb, 7), z(F, bs * nb, 6), z(F, bs * nb, 6), z(F, bs * nb, 6), z(7), tl
+
+        def rollout_backward_traj_loss(self, bs_, nsteps, dt, *args, fk=None):
+            calls["bwd"] = dict(n_args=len(args), gl=float(args[-1]), fk=None if fk is None else [tuple(x.shape) for x in fk])
+            g = dict(q_init=torch.ones(bs * nq), qd_init=torch.ones(bs * nqd), torques=torch.ones(T, bs * nqd), res_f=torch.ones(T, bs * nb, 6),
+                     refs=torch.ones(T, bs * nqd), target_ke=torch.ones(bs * nqd), target_kd=torch.ones(bs * nqd), body_inv_mass=torch.ones(bs * nb),
+                     body_inertia=torch.ones(bs * nb, 3, 3), body_inv_inertia=torch.ones(bs * nb, 3, 3))
+            if fk is not None:
+                g["fk_joint_q"], g["fk_joint_qd"] = torch.full((F, bs, nq), 2.0), torch.full((F, bs, nqd), 3.0)
+            return g
+
+    monkeypatch.setattr(hip_backend, "device_model", lambda env: Fake())
+
+    class Host:
+        pass
+
+    h = Host()
+    h.env, h.num_envs, h.steps_idx, h.frame2step, h.dt = object(), bs, range(T), [0, 4], 5e-4
+    shapes = [(bs * nq,), (bs * nqd,), (T, bs * nqd), (T, bs * nb, 6), (T, bs * nqd), (bs * nqd,), (bs * nqd,), (bs * nb,), (bs * nb,), (bs * nb, 3, 3), (bs * nb, 3, 3)]
+    args = [torch.zeros(*s, requires_grad=True) for s in shapes]
+    tgt = torch.zeros(bs, F, nb, 7, requires_grad=True)
+    outseq = torch.zeros(bs, F, dtype=torch.bool)
+    qq, qqd = torch.zeros(F, bs, nq, requires_grad=True), torch.zeros(F, bs, nqd, requires_grad=True)
+    loss, pos, vel, qp, qv, pid = dp_model.ForwardWarpTrajLossFK.apply(*args, tgt, outseq, qq, qqd, h)
+    assert calls["fwd"] == dict(n_inp=10, fk=[(F, bs, nq), (F, bs, nqd)], tgt=(bs, F, nb, 7), f2s=[0, 4])
+    assert float(loss.detach()) == 0.5 and not pos.requires_grad and not vel.requires_grad and qp.requires_grad and qv.requires_grad
+    assert qp.shape == (bs, F, nb, 7) and qv.shape == (bs, F, nb, 6) and len(pid) == F and len(h.grfs) == 2
+    (loss * 0.3 + qp.sum() * 2.0).backward()           # qv unused: its adjoint arrives as zeros
+    assert calls["bwd"]["fk"] == [(F, bs, nq), (F, bs, nqd), (bs, F, nb, 7), (bs, F, nb, 6)] and abs(calls["bwd"]["gl"] - 0.3) < 1e-7
+    assert all(a.grad is not None and a.grad.shape == a.shape for a in args)
+    assert float(args[7].grad.abs().max()) == 0.0 and float(args[8].grad.min()) == 1.0      # body_mass: zero gradient; inv_mass: the backend's
+    assert float(qq.grad.min()) == 2.0 and float(qqd.grad.min()) == 3.0
+    assert torch.allclose(tgt.grad, torch.full_like(tgt, 0.25 * 0.3 / nb))                   # seed_gt x scale x g / nb
+    # the plain form: no FK arguments reach the backend, 14 gradient slots
+    for a in args + [tgt]:
+        a.grad = None
+    loss2, _, _ = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
+    loss2.backward()
+    assert calls["fwd"]["fk"] is None and calls["bwd"]["fk"] is None and all(a.grad is not None for a in args)
