@@ -345,7 +345,8 @@ def main():
         ach_bwd = bs * T * bb / (bwd_ms * 1e-3)
         ach_fwd = bs * T * bf / (fwd_ms * 1e-3)
         prof = {}
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        # committed PMC profiles: the headline configuration, and the 512 envs a GPU holds at N = 8 (quad-lane kernels)
+        pmc = os.path.join(ROOT, "profiles", "r04_l512_pmc_summary.json" if bs == 512 else "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
@@ -353,7 +354,7 @@ def main():
             except Exception:
                 prof = {}
         pb, pf = prof.get("k_rollout_bwd", {}), prof.get("k_rollout_fwd", {})
-        same_cfg = args.robot == "laikago" and bs == GLOBAL_BS and T == 100  # the committed profile is of this configuration
+        same_cfg = args.robot == "laikago" and bs in (GLOBAL_BS, 512) and T == 100 and args.segw == 0  # a committed profile is of this configuration
         geo_b, geo_f = dm.last_launch_info(1), dm.last_launch_info(0)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
