@@ -1479,3 +1479,56 @@ def test_other_model_constants(name, family, dev, oracle_libs):
     own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)
     print("%s family %d, other constants: own trajectory worst env %.1e" % (name, family, own["worst"].max()))
     assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), own["worst"]
+
+
+def test_reduce_loss_inside_the_launch_on_awkward_tables(dev):
+    """reduce_loss(clip=True) as the launch after the rollout does it (pd_trajloss.h), against the reference's per-env loop
+    (oracle/pose_torch.reduce_loss_loop = dp_utils.py:93-110) on the SAME table, for tables built to be awkward: the first envs without
+    a positive entry (outseq everywhere / NaN targets), every entry out of sequence (the "mean of all entries" branch), one env, a
+    threshold that clips many envs at different frames, 40 frames.  Also the shares: scale = d loss / d table entry (autograd on
+    the loop)."""
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.pose_torch import reduce_loss_loop
+
+    tpl = robots.load_template("laikago")
+    nb = int(tpl["nb"])
+    dm = hip_backend.DeviceModel(tpl)
+    g = torch.Generator().manual_seed(31)
+    cases = [("first envs empty", 12, 6), ("all out of sequence", 5, 4), ("one env", 1, 7), ("many clipped", 40, 8), ("forty frames", 6, 40), ("far first env", 9, 5)]
+    for tag, bs, F in cases:
+        T = F - 1
+        inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=23, steps_per_frame=1, penetration=0.002)
+        t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in FWD}
+        f2s = list(range(F))
+        pos0 = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s)[0]
+        tgt = (pos0.view(F, bs, nb, 7).permute(1, 0, 2, 3) + 0.01 * torch.randn(bs, F, nb, 7, generator=g).to(dev)).contiguous()
+        outseq = torch.zeros(bs, F, dtype=torch.bool, device=dev)
+        if tag == "first envs empty":
+            outseq[0] = True
+            tgt[1] = float("nan")
+            outseq[2, : F - 1] = True
+            tgt[5, 3:, :, :3] += 1.0
+        elif tag == "all out of sequence":
+            outseq[:] = True
+        elif tag == "many clipped":
+            for e in range(1, bs, 2):
+                tgt[e, e % F:, :, :3] += 0.5 + 0.1 * e
+        elif tag == "far first env":
+            tgt[0, :, :, :3] += 2.0       # the threshold comes from env 0's (large) losses: nothing is clipped
+            tgt[4, 2:, :, :3] += 0.7
+        o = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s, target_pos=tgt, outseq=outseq)
+        tl = o[5]
+        table = tl["table"].detach().clone().double().requires_grad_(True)
+        ref = reduce_loss_loop(table.clone(), clip=True)
+        (gref,) = torch.autograd.grad(ref, table, allow_unused=True)
+        gref = torch.zeros_like(table) if gref is None else gref
+        red = tl["reduced"].cpu().numpy()
+        print("%-20s bs=%d F=%d: loss %.6e (loop %.6e) th %.3e positives %d clipped envs %d" % (tag, bs, F, red[0], float(ref), red[1], red[2], red[3]))
+        assert abs(red[0] - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-12, tag
+        assert float((tl["scale"].double() - gref).abs().max()) <= 1e-6 * float(gref.abs().max()) + 1e-12, tag
+        if tag == "all out of sequence":
+            assert red[0] == 0.0 and red[2] == 0
+        if tag == "many clipped":
+            assert red[3] >= 5
+        if tag == "far first env":
+            assert red[3] == 0
