@@ -1532,3 +1532,58 @@ def test_reduce_loss_inside_the_launch_on_awkward_tables(dev):
             assert red[3] >= 5
         if tag == "far first env":
             assert red[3] == 0
+
+
+def test_generic_robot_through_the_loss_and_fk_entries(dev, tmp_path):
+    """The toy robot (free + revolute + compound + fixed joints: the GENERIC kernel instantiation) through the row-f4 entries: the
+    loss table is se3_loss of the gathered poses, the self-seeded adjoint equals the plain adjoint fed the same seeds, the FK chains
+    that ride along are pd_fk_forward / pd_fk_backward's -- for a 6-step rollout and for a zero-step one."""
+    from test_host import OBJ, URDF
+    from diffphys_amd import dp_utils, hip_backend, sim
+    from diffphys_amd.import_urdf import parse_urdf
+    from helpers import build_template
+
+    (tmp_path / "toy.urdf").write_text(URDF)
+    (tmp_path / "tet.obj").write_text(OBJ)
+    b = sim.ModelBuilder()
+    parse_urdf(str(tmp_path / "toy.urdf"), b, xform=sim.transform((0, 0.5, 0), sim.quat_identity()), floating=True, density=1000.0,
+               armature=0.01, stiffness=220.0, damping=2.0, shape_ke=1e4, shape_kd=10.0, shape_kf=1e2, shape_mu=0.7, limit_ke=50.0, limit_kd=1.0)
+    tpl = build_template(b, attach_ke=8000.0, attach_kd=200.0)
+    nb, nq, nqd, bs = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"]), 5
+    dm = hip_backend.DeviceModel(tpl)
+    rng = np.random.RandomState(0)
+    g = torch.Generator().manual_seed(41)
+    for T, f2s in ((6, [0, 3, 6]), (0, [0])):
+        F = len(f2s)
+        q = np.tile(tpl["joint_q"].astype(np.float64), (bs, 1))
+        q[:, 1] = 0.13 + rng.rand(bs) * 0.02
+        q[:, 7:] = rng.uniform(-0.4, 0.4, (bs, nq - 7))
+        mass = np.tile(tpl["body_mass"].astype(np.float64), bs)
+        inertia = np.tile(tpl["body_inertia"].astype(np.float64), (bs, 1, 1))
+        ke = np.tile(np.r_[np.zeros(6), np.full(nqd - 6, 60.0)], bs)
+        inp = dict(q_init=q.reshape(-1), qd_init=rng.randn(bs * nqd) * 0.2, torques=rng.randn(T, bs * nqd) * 0.3, res_f=rng.randn(T, bs * nb, 6) * 0.3,
+                   refs=rng.uniform(-0.3, 0.3, (T, bs * nqd)), target_ke=ke, target_kd=ke * 0.02, body_inv_mass=1 / mass, body_inertia=inertia,
+                   body_inv_inertia=np.linalg.inv(inertia))
+        t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in inp.items()}
+        jq = (t["q_init"].view(1, bs, nq) + 0.05 * torch.randn(3, bs, nq, generator=g).to(dev)).contiguous()
+        jqd = (0.2 * torch.randn(3, bs, nqd, generator=g)).to(dev).contiguous()
+        pos0 = dm.rollout_forward(bs, T, 5e-4, *[t[k] for k in FWD], frame2step=f2s)[0]
+        tgt = (pos0.view(F, bs, nb, 7).permute(1, 0, 2, 3) + 0.02 * torch.randn(bs, F, nb, 7, generator=g).to(dev)).contiguous()
+        o = dm.rollout_forward_traj_loss(bs, T, 5e-4, *[t[k] for k in FWD], frame2step=f2s, target_pos=tgt, fk=(jq, jqd))
+        assert torch.equal(o[0], pos0)
+        want = dp_utils.se3_loss(pos0.view(F, bs, nb, 7).permute(1, 0, 2, 3).contiguous(), tgt).mean(-1)
+        assert float((o[5]["table"] - want).abs().max()) <= 2e-6 * float(want.abs().max())
+        wq, wqd = dm.fk_forward(jq.view(3 * bs, nq), jqd.view(3 * bs, nqd))
+        assert torch.equal(o[5]["fk_body_q"], wq.view(3, bs, nb, 7).permute(1, 0, 2, 3)) and torch.equal(o[5]["fk_body_qd"], wqd.view(3, bs, nb, 6).permute(1, 0, 2, 3))
+        aq, aqd = torch.randn(bs, 3, nb, 7, generator=g).to(dev), torch.randn(bs, 3, nb, 6, generator=g).to(dev)
+        one = torch.ones(1, device=dev)
+        gr = dm.rollout_backward_traj_loss(bs, T, 5e-4, *[t[k] for k in BWD], f2s, o[4], o[5], one, fk=(jq, jqd, aq, aqd))
+        wgq, wgqd = dm.fk_backward(jq.view(3 * bs, nq), jqd.view(3 * bs, nqd), aq.permute(1, 0, 2, 3).contiguous(), aqd.permute(1, 0, 2, 3).contiguous())
+        assert torch.equal(gr["fk_joint_q"].view(3 * bs, nq), wgq) and torch.equal(gr["fk_joint_qd"].view(3 * bs, nqd), wgqd)
+        seeds = (o[5]["seed_pos"].view(F, bs, nb, 7) * (o[5]["scale"].t() / nb)[:, :, None, None]).reshape(F, bs * nb, 7).contiguous()
+        g2 = dm.rollout_backward(bs, T, 5e-4, *[t[k] for k in BWD], f2s, o[4], seeds, torch.zeros(F, bs * nb, 6, device=dev))
+        for k in g2:
+            if g2[k].numel() == 0:   # (the per-step gradients of a zero-step rollout)
+                continue
+            assert bool(torch.isfinite(gr[k]).all()), k
+            assert float((gr[k] - g2[k]).abs().max()) <= 1e-5 * float(g2[k].abs().max()) + 1e-30, (k, T)
