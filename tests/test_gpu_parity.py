@@ -1587,3 +1587,49 @@ def test_generic_robot_through_the_loss_and_fk_entries(dev, tmp_path):
                 continue
             assert bool(torch.isfinite(gr[k]).all()), k
             assert float((gr[k] - g2[k]).abs().max()) <= 1e-5 * float(g2[k].abs().max()) + 1e-30, (k, T)
+
+
+@pytest.mark.parametrize("bs", [64, 2100])
+def test_graph_capture_of_the_fused_iteration(bs, dev):
+    """The row-f4 form of an iteration -- rollout with the loss inside, reduce_loss + FK forward in one launch, seeds + FK backward in
+    one launch, adjoint rollout: four launches -- captured into ONE HIP graph and replayed bit for bit (quad-lane kernels at 64 envs,
+    lane per body at 2100)."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template("laikago")
+    dm = hip_backend.DeviceModel(tpl)
+    T, nb, nq, nqd = 34, 13, 19, 18
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=2, penetration=0.002)
+    t = {k: torch.from_numpy(inp[k]).to(dev) for k in INPUT_NAMES}
+    f2s = list(inp["frame2step"])
+    F = len(f2s)
+    g = torch.Generator().manual_seed(5)
+    pos0 = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s)[0]
+    tgt = (pos0.view(F, bs, nb, 7).permute(1, 0, 2, 3) + 0.02 * torch.randn(bs, F, nb, 7, generator=g).to(dev)).contiguous()
+    jq = (t["q_init"].view(1, bs, nq) + 0.05 * torch.randn(F, bs, nq, generator=g).to(dev)).contiguous()
+    jqd = torch.zeros(F, bs, nqd, device=dev)
+    aq, aqd = torch.randn(bs, F, nb, 7, generator=g).to(dev), torch.randn(bs, F, nb, 6, generator=g).to(dev)
+    gain = torch.full((1,), 0.37, device=dev)
+
+    def run():
+        o = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s, target_pos=tgt, fk=(jq, jqd))
+        gr = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], o[5], gain, fk=(jq, jqd, aq, aqd))
+        return o[0], o[5]["reduced"], o[5]["fk_body_q"], gr["q_init"], gr["refs"], gr["fk_joint_q"]
+
+    ref = [x.clone() for x in run()]
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+        with torch.cuda.graph(graph, stream=side):
+            cap = run()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        for x in cap:
+            x.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(cap, ref))
+    assert float(ref[1][0]) > 0 and float(ref[3].abs().max()) > 0 and float(ref[5].abs().max()) > 0
