@@ -46,7 +46,17 @@ for cfg in (sys.argv[1:] or ["laikago:512", "laikago:4096"]):
         loss, _, _ = dp_model.ForwardWarpTrajLoss.apply(*args, tgt, outseq, h)
         loss.backward()
 
-    for tag, fn, mt in (("raw backend calls", raw, True), ("ForwardWarp autograd", autograd, True), ("ForwardWarpTrajLoss", fused, True),
+    # the raw pair captured in a HIP graph: one host call per iteration
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        raw()
+        with torch.cuda.graph(graph, stream=side):
+            raw()
+    torch.cuda.current_stream().wait_stream(side)
+
+    for tag, fn, mt in (("graph replay (raw pair)", graph.replay, True), ("raw backend calls", raw, True), ("ForwardWarp autograd", autograd, True), ("ForwardWarpTrajLoss", fused, True),
                         ("ForwardWarp, 1 thread", autograd, False), ("TrajLoss, 1 thread", fused, False)):
         torch.autograd.set_multithreading_enabled(mt)   # False: backward runs on the calling thread (no hand-over to the device thread)
         for _ in range(20): fn()
@@ -57,4 +67,4 @@ for cfg in (sys.argv[1:] or ["laikago:512", "laikago:4096"]):
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print("HOST %-8s bs=%-5d %-22s enqueue %.3f ms / iteration, complete %.3f ms / iteration" % (name, bs, tag, (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3), flush=True)
+        print("HOST %-8s bs=%-5d %-24s enqueue %.3f ms / iteration, complete %.3f ms / iteration" % (name, bs, tag, (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3), flush=True)
