@@ -128,6 +128,28 @@ static inline real twist_angle_atan2(v3 axis, real da, real w, real *dq_dda, rea
   if (dq_dda) { *dq_dda = den > (real)0 ? (real)2 * L * w / den : (real)0; *dq_dw = den > (real)0 ? -(real)2 * L * da / den : (real)0; }
   return (real)2 * sgn * R_ATAN2(y, w);
 }
+/* The FIXED joint's angular error (integrator_euler.py:385-390), normalize(r.xyz) * 2 acos(r.w).  Literally (switch 0, default) it is
+ * ill-posed for the quaternions a simulation holds: r = conj(q_p) q_c of fp32-normalised q has |r| = 1 + O(1e-7), and at the joint's operating
+ * point (angle error ~ 0) acos(r.w) turns that norm error into +-9e-4 rad of "angle" (or clamps it to 0) -- in float64 as much as in fp32.
+ * With ref_set_twist_eval(1) it is evaluated as the same function of a unit quaternion in its scale-invariant form
+ *     ang_err = v h,   h = 2 atan2(|v|, w) / |v|   (series of atan(x) / x, x = |v| / w, below x = 1e-2),
+ * with the partials  d ang_err / d v = h I + (h_s / s) v v^T,  d ang_err / d w = v h_w,  h_w = -2 / (|v|^2 + w^2)  -- what the HIP kernels
+ * evaluate (pd_math.h fixed_ang_h).  Returns h; hs_over_s / h_w may be NULL. */
+static inline real fixed_ang_h(v3 v, real w, real *hs_over_s, real *h_w) {
+  const real s2 = vdot(v, v), den = s2 + w * w;
+  real h = (real)0, hss = (real)0;
+  if (w > (real)0 && s2 < (real)1e-4 * w * w) {
+    const real x2 = s2 / (w * w);
+    const real u = (real)1 - x2 * ((real)1 / (real)3 - x2 * ((real)1 / (real)5 - x2 / (real)7));
+    const real upx = -(real)2 / (real)3 + x2 * ((real)4 / (real)5 - x2 * (real)6 / (real)7);   /* u'(x) / x */
+    h = (real)2 * u / w; hss = (real)2 * upx / (w * w * w);
+  } else if (s2 > (real)0) {
+    const real sl = R_SQRT(s2), phi = R_ATAN2(sl, w);
+    h = (real)2 * phi / sl; hss = (real)2 * (w / den - phi / sl) / s2;
+  }
+  if (hs_over_s) { *hs_over_s = hss; *h_w = den > (real)0 ? -(real)2 / den : (real)0; }
+  return h;
+}
 /* Conditioning probe (tests): with this on, ref_rollout_forward rounds every state it stores to fp32 (value kept in `real`).  In
  * the float64 build that is the LEAST any fp32 implementation does to a rollout -- one rounding per state component and step,
  * exact arithmetic otherwise -- so how far the gradients of an env move under it measures how ill-conditioned the env is.
@@ -569,6 +591,7 @@ static void joints_fwd(const RefTemplate *t, const real *body_q, const real *bod
     v3 t_total = V(0, 0, 0), f_total = V(0, 0, 0);
     if (c.ty == JOINT_FIXED) {
       v3 ang_err = vscale(vnormalize(qv(c.r_err)), acos_c(c.r_err.w) * (real)2);
+      if (g_twist_atan2) ang_err = vscale(qv(c.r_err), fixed_ang_h(qv(c.r_err), c.r_err.w, NULL, NULL));
       f_total = vadd(f_total, vadd(vscale(c.x_err, ake), vscale(c.v_err, akd)));
       t_total = vadd(t_total, vadd(vscale(qrot(c.q_p, ang_err), ake), vscale(c.w_err, akd * ads)));
     }
@@ -649,13 +672,22 @@ static void joints_adj(const RefTemplate *t, const real *body_q, const real *bod
       v3 nrm = vnormalize(rv); v3 ang_err = vscale(nrm, ac);
       vacc(&adj_x_err, vscale(adj_f, ake)); vacc(&adj_v_err, vscale(adj_f, akd));
       vacc(&adj_w_err, vscale(adj_t, akd * ads));
+      real hss = 0, h_w = 0, h = 0;
+      if (g_twist_atan2) { h = fixed_ang_h(rv, c.r_err.w, &hss, &h_w); ang_err = vscale(rv, h); }
       v3 adj_ang_err = V(0, 0, 0);
       adj_qrot(c.q_p, ang_err, &adj_q_p, &adj_ang_err, vscale(adj_t, ake));
-      v3 adj_nrm = vscale(adj_ang_err, ac); real adj_ac = vdot(adj_ang_err, nrm);
-      v3 adj_rv = V(0, 0, 0);
-      adj_vnormalize(rv, &adj_rv, adj_nrm);
-      adj_r_err.x += adj_rv.x; adj_r_err.y += adj_rv.y; adj_r_err.z += adj_rv.z;
-      adj_r_err.w += -(real)2 * adj_ac * inv_sqrt_1mx2(c.r_err.w);
+      if (g_twist_atan2) {
+        const real va = vdot(rv, adj_ang_err);
+        adj_r_err.x += adj_ang_err.x * h + rv.x * (va * hss); adj_r_err.y += adj_ang_err.y * h + rv.y * (va * hss);
+        adj_r_err.z += adj_ang_err.z * h + rv.z * (va * hss);
+        adj_r_err.w += va * h_w;
+      } else {
+        v3 adj_nrm = vscale(adj_ang_err, ac); real adj_ac = vdot(adj_ang_err, nrm);
+        v3 adj_rv = V(0, 0, 0);
+        adj_vnormalize(rv, &adj_rv, adj_nrm);
+        adj_r_err.x += adj_rv.x; adj_r_err.y += adj_rv.y; adj_r_err.z += adj_rv.z;
+        adj_r_err.w += -(real)2 * adj_ac * inv_sqrt_1mx2(c.r_err.w);
+      }
     }
     if (c.ty == JOINT_REVOLUTE) {
       v3 axis = ld3(t->axis + i * 3);

@@ -510,7 +510,9 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
   const float ake = m.attach_ke, akd = m.attach_kd, ads = 0.01f;
   v3 t_total = V3(0, 0, 0), f_total = V3(0, 0, 0);
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {  // :385-390
-    v3 ang_err = normalize(qvec(j.r_err)) * (acos_c(j.r_err.w) * 2.0f);
+    float hss_, hw_;
+    const v3 rv = qvec(j.r_err);
+    v3 ang_err = rv * fixed_ang_h(dot(rv, rv), j.r_err.w, hss_, hw_);  // = normalize(rv) * 2 acos(w), scale-invariantly (pd_math.h)
     f_total += j.x_err * ake + j.v_err * akd;
     t_total += qrot(j.q_p, ang_err) * ake + j.w_err * (akd * ads);
   }
@@ -657,15 +659,16 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
   qt adj_r_err = Q4(0, 0, 0, 0), adj_q_p = Q4(0, 0, 0, 0), adj_q_c = Q4(0, 0, 0, 0);
   if ((JT & PD_JT_FIXED) && c.type == PD_JOINT_FIXED) {
     v3 rv = qvec(j.r_err);
-    float ac = acos_c(j.r_err.w) * 2.0f;
-    v3 nrm = normalize(rv), ang_err = nrm * ac;
+    float hss, h_w;
+    const float h = fixed_ang_h(dot(rv, rv), j.r_err.w, hss, h_w);
+    v3 ang_err = rv * h;
     adj_x_err += adj_f * ake; adj_v_err += adj_f * akd; adj_w_err += adj_t * (akd * ads);
     v3 adj_ang_err = V3(0, 0, 0);
     adj_qrot(j.q_p, ang_err, adj_q_p, adj_ang_err, adj_t * ake);
-    v3 adj_rv = V3(0, 0, 0);
-    adj_normalize(rv, adj_rv, adj_ang_err * ac);
+    const float va = dot(rv, adj_ang_err);
+    v3 adj_rv = adj_ang_err * h + rv * (va * hss);
     adj_r_err.x += adj_rv.x; adj_r_err.y += adj_rv.y; adj_r_err.z += adj_rv.z;
-    adj_r_err.w += -2.0f * dot(adj_ang_err, nrm) * inv_sqrt_1mx2(j.r_err.w);
+    adj_r_err.w += va * h_w;
   }
   if ((JT & PD_JT_REVOLUTE) && c.type == PD_JOINT_REVOLUTE) {
     v3 axis_p = qrot(j.q_p, c.axis), axis_c = qrot(s.r, c.axis);

@@ -120,6 +120,26 @@ PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq
   dq_dw = -2.0f * sgn * y * id;
   return 2.0f * sgn * atan2_pos(y, w);
 }
+// The FIXED joint's angular error normalize(v) * 2 acos(w) (integrator_euler.py:385-390) as the same function of a unit quaternion in
+// its scale-invariant form  v h,  h = 2 atan2(|v|, w) / |v|  (series of atan(x) / x below x = |v| / w = 1e-2): r = conj(q_p) q_c of
+// fp32-normalised quaternions has |r| = 1 + O(1e-7), which the literal acos(r.w) turns into +-9e-4 rad of spurious angle at the joint's
+// operating point -- NAMED DEVIATION in evaluation, like twist_angle (both C oracles evaluate it this way with
+// ref_set_twist_eval(1)).  Partials: d(v h)/dv = h I + hs_over_s v v^T,  d(v h)/dw = v h_w.
+PD_DEV float fixed_ang_h(float s2, float w, float &hs_over_s, float &h_w) {
+  const float den = s2 + w * w;
+  float h = 0.0f, hss = 0.0f;
+  if (w > 0.0f && s2 < 1e-4f * w * w) {
+    const float iw = 1.0f / w, x2 = s2 * iw * iw;
+    const float u = 1.0f - x2 * (1.0f / 3.0f - x2 * (1.0f / 5.0f - x2 * (1.0f / 7.0f)));
+    const float upx = -2.0f / 3.0f + x2 * (4.0f / 5.0f - x2 * (6.0f / 7.0f));
+    h = 2.0f * u * iw; hss = 2.0f * upx * iw * iw * iw;
+  } else if (s2 > 0.0f) {
+    const float sl = sqrtf(s2), phi = atan2_pos(sl, w);
+    h = 2.0f * phi / sl; hss = 2.0f * (w / den - phi / sl) / s2;
+  }
+  hs_over_s = hss; h_w = den > 0.0f ? -2.0f / den : 0.0f;
+  return h;
+}
 PD_DEV float twist_angle(float da, float w, float alen) {
   const float y = fabsf(da) * alen;
   return 2.0f * (da < 0.0f ? -1.0f : 1.0f) * atan2_pos(y, w);

@@ -229,25 +229,33 @@ def own_trajectory_check(dm, tpl, inp, dev, hitlog_check=True, abs_floor=0.0):
     traj = dict(states_q=bq.cpu().numpy(), states_qd=bqd.cpu().numpy(), states_f=bf.cpu().numpy())
     mask = mask.cpu().numpy()
     rc = RefC(tpl, np.float64)
-    st = rc.trajectory_state(traj, inp)
-    g64 = rc.rollout_backward_forced(st, inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, pinned_touch=True)
-    errs = grad_env_errors(grads, g64, bs, abs_floor)
-    worst = np.max(np.stack([errs[k] for k in GRAD_LEAD]), axis=0)
-    # conditioning of the adjoint ON THIS FIXED TRAJECTORY: how far the float64 gradients move when every stored fp32 value (state and
-    # total wrench) is replaced by an adjacent fp32 number, all decisions held (two random sign patterns).  No forward pass is re-run, so
-    # no chaos enters: it is what the last stored bit is worth -- the precision at which ANY fp32 evaluation sees the joint gaps
-    # (x_err = a difference of ~0.5 m positions, 1e-5 .. 1e-4 m long on Laikago's 16 kN/m springs)
-    tl = rc.touch_fp32(st, cap=64)
-    cond = np.zeros(bs)
-    for seed in (0, 1):
-        rng = np.random.RandomState(1234 + seed)
-        jit = {}
-        for k, v in traj.items():
-            v = np.asarray(v, np.float32)
-            jit[k] = np.nextafter(v, np.where(rng.rand(*v.shape) < 0.5, -np.inf, np.inf).astype(np.float32))
-        g_j = rc.rollout_backward_forced(rc.trajectory_state(jit, inp), inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, touch_list=tl)
-        e_j = grad_env_errors(g_j, g64, bs, abs_floor)
-        cond = np.maximum(cond, np.max(np.stack([e_j[k] for k in GRAD_LEAD]), axis=0))
+    # A model with FIXED joints: their angular error is evaluated scale-invariantly by the kernels (pd_math.h fixed_ang_h); the float64
+    # reference must do the same (ref_set_twist_eval(1)) -- its literal form turns the fp32 norm error of the stored quaternions into
+    # spurious angles (oracle/ref_c/diffphys_ref.c fixed_ang_h).  For the other joint types the switch changes nothing in float64.
+    has_fixed = 3 in set(int(t) for t in np.asarray(tpl["joint_type"]))
+    rc.set_twist_eval(has_fixed)
+    try:
+        st = rc.trajectory_state(traj, inp)
+        g64 = rc.rollout_backward_forced(st, inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, pinned_touch=True)
+        errs = grad_env_errors(grads, g64, bs, abs_floor)
+        worst = np.max(np.stack([errs[k] for k in GRAD_LEAD]), axis=0)
+        # conditioning of the adjoint ON THIS FIXED TRAJECTORY: how far the float64 gradients move when every stored fp32 value (state and
+        # total wrench) is replaced by an adjacent fp32 number, all decisions held (two random sign patterns).  No forward pass is re-run, so
+        # no chaos enters: it is what the last stored bit is worth -- the precision at which ANY fp32 evaluation sees the joint gaps
+        # (x_err = a difference of ~0.5 m positions, 1e-5 .. 1e-4 m long on Laikago's 16 kN/m springs)
+        tl = rc.touch_fp32(st, cap=64)
+        cond = np.zeros(bs)
+        for seed in (0, 1):
+            rng = np.random.RandomState(1234 + seed)
+            jit = {}
+            for k, v in traj.items():
+                v = np.asarray(v, np.float32)
+                jit[k] = np.nextafter(v, np.where(rng.rand(*v.shape) < 0.5, -np.inf, np.inf).astype(np.float32))
+            g_j = rc.rollout_backward_forced(rc.trajectory_state(jit, inp), inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, touch_list=tl)
+            e_j = grad_env_errors(g_j, g64, bs, abs_floor)
+            cond = np.maximum(cond, np.max(np.stack([e_j[k] for k in GRAD_LEAD]), axis=0))
+    finally:
+        rc.set_twist_eval(False)
     # a plain fp32 evaluation of the same adjoint on the same trajectory with the same decisions: the fp32 build of the C oracle,
     # once with the literal twist angle (2 acos(twist.w): what an fp32 tape of the reference's text does) and once through atan2 (the
     # kernels' evaluation of that function) -- the yardstick for "as accurate as fp32 arithmetic allows"

@@ -453,22 +453,30 @@ def test_generic_joint_kernel_on_toy_robot(dev, oracle_libs, tmp_path):
                adj_pos=rng.randn(3, bs * nb, 7) * 1e-3, adj_vel=rng.randn(3, bs * nb, 6) * 1e-3)
     inp = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inp.items()}
     inp.update(frame2step=[0, 14, 29], nsteps=T, dt=5e-4)
-    out = gpu_rollout(hip_backend.DeviceModel(tpl), inp, dev)
-    rc = RefC(tpl, np.float32)
-    st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
-    gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
+    dm = hip_backend.DeviceModel(tpl)
+    out = gpu_rollout(dm, inp, dev)
+    # The FIXED joint's angular error is evaluated scale-invariantly by the kernels (pd_math.h fixed_ang_h: NAMED DEVIATION in evaluation,
+    # like the revolute twist angle -- the literal normalize(v) * 2 acos(w) turns the 1e-7 norm error of fp32 quaternions into +-9e-4 rad
+    # at the joint's operating point, for ANY evaluator): both C oracles take the same form with set_twist_eval(True).  Rounds 1-3 compared
+    # against the literal fp32 oracle here and had to allow 15 % in the joint forces and medians only in the gradients.
+    from helpers import own_trajectory_check
+
+    rc, rc64 = RefC(tpl, np.float32), RefC(tpl, np.float64)
+    try:
+        rc.set_twist_eval(True); rc64.set_twist_eval(True)
+        st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+        st64 = rc64.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
+    finally:
+        rc.set_twist_eval(False); rc64.set_twist_eval(False)
     assert np.abs(st["grf"]).max() > 5.0 and np.abs(st["jaf"]).max() > 1.0
-    # looser bars than the robots': a FIXED joint's angular error is normalize(tiny) * acos(w ~ 1), which is round-off
-    # dominated in fp32 (the fp32 and fp64 C oracles themselves differ by 3e-3 / 1.4e-2 / 1.2e-2 here)
-    assert relmax(out["wp_pos"], st["wp_pos"]) < 1e-4 and relmax(out["wp_vel"], st["wp_vel"]) < 1e-2
-    assert relmax(out["grf"], st["grf"]) < 2e-2 and relmax(out["jaf"], st["jaf"]) < 0.15  # jaf: FIXED-joint round-off, ~8 N m of 122
+    for k, floor in (("wp_pos", 2e-5), ("wp_vel", 2e-3), ("grf", 5e-3), ("jaf", 5e-3)):
+        e, y = relmax(out[k], st64[k]), relmax(st[k], st64[k])
+        print("toy robot %s: kernels vs float64 %.1e, fp32 oracle vs float64 %.1e" % (k, e, y))
+        assert e < max(floor, 3.0 * y), (k, e, y)
     assert all(np.isfinite(v).all() for v in out["grads"].values())
-    # per-env medians: at its operating point (zero rotation error, w = 1 - O(ulp)) the FIXED joint's acos adjoint is
-    # 1/sqrt(1 - w^2) ~ 3e3 times round-off, so single envs can legitimately disagree wildly in fp32
-    for k in ("q_init", "qd_init", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia"):
-        g, r = out["grads"][k].reshape(bs, -1).astype(np.float64), gr[k].reshape(bs, -1).astype(np.float64)
-        per_env = np.abs(g - r).max(1) / (np.abs(r).max(1) + 1e-12)
-        assert np.median(per_env) < 5e-2, (k, per_env)
+    own = own_trajectory_check(dm, tpl, inp, dev, abs_floor=1e-8)   # (float64 reference in the same scale-invariant form: helpers.py)
+    print("toy robot: own trajectory worst env %.1e, median %.1e (plain fp32: %.1e)" % (own["worst"].max(), np.median(own["worst"]), np.median(own["fp32_atan2"])))
+    assert (own["worst"] <= np.maximum(1e-3, 3.0 * own["fp32_atan2"])).all(), (own["worst"], own["fp32_atan2"])
 
 
 @pytest.mark.gpu
