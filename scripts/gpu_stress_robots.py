@@ -59,7 +59,7 @@ bad = 0
 for r in range(nrob):
     flavour = rng.randint(5)
     kinds = (["rev"], ["cmp"], ["rev", "cmp"], ["rev", "cmp", "fix"], ["rev"])[flavour]
-    rotated = flavour >= 3 and rng.rand() < 0.6
+    rotated = flavour >= 3 and rng.rand() < 0.6   # (flavour 4: revolute-only robots with rotated joint origins and general axes)
     n_joints = int(rng.choice([1, 2, 3, 5, 8, 12, 15, 20, 30, 39]))
     branchy = rng.rand() < 0.7
     path = os.path.join(tmp, "r%d.urdf" % r)
@@ -105,7 +105,7 @@ for r in range(nrob):
     tag = "nb=%-2d joints=%s rot=%d branchy=%d bs=%d T=%-2d" % (nb, "+".join(kinds), rotated, branchy, bs, T)
     try:
         dm = hip_backend.DeviceModel(tpl)
-        fams = [1, 2] if (kinds == ["rev"] and not rotated and nb <= 16) else [0]
+        fams = [1, 2] if (kinds == ["rev"] and nb <= 16) else [0]   # revolute-only, <= 16 bodies: quad-lane eligible (rotated joint origins and general axes included)
         rc32 = RefC(tpl, np.float32)
         try:   # FIXED joints: the scale-invariant evaluation the kernels use (oracle switch; changes nothing in float64 for the others)
             rc32.set_twist_eval(has_fixed); rc64.set_twist_eval(has_fixed)
