@@ -1641,3 +1641,36 @@ def test_graph_capture_of_the_fused_iteration(bs, dev):
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(cap, ref))
     assert float(ref[1][0]) > 0 and float(ref[3].abs().max()) > 0 and float(ref[5].abs().max()) > 0
+
+
+@pytest.mark.parametrize("name,family", [("laikago", 1), ("laikago", 2), ("human", 0)])
+def test_a_nan_env_stays_in_its_lanes(name, family, dev):
+    """Envs share wavefronts (four Laikago envs per body wave, votes and compaction across the wave): an env whose inputs are NaN / inf
+    must not change ANY bit of its neighbours' results, must not hang the speculative sweep, and its own gradients come back scrubbed
+    (NaN -> 0, the boundary's remove_nan)."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    tpl = robots.load_template(name)
+    nb, bs, T = int(tpl["nb"]), 11, 30
+    inp = synth.make_inputs(tpl, name, bs=bs, nsteps=T, seed=24, steps_per_frame=9, penetration=0.003)
+    dm = hip_backend.DeviceModel(tpl)
+    if family:
+        dm.set_kernel_family(family)
+    clean = gpu_rollout(dm, inp, dev)
+    bad = {k: np.array(v, copy=True) if isinstance(v, np.ndarray) else v for k, v in inp.items()}
+    nq, nqd = int(tpl["nq"]), int(tpl["nqd"])
+    bad["q_init"].reshape(bs, nq)[2, 8] = np.nan                 # a joint angle
+    bad["qd_init"].reshape(bs, nqd)[5, 1] = np.inf               # a root velocity
+    bad["refs"].reshape(T, bs, nqd)[7, 6, 9] = np.nan            # a control, from step 7 on
+    bad["body_inv_mass"].reshape(bs, nb)[9, 3] = np.nan
+    out = gpu_rollout(dm, bad, dev)
+    good = [e for e in range(bs) if e not in (2, 5, 6, 9)]
+    F = clean["wp_pos"].shape[0]
+    for k, w in (("wp_pos", 7), ("wp_vel", 6), ("grf", 6), ("jaf", 6)):
+        a, b = clean[k].reshape(F, bs, nb, w)[:, good], out[k].reshape(F, bs, nb, w)[:, good]
+        assert np.array_equal(a, b), k
+    for k, v in out["grads"].items():
+        assert not np.isnan(v).any(), k                            # scrubbed at the stores (inf may remain, as in the reference)
+    per_env = lambda k, v: v.reshape(T, bs, -1).transpose(1, 0, 2).reshape(bs, -1) if k in ("torques", "res_f", "refs") else v.reshape(bs, -1)
+    for k in out["grads"]:
+        assert np.array_equal(per_env(k, clean["grads"][k])[good], per_env(k, out["grads"][k])[good]), k
