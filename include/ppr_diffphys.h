@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 6   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches) */
+#define PD_ABI_VERSION 7   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches); 7: pd_reduce_loss (reduce_loss on any table, threshold from env 0 as the reference takes it), pd_model_set_numeric_policy (the reference's literal acos forms as a run-time mode) */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -86,6 +86,21 @@ int pd_model_get_segment_width(const pd_model *m);
  * pd_model_get_kernel_family returns the setting; *eligible (may be NULL) = 1 when the robot has quad-lane kernels at all. */
 int pd_model_set_kernel_family(pd_model *m, int family);
 int pd_model_get_kernel_family(const pd_model *m, int *eligible);
+
+/* Numeric policy of the rollout launches of this model (ABI v7) -- HOW two expressions of the joint pass are evaluated in fp32, forward
+ * and adjoint, both kernel families; the functions are the same, a float64 evaluation of either policy gives the same numbers:
+ *   PD_NUM_STABLE  (default)  revolute twist angle q = 2 sign(d) atan2(|axis| |d|, r.w), d = r.xyz . axis; FIXED joint's angular error
+ *                  r.xyz * 2 atan2(|r.xyz|, r.w) / |r.xyz| -- accurate to an ulp at joint angle 0 / at the joint's operating point
+ *   PD_NUM_LITERAL the reference's text, diffphys/integrator_euler.py:385-400: twist = normalize((axis d, r.w)), q = 2 acos(twist.w)
+ *                  sign(axis . twist.xyz); FIXED: normalize(r.xyz) * acos(r.w) * 2; adjoints through acos' (0 at |x| = 1, argument clamped
+ *                  to [-1, 1]: the policy of both modes) and the normalisations.  In fp32 acos near 1 turns one ulp of twist.w into 7e-4
+ *                  rad of a small joint angle: use it for a side-by-side run against the reference on Warp,
+ *                  expect it 1e-3 .. 1 away from a float64 evaluation in long-horizon gradients where PD_NUM_STABLE is 1e-5 .. 1e-3.
+ * May be changed between launches; a forward pass and its adjoint must run under the same policy. */
+#define PD_NUM_STABLE 0
+#define PD_NUM_LITERAL 1
+int pd_model_set_numeric_policy(pd_model *m, int policy);
+int pd_model_get_numeric_policy(const pd_model *m);
 
 /* Floats of caller-provided workspace that pd_rollout_forward fills and pd_rollout_backward reads:
  * per step the 13-float body state and the 6-float body wrench as five float4 planes [step][plane][bs*nb], followed
@@ -145,8 +160,9 @@ int pd_rollout_backward(const pd_model *m, int bs, int nsteps, float dt,
  * pose against target_pos_dev [bs][F][nb][7] (p, real-last quaternion), its UNSCALED gradients to seed_pos_dev [F][bs*nb][7] (the
  * layout of adj_pos) and seed_gt_dev [bs][F][nb][7] (d / d target; may be NULL), the mean over the env's bodies to
  * loss_table_dev [bs][F] (0 where outseq_dev [bs][F] bytes are non-zero; outseq_dev may be NULL); then one small launch that does
- * reduce_loss on the table: reduced_dev[4] = { loss_traj, the clip threshold (10 x the lower median of the positive entries of the
- * first env that has any; +inf if none), the number of positive entries left, the number of clipped envs } and scale_dev [bs][F] =
+ * reduce_loss on the table: reduced_dev[4] = { loss_traj, the clip threshold (10 x the lower median of the positive entries of
+ * ENV 0, as the reference takes it, dp_utils.py:98-100; NaN when env 0 has none, and then -- like the reference -- no env is
+ * clipped), the number of positive entries left, the number of clipped envs } and scale_dev [bs][F] =
  * d loss_traj / d table entry (0 for entries the clip / outseq assigned zero).  wp_pos / wp_vel / grf / jaf as pd_rollout_forward.
  * pd_rollout_backward_traj_loss = pd_rollout_backward whose frame seeds are  g_loss_dev[0] * scale[env][frame] / nb * seed_pos
  * (g_loss_dev: DEVICE scalar, the upstream gradient of loss_traj, e.g. traj_wt) PLUS the rows of adj_pos_dev / adj_vel_dev when
@@ -230,6 +246,17 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const flo
  * give loss 0 and zero gradients, like the reference. */
 int pd_se3_loss(int n, int dim, const float *pred_dev, const float *gt_dev, float rot_ratio, float *loss_dev,
                 float *g_pred_dev, float *g_gt_dev, void *stream);
+
+/* reduce_loss of the reference (diffphys/dp_utils.py:93-110) on any [bs][nframes] device table (ABI v7) -- the same one-workgroup code
+ * the trajectory-loss entries run after the rollout, callable on its own (the reference also reduces its other loss terms with it,
+ * dp_model.py:797-809, clip = 0 there).  clip != 0: the threshold is 10 x the lower median (torch.median) of env 0's positive entries,
+ * taken once and used for every env; each env's entries from the first one above it on are ASSIGNED zero IN table_dev (the reference
+ * truncates its argument in place); env 0 without a positive entry: the threshold is NaN and nothing is clipped (what the reference
+ * does on torch >= 1.8: tests/golden/ref_host_reduce_loss.npz holds its outputs).  The value is the mean of the positive entries
+ * left when the sum of all entries is positive, else the mean of all entries (NaN entries make that NaN, as in the reference).
+ * reduced_dev[4] = { value, threshold, positive entries left, clipped envs }; scale_dev [bs][nframes] (may be NULL) = d value /
+ * d entry (0 for assigned entries).  An empty table gives 0. */
+int pd_reduce_loss(int bs, int nframes, float *table_dev, int clip, float *reduced_dev, float *scale_dev, void *stream);
 
 /* SE(3) pose algebra of the loss plumbing, one launch per op and one per vector-Jacobian
  * product; replaces the reference's compositions of dqtorch kernels and torch ops:

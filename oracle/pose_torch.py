@@ -140,18 +140,19 @@ def se3_loss(pred, gt, rot_ratio=0.1):
 
 
 def reduce_loss_loop(loss_seq, clip=False, th=0):
-    """The reference's per-env loop (dp_utils.py:93-110), one host synchronisation per env: the test reference of the product's
-    synchronisation-free reduce_loss and of the one-workgroup kernel behind pd_rollout_forward_traj_loss."""
+    """The reference's per-env loop, control flow as written there (dp_utils.py:93-110), one host synchronisation per env: the test
+    reference of the product's synchronisation-free reduce_loss and of the one-workgroup kernel behind pd_rollout_forward_traj_loss.
+    Pinned by the reference's own outputs (tests/golden/ref_host_reduce_loss.npz, tests/test_ref_fixtures.py).  NB the threshold is
+    taken while ``th == 0`` holds, i.e. at env 0 only: a NaN threshold (env 0 without a positive entry: median of an empty selection)
+    is not 0, is never replaced, and compares false with everything -- no env is clipped then."""
     if clip:
         for i in range(len(loss_seq)):
             if th == 0:
-                sub = loss_seq[i]
-                pos = sub[sub > 0]
-                th = pos.median() * 10 if pos.numel() > 0 else 0
-            if th != 0:
-                over = loss_seq[i] > th
-                if bool(over.any()):
-                    loss_seq[i, int(over.float().argmax()):] = 0
+                row = loss_seq[i]
+                th = row[row > 0].median() * 10
+            hit, at = torch.max(loss_seq[i] > th, 0)  # first exceedance (the first maximal index)
+            if hit == 1:
+                loss_seq[i, at:] = 0
     if loss_seq.sum() > 0:
         return loss_seq[loss_seq > 0].mean()
     return loss_seq.mean()

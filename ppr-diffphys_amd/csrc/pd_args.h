@@ -115,3 +115,10 @@ hipError_t pd_launch_seg64(int kind, int jt, const PdDevModel &m, const void *ar
 hipError_t pd_set_lds_seg16(int jt, int bytes);
 hipError_t pd_set_lds_seg32(int jt, int bytes);
 hipError_t pd_set_lds_seg64(int jt, int bytes);
+// the same launchers of the PD_NUM_LITERAL objects (rollout kinds only; pd_math.h PD_POLICY)
+hipError_t pd_launch_seg16_literal(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);
+hipError_t pd_launch_seg32_literal(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);
+hipError_t pd_launch_seg64_literal(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st);
+hipError_t pd_set_lds_seg16_literal(int jt, int bytes);
+hipError_t pd_set_lds_seg32_literal(int jt, int bytes);
+hipError_t pd_set_lds_seg64_literal(int jt, int bytes);

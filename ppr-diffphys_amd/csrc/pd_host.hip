@@ -27,6 +27,7 @@ struct pd_model {
   // models with at most 16 bodies; null otherwise
   struct Quad { void *blob; PdDevModel dev; size_t lds_tables; int jt; };
   Quad *quad = nullptr;
+  int policy = 0;  // pd_model_set_numeric_policy: PD_NUM_STABLE / PD_NUM_LITERAL (which objects' rollout kernels a launch takes)
   int family = 0;  // pd_model_set_kernel_family: 0 automatic (by batch size), 1 lane per body always, 2 quad-lane wherever eligible
   void *blob = nullptr;
   PdDevModel dev{};
@@ -275,6 +276,8 @@ static int build_device(pd_model *m, int segw) {
   int &attr = dev_id < PD_MAX_DEVICES ? g_lds_attr[dev_id][segw == 16 ? 0 : (segw == 32 ? 1 : 2)][jt_slot(jt)] : uncached;
   if (lds_max > attr) {
     hipError_t ea = segw == 16 ? pd_set_lds_seg16(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32(jt, lds_max) : pd_set_lds_seg64(jt, lds_max));
+    if (ea == hipSuccess)  // ... and on the PD_NUM_LITERAL kernels, whichever policy the model runs under now
+      ea = segw == 16 ? pd_set_lds_seg16_literal(jt, lds_max) : (segw == 32 ? pd_set_lds_seg32_literal(jt, lds_max) : pd_set_lds_seg64_literal(jt, lds_max));
     if (ea != hipSuccess) return hip_fail(ea, "hipFuncSetAttribute(LDS)");
     attr = lds_max;
   }
@@ -364,13 +367,18 @@ static hipError_t launch(const pd_model *m, int kind, const void *args, int n_en
     if (c.nblocks == 0) return hipSuccess;
     int *ll = const_cast<pd_model *>(m)->last_launch[kind];
     ll[0] = c.nblocks; ll[1] = c.threads; ll[2] = (int)c.lds; ll[3] = c.groups;
-    return pd_launch_seg64(kind, m->quad->jt, d, args, c, st);
+    return (m->policy == PD_NUM_LITERAL ? pd_launch_seg64_literal : pd_launch_seg64)(kind, m->quad->jt, d, args, c, st);
   }
   const PdLaunchCfg c = launch_cfg(m, kind, n_envs);
   if (c.nblocks == 0) return hipSuccess;
   if (kind < 2) {
     int *ll = const_cast<pd_model *>(m)->last_launch[kind];
     ll[0] = c.nblocks; ll[1] = c.threads; ll[2] = (int)c.lds; ll[3] = c.groups * (64 / m->segw);
+  }
+  if (m->policy == PD_NUM_LITERAL && kind <= PD_K_ROLLOUT_BWD) {  // (FK evaluates no joint force: one copy of those kernels)
+    if (m->segw == 16) return pd_launch_seg16_literal(kind, m->jt, m->dev, args, c, st);
+    if (m->segw == 32) return pd_launch_seg32_literal(kind, m->jt, m->dev, args, c, st);
+    return pd_launch_seg64_literal(kind, m->jt, m->dev, args, c, st);
   }
   if (m->segw == 16) return pd_launch_seg16(kind, m->jt, m->dev, args, c, st);
   if (m->segw == 32) return pd_launch_seg32(kind, m->jt, m->dev, args, c, st);
@@ -492,6 +500,13 @@ int pd_model_get_kernel_family(const pd_model *m, int *eligible) {
   if (eligible) *eligible = (m && m->quad) ? 1 : 0;
   return m ? m->family : 0;
 }
+int pd_model_set_numeric_policy(pd_model *m, int policy) {
+  if (!m) return fail("null model");
+  if (policy != PD_NUM_STABLE && policy != PD_NUM_LITERAL) return fail("numeric policy: PD_NUM_STABLE (0) or PD_NUM_LITERAL (1)");
+  m->policy = policy;
+  return 0;
+}
+int pd_model_get_numeric_policy(const pd_model *m) { return m ? m->policy : 0; }
 int pd_model_get_segment_width(const pd_model *m) { return m ? m->segw : 0; }
 
 int pd_model_bind_joint_X_p(pd_model *m, const float *joint_X_p_dev, int n_envs) {
@@ -558,7 +573,7 @@ static int reduce_launch(const pd_model *m, int bs, int nframes, const float *ta
   if (!fk || fk->n == 0) return pd_traj_loss_reduce_launch(bs, nframes, table, reduced, scale, st) ? fail("trajectory-loss reduction launch failed") : 0;
   ReduceFkArgs a{};
   a.fk = fk_ride_args(fk);
-  a.red = TrajReduceArgs{bs, nframes, table, reduced, scale};
+  a.red = TrajReduceArgs{bs, nframes, table, reduced, scale, 1, nullptr};
   const size_t bytes = (size_t)bs * nframes * sizeof(float);
   a.in_lds = bytes <= std::min((size_t)PD_REDUCE_LDS_BYTES, m->lds_max) ? 1 : 0;
   hipError_t e = launch_ride(m, PD_K_REDUCE_FK, &a, fk->n, 1, a.in_lds ? bytes : 0, st);

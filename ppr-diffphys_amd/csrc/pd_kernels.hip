@@ -10,6 +10,19 @@
 #include "pd_se3.h"
 #include "pd_quad.h"
 
+// This file is compiled once per segment width AND per numeric policy (pd_math.h PD_POLICY; Makefile).  The PD_NUM_LITERAL objects carry
+// the rollout kernels only, under their own names (the FK kernels evaluate no joint force: one copy serves both policies).
+#if PD_POLICY == 1
+#define k_rollout_fwd k_rollout_fwd_literal
+#define k_rollout_bwd k_rollout_bwd_literal
+#define k_rollout_bwd3 k_rollout_bwd3_literal
+#define PD_LAUNCH_NAME(w) PD_CAT(PD_CAT(pd_launch_seg, w), _literal)
+#define PD_SET_LDS_NAME(w) PD_CAT(PD_CAT(pd_set_lds_seg, w), _literal)
+#else
+#define PD_LAUNCH_NAME(w) PD_CAT(pd_launch_seg, w)
+#define PD_SET_LDS_NAME(w) PD_CAT(pd_set_lds_seg, w)
+#endif
+
 // In-kernel phase stamps (diagnostic build only, never in the shipped library): cdna_hip_programming.md section 7.
 #ifdef PD_STAMPS
 #define STAMP_DECL unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = pd_memtime()
@@ -2550,6 +2563,7 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
         hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
       }
       break;
+#if PD_POLICY == 0  // (the host routes the FK kinds to these launchers whatever the model's policy)
     case PD_K_FK_FWD:
       hipLaunchKernelGGL((k_fk<PD_SEGW, JT, false>), g, t, lds, st, m, *(const FkArgs *)args);
       break;
@@ -2562,6 +2576,7 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
     case PD_K_SEEDS_FK:
       hipLaunchKernelGGL((k_seeds_fk<PD_SEGW, JT>), g, t, lds, st, m, *(const SeedsFkArgs *)args);
       break;
+#endif
     default:
       return hipErrorInvalidValue;
   }
@@ -2594,19 +2609,23 @@ static hipError_t set_lds_jt(int bytes) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
 #endif
   }
+#if PD_POLICY == 0
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_reduce_fk<PD_SEGW, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if ((e = hipFuncSetAttribute((const void *)k_seeds_fk<PD_SEGW, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   return hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#else
+  return hipSuccess;
+#endif
 }
 
 // jt: PD_JT_REVOLUTE only, PD_JT_COMPOUND only, anything else -> generic (all joint types)
-hipError_t PD_CAT(pd_launch_seg, PD_SEGW)(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st) {
+hipError_t PD_LAUNCH_NAME(PD_SEGW)(int kind, int jt, const PdDevModel &m, const void *args, const PdLaunchCfg &cfg, hipStream_t st) {
   if (jt == PD_JT_REVOLUTE) return launch_jt<PD_JT_REVOLUTE>(kind, m, args, cfg, st);
   if (jt == PD_JT_COMPOUND) return launch_jt<PD_JT_COMPOUND>(kind, m, args, cfg, st);
   return launch_jt<PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED>(kind, m, args, cfg, st);
 }
-hipError_t PD_CAT(pd_set_lds_seg, PD_SEGW)(int jt, int bytes) {
+hipError_t PD_SET_LDS_NAME(PD_SEGW)(int jt, int bytes) {
   if (jt == PD_JT_REVOLUTE) return set_lds_jt<PD_JT_REVOLUTE>(bytes);
   if (jt == PD_JT_COMPOUND) return set_lds_jt<PD_JT_COMPOUND>(bytes);
   return set_lds_jt<PD_JT_REVOLUTE | PD_JT_COMPOUND | PD_JT_FIXED>(bytes);

@@ -55,20 +55,36 @@ __global__ __launch_bounds__(1024) void k_traj_loss_reduce(TrajReduceArgs r) {
 __global__ __launch_bounds__(256) void k_traj_seeds(TrajSeedsArgs s) { traj_seeds_block(s, blockIdx.x); }
 }  // namespace
 
-extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(int bs, int nframes, const float *table, float *reduced, float *scale, hipStream_t st) {
-  if (bs < 0 || nframes < 0 || !reduced) return 1;
-  if ((size_t)bs * nframes > 0 && (!table || !scale)) return 1;
-  const TrajReduceArgs r{bs, nframes, table, reduced, scale};
-  const size_t bytes = (size_t)bs * nframes * sizeof(float);
+static int reduce_launch_impl(const TrajReduceArgs &r, hipStream_t st) {
+  const size_t bytes = (size_t)r.bs * r.F * sizeof(float);
   if (bytes <= PD_REDUCE_LDS_BYTES) {
-    static const hipError_t attr = hipFuncSetAttribute((const void *)k_traj_loss_reduce<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       PD_REDUCE_LDS_BYTES);
-    if (attr != hipSuccess) return 2;
+    // the attribute is PER DEVICE: a process that uses a second GPU must raise it there too (a 4096 x 4 table is already 64 KiB)
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev >= 64 || !done[dev]) {
+      if (hipFuncSetAttribute((const void *)k_traj_loss_reduce<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PD_REDUCE_LDS_BYTES) != hipSuccess) return 2;
+      if (dev < 64) done[dev] = true;
+    }
     hipLaunchKernelGGL(k_traj_loss_reduce<true>, dim3(1), dim3(1024), bytes, st, r);
   } else {
     hipLaunchKernelGGL(k_traj_loss_reduce<false>, dim3(1), dim3(1024), 0, st, r);
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(int bs, int nframes, const float *table, float *reduced, float *scale, hipStream_t st) {
+  if (bs < 0 || nframes < 0 || !reduced) return 1;
+  if ((size_t)bs * nframes > 0 && (!table || !scale)) return 1;
+  return reduce_launch_impl(TrajReduceArgs{bs, nframes, table, reduced, scale, 1, nullptr}, st);
+}
+
+// reduce_loss of the reference (diffphys/dp_utils.py:93-110) on ANY [bs][F] device table, as its own entry: the same one-workgroup code
+// the rollout's trajectory-loss path runs, with the reference's in-place truncation of its argument.
+extern "C" int pd_reduce_loss(int bs, int nframes, float *table_dev, int clip, float *reduced_dev, float *scale_dev, void *stream) {
+  if (bs < 0 || nframes < 0 || !reduced_dev) return 1;
+  if ((size_t)bs * nframes > 0 && !table_dev) return 1;
+  return reduce_launch_impl(TrajReduceArgs{bs, nframes, table_dev, reduced_dev, scale_dev, clip ? 1 : 0, clip ? table_dev : nullptr}, (hipStream_t)stream);
 }
 
 extern "C" __attribute__((visibility("hidden"))) int pd_traj_seeds_launch(int bs, int nb, int nframes, const float *seed_pos, const float *scale, const float *gain,

@@ -9,6 +9,14 @@
 #include <hip/hip_runtime.h>
 
 #define PD_DEV __device__ __forceinline__
+// Numeric policy of this translation unit (pd_model_set_numeric_policy, include/ppr_diffphys.h): the kernel file is compiled once per
+// policy and the host picks the launchers at run time.  0 = PD_NUM_STABLE (default): the revolute twist angle through atan2 and the
+// FIXED joint's angular error scale-invariantly -- the same functions as the reference's, well-conditioned in fp32.  1 = PD_NUM_LITERAL:
+// the reference's text, 2 acos(twist.w) sign(..) and normalize(v) 2 acos(w) (integrator_euler.py:385-400), for side-by-side runs
+// against Warp.  Nothing else differs between the two.
+#ifndef PD_POLICY
+#define PD_POLICY 0
+#endif
 
 struct v3 { float x, y, z; };
 struct qt { float x, y, z, w; };
@@ -104,11 +112,11 @@ PD_DEV float atan2_pos(float y, float x) {
   return (x != x || y != y) ? x + y : r;
 }
 PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq_dw) {
-#ifdef PD_AB_ACOS  // A/B timing only: the literal form (normalise, acos, guarded derivative)
-  {
+#if PD_POLICY == 1  // the reference's text: twist = normalize((axis da, w)), q = 2 acos(twist.w) sign(axis . twist.xyz); adjoint through
+  {                              // acos' (guarded: 0 at |twist.w| = 1) and the normalisation
     const float y0 = da * alen, n2 = w * w + y0 * y0, il = 1.0f / sqrtf(n2), tw = w * il, sg = da < 0.0f ? -1.0f : 1.0f;
-    const float q0 = acosf(clampf(tw, -1.0f, 1.0f)) * 2.0f * sg;
-    const float sq = sqrtf(1.0f - tw * tw), dq = sq > 0.0f ? -2.0f * sg / sq : 0.0f;
+    const float q0 = acos_c(tw) * 2.0f * sg;
+    const float dq = -2.0f * sg * inv_sqrt_1mx2(tw);
     dq_dw = dq * (il - w * w * il * il * il);
     dq_dda = dq * (-w * y0 * alen * il * il * il);
     return q0;
@@ -126,6 +134,13 @@ PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq
 // operating point -- NAMED DEVIATION in evaluation, like twist_angle (both C oracles evaluate it this way with
 // ref_set_twist_eval(1)).  Partials: d(v h)/dv = h I + hs_over_s v v^T,  d(v h)/dw = v h_w.
 PD_DEV float fixed_ang_h(float s2, float w, float &hs_over_s, float &h_w) {
+#if PD_POLICY == 1  // the reference's text: normalize(v) * acos(w) * 2 (normalize(0) = 0), adjoint through acos' (guarded) and normalize
+  {
+    const float sl = sqrtf(s2), isl = sl > 0.0f ? 1.0f / sl : 0.0f, h0 = 2.0f * acos_c(w) * isl;
+    hs_over_s = -h0 * isl * isl; h_w = -2.0f * inv_sqrt_1mx2(w) * isl;
+    return h0;
+  }
+#endif
   const float den = s2 + w * w;
   float h = 0.0f, hss = 0.0f;
   if (w > 0.0f && s2 < 1e-4f * w * w) {
@@ -141,6 +156,9 @@ PD_DEV float fixed_ang_h(float s2, float w, float &hs_over_s, float &h_w) {
   return h;
 }
 PD_DEV float twist_angle(float da, float w, float alen) {
+#if PD_POLICY == 1
+  { const float y0 = da * alen; return acos_c(w * (1.0f / sqrtf(w * w + y0 * y0))) * 2.0f * (da < 0.0f ? -1.0f : 1.0f); }
+#endif
   const float y = fabsf(da) * alen;
   return 2.0f * (da < 0.0f ? -1.0f : 1.0f) * atan2_pos(y, w);
 }

@@ -6,7 +6,9 @@
 struct TrajReduceArgs {
   int bs, F;
   const float *table;      // [bs][F] per-frame losses the rollout kernel wrote
-  float *reduced, *scale;  // [4], [bs][F]
+  float *reduced, *scale;  // [4], [bs][F] (scale may be null)
+  int clip;                // reduce_loss(clip=...): 1 on the rollout's path (dp_model.py:779)
+  float *table_after;      // null, or where the table goes after the clip's assignments (the reference truncates its argument in place)
 };
 struct TrajSeedsArgs {
   int bs, nb, F;
@@ -17,7 +19,7 @@ struct TrajSeedsArgs {
 
 // ---- reduce_loss(loss_traj, clip=True) of the reference (diffphys/dp_utils.py:93-110) on the [bs][F] table the rollout kernel wrote
 // (k_rollout_fwd<..., LOSS>), ONE workgroup, and each entry's share of the result -- what the adjoint rollout scales its seeds with:
-//   th        10 x the (lower, like torch.median) median of the positive entries of the first env that has any; none: +inf
+//   th        10 x the (lower, like torch.median) median of the positive entries of ENV 0; env 0 has none: NaN, and nothing is clipped
 //   clipping  per env, entries from the first one above th on are ASSIGNED zero (loss_seq[i, clip_idx:] = 0)
 //   value     mean of the positive entries left when their sum is positive, else the mean of all entries
 //   scale     0 for an assigned-zero entry; else 1 / N_pos for a positive entry (0 for the others) or 1 / (bs F) in the "else" case
@@ -28,15 +30,14 @@ struct TrajSeedsArgs {
 template <bool IN_LDS>
 __device__ __forceinline__ void traj_loss_reduce_block(const TrajReduceArgs &r, float *s_tab) {  // one workgroup (any multiple of 64 threads up to 1024)
   const int bs = r.bs, F = r.F;
-  const float *__restrict__ table = r.table;
+  const float *table = r.table;  // (pd_reduce_loss truncates it in place: no restrict)
   float *__restrict__ reduced = r.reduced, *__restrict__ scale = r.scale;
-  __shared__ int s_first;
   __shared__ float s_med;
   __shared__ double s_sum[16], s_tot[16];
   __shared__ int s_cnt[16], s_clip[16];
   const int tid = threadIdx.x, NT = blockDim.x;
   const size_t n_all = (size_t)bs * F;
-  if (tid == 0) { s_first = bs; s_med = 0.f; }
+  if (tid == 0) s_med = 0.f;
   if (IN_LDS) {  // sixteen loads in flight per thread (one at a time: a memory latency each, 16 of them at 4096 x 4)
     for (size_t i0 = tid; i0 < n_all; i0 += (size_t)16 * NT) {
       float v[16];
@@ -48,37 +49,26 @@ __device__ __forceinline__ void traj_loss_reduce_block(const TrajReduceArgs &r, 
   }
   __syncthreads();
   auto tab = [&](size_t i) { return IN_LDS ? s_tab[i] : table[i]; };
-  {  // the first env with a positive entry: minimum per thread, per wave, then one LDS atomic per wave (one per env with positives
-     // is thousands of atomics on one word)
-    int mine = bs;
-    for (int e = tid; e < bs && mine == bs; e += NT) {
-      bool has = false;
-      for (int f = 0; f < F; ++f) has |= tab((size_t)e * F + f) > 0.f;
-      if (has) mine = e;
-    }
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) { const int o = __shfl_xor(mine, w); mine = o < mine ? o : mine; }
-    if ((tid & 63) == 0 && mine < bs) atomicMin(&s_first, mine);
-  }
-  __syncthreads();
-  const int first = s_first;
-  float th = __builtin_inff();
-  if (first < bs) {  // lower median of the row's positive entries by rank counting (ties broken by index: ranks are distinct)
-    const size_t row = (size_t)first * F;
+  // the threshold comes from env 0 ALONE (the reference computes it at i == 0 and never again, dp_utils.py:98-100): 10 x the lower
+  // median (torch.median) of env 0's positive entries by rank counting (ties broken by index: ranks are distinct).  Env 0 without a
+  // positive entry: the reference's median of an empty selection is NaN (torch >= 1.8; tests/golden/ref_host_reduce_loss.npz holds what
+  // it returned), `th == 0` is never true again and `loss > NaN` is false: NOTHING is clipped in the whole batch.  Same here.
+  float th = __builtin_nanf("");  // clip == 0: stays NaN, nothing exceeds it
+  if (bs > 0 && r.clip) {
     int np = 0;
-    for (int j = 0; j < F; ++j) np += tab(row + j) > 0.f;
+    for (int j = 0; j < F; ++j) np += tab(j) > 0.f;
     for (int i = tid; i < F; i += NT) {
-      const float v = tab(row + i);
+      const float v = tab(i);
       if (!(v > 0.f)) continue;
       int rank = 0;
       for (int j = 0; j < F; ++j) {
-        const float u = tab(row + j);
+        const float u = tab(j);
         rank += (u > 0.f) && (u < v || (u == v && j < i));
       }
       if (rank == (np - 1) / 2) s_med = v;
     }
     __syncthreads();
-    th = s_med * 10.f;
+    if (np > 0) th = s_med * 10.f;
   }
   // per env: first exceedance, then the sums over what is left
   double sum = 0.0, tot = 0.0;
@@ -116,18 +106,20 @@ __device__ __forceinline__ void traj_loss_reduce_block(const TrajReduceArgs &r, 
       for (int f = 0; f < F; ++f) {
         const float v = s_tab[(size_t)e * F + f];
         if (!cut && v > th) cut = true;
+        if (r.table_after) r.table_after[(size_t)e * F + f] = cut ? 0.f : v;  // (standalone pd_reduce_loss only: small tables)
         s_tab[(size_t)e * F + f] = cut ? 0.f : (pos_case ? (v > 0.f ? share_pos : 0.f) : share_all);
       }
     }
     __syncthreads();
-    for (size_t i = tid; i < n_all; i += NT) scale[i] = s_tab[i];
+    if (scale) for (size_t i = tid; i < n_all; i += NT) scale[i] = s_tab[i];
   } else {
     for (int e = tid; e < bs; e += NT) {
       bool cut = false;
       for (int f = 0; f < F; ++f) {
         const float v = table[(size_t)e * F + f];
         if (!cut && v > th) cut = true;
-        scale[(size_t)e * F + f] = cut ? 0.f : (pos_case ? (v > 0.f ? share_pos : 0.f) : share_all);
+        if (scale) scale[(size_t)e * F + f] = cut ? 0.f : (pos_case ? (v > 0.f ? share_pos : 0.f) : share_all);
+        if (r.table_after) r.table_after[(size_t)e * F + f] = cut ? 0.f : v;
       }
     }
   }

@@ -70,23 +70,26 @@ def rotate_frame_vel(global_q, target_qd):
 
 
 def reduce_loss(loss_seq, clip=False, th=0):
-    """(bs,T) -> scalar; with clip, a rollout's loss is zeroed from the first step that exceeds the threshold on -- the
-    threshold being 10x the median of the positive entries of the FIRST env that has any (the reference computes it once
-    and reuses it for every env)   dp_utils.py:93-110.  Same values and in-place effect as the reference's per-env loop,
-    without its host synchronisations (~4 per env and iteration)."""
-    if clip:
-        pos = loss_seq > 0
-        if not torch.is_tensor(th) and th == 0:
-            has = pos.any(1)
-            row = loss_seq.index_select(0, has.float().argmax().reshape(1))[0]
-            rp = row > 0
-            srt = torch.where(rp, row, torch.full_like(row, float("inf"))).sort().values
-            med = srt.gather(0, ((rp.sum() - 1).clamp(min=0) // 2).reshape(1))[0]  # torch.median: the lower one
-            th = torch.where(has.any(), med * 10, torch.full_like(med, float("inf"))).detach()
+    """(bs,T) -> scalar; with clip, a rollout's loss is zeroed (in place) from the first step that exceeds the threshold on -- the
+    threshold being 10x the median of the positive entries of ENV 0: the reference computes it at i == 0 and reuses it for every env
+    (dp_utils.py:93-110).  When env 0 has no positive entry the reference's median of an empty selection is NaN, ``th == 0`` is never
+    true again and ``loss > NaN`` is false: nothing is clipped in the whole batch -- reproduced here (held to the reference's own outputs,
+    tests/golden/ref_host_reduce_loss.npz).  Same values and in-place effect as the reference's per-env loop without its host
+    synchronisations (~4 per env and iteration)."""
+    if clip and loss_seq.shape[0] > 0:
+        row = loss_seq.detach()[0]
+        rp = row > 0
+        srt = torch.where(rp, row, torch.full_like(row, float("inf"))).sort().values
+        med = srt.gather(0, ((rp.sum() - 1).clamp(min=0) // 2).reshape(1))[0]  # torch.median: the lower one
+        th0 = torch.where(rp.any(), med * 10, torch.full_like(med, float("nan")))
+        if torch.is_tensor(th):
+            th = torch.where(th.detach().to(th0) == 0, th0, th.detach().to(th0))
+        elif th == 0:
+            th = th0
         keep = (loss_seq.detach() > th).cumsum(1) == 0
         loss_seq.masked_fill_(~keep, 0)  # assignment like the reference's loss_seq[i, idx:] = 0: an inf / NaN past the clip is zeroed, not 0 * inf
     pos = loss_seq > 0
-    mean_pos = (loss_seq * pos).sum() / pos.sum().clamp(min=1)
+    mean_pos = torch.where(pos, loss_seq, torch.zeros_like(loss_seq)).sum() / pos.sum().clamp(min=1)
     return torch.where(loss_seq.sum() > 0, mean_pos, loss_seq.mean())
 
 

@@ -14,7 +14,8 @@ import torch
 _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpprdiffphys_hip.so")
 _lib = None
 
-ABI_VERSION = 6  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+NUM_STABLE, NUM_LITERAL = 0, 1  # PD_NUM_* of include/ppr_diffphys.h (DeviceModel.set_numeric_policy)
+ABI_VERSION = 7  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -61,6 +62,8 @@ def lib():
         if hasattr(L, "pd_model_set_kernel_family"):
             L.pd_model_set_kernel_family.argtypes = [ctypes.c_void_p, ctypes.c_int]
             L.pd_model_get_kernel_family.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        L.pd_model_set_numeric_policy.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.pd_model_get_numeric_policy.argtypes = [ctypes.c_void_p]
         L.pd_last_kernel_ms.restype = ctypes.c_float
         L.pd_last_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.pd_model_set_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -80,6 +83,7 @@ def lib():
         L.pd_fk_forward.argtypes = [vp, ci] + [vp] * 4 + [vp]
         L.pd_fk_backward.argtypes = [vp, ci] + [vp] * 6 + [vp]
         L.pd_se3_loss.argtypes = [ci, ci, vp, vp, cf, vp, vp, vp, vp]
+        L.pd_reduce_loss.argtypes = [ci, ci, vp, ci, vp, vp, vp]
         L.pd_pose_op.argtypes = [ci, ci, vp, ci, vp, vp, vp]
         L.pd_pose_op_vjp.argtypes = [ci, ci, vp, ci, vp, vp, vp, vp, vp]
         L.pd_foot_height.argtypes = [ci, ci, ci] + [vp] * 6 + [vp]
@@ -204,6 +208,14 @@ class DeviceModel:
     def set_kernel_family(self, family):
         """0 automatic (by batch size), 1 lane per body always, 2 quad-lane (four lanes per body) wherever the robot is eligible."""
         _check(lib().pd_model_set_kernel_family(self.h, int(family)))
+
+    def set_numeric_policy(self, policy):
+        """NUM_STABLE (default) / NUM_LITERAL: how the revolute twist angle and the FIXED joint's angular error are evaluated by the rollout
+        launches (``pd_model_set_numeric_policy``; LITERAL = the reference's acos forms, for side-by-side runs against Warp)."""
+        _check(lib().pd_model_set_numeric_policy(self.h, int(policy)))
+
+    def numeric_policy(self):
+        return int(lib().pd_model_get_numeric_policy(self.h))
 
     def kernel_family(self):
         """(setting, eligible): eligible = the robot has quad-lane kernels (revolute-only, at most 16 bodies)."""
@@ -470,6 +482,22 @@ def se3_loss(pred, gt, rot_ratio, want_grads=True):
     if rc != 0:
         raise RuntimeError("pd_se3_loss failed (rc %d)" % rc)
     return loss, gp, gg
+
+
+def reduce_loss(table, clip=False, want_scale=True):
+    """reduce_loss of the reference (dp_utils.py:93-110) as ONE one-workgroup launch (``pd_reduce_loss``) on a float32 GPU table
+    (bs, F): with clip the table is truncated IN PLACE like the reference's argument.  Returns reduced [4] = (value, threshold, positive
+    entries left, clipped envs) and scale (bs, F) = d value / d entry (None unless want_scale)."""
+    if table.dim() != 2:
+        raise ValueError("reduce_loss: a (bs, F) table; got %s" % (tuple(table.shape),))
+    bs, F = table.shape
+    reduced = torch.empty(4, device=table.device, dtype=torch.float32)
+    scale = torch.empty_like(table) if want_scale else None
+    rc = lib().pd_reduce_loss(bs, F, _dev(table, "table") if table.numel() else ctypes.c_void_p(0), 1 if clip else 0, _dev(reduced, "reduced"),
+                              _dev(scale, "scale") if want_scale and table.numel() else ctypes.c_void_p(0), _stream())
+    if rc != 0:
+        raise RuntimeError("pd_reduce_loss failed (rc %d)" % rc)
+    return reduced, scale
 
 
 POSE_COMPOSE_DELTA, POSE_ROTATE_FRAME, POSE_ROTATE_VEL = 0, 1, 2

@@ -205,7 +205,7 @@ def oracle_bundle(tpl, inp, bs):
     return dict(rc64=rc64, st64=st64, g64=g64, st32=st32, g32=g32, cond=e_round, cond_fp32=np.maximum(worst(g32), e_round), e_round=e_round)
 
 
-def own_trajectory_check(dm, tpl, inp, dev, hitlog_check=True, abs_floor=0.0):
+def own_trajectory_check(dm, tpl, inp, dev, hitlog_check=True, abs_floor=0.0, literal=False):
     """The airtight gradient comparison: the kernel's gradients against the float64 C oracle's adjoint OF THE
     KERNEL'S OWN saved trajectory -- same linearisation point, so the chaos of a 100-step rollout is not in the comparison -- with the
     kernel's discrete decisions: its stored velocity-clamp masks, and "this candidate touches" by its pinned fp32 height test
@@ -232,8 +232,9 @@ def own_trajectory_check(dm, tpl, inp, dev, hitlog_check=True, abs_floor=0.0):
     # A model with FIXED joints: their angular error is evaluated scale-invariantly by the kernels (pd_math.h fixed_ang_h); the float64
     # reference must do the same (ref_set_twist_eval(1)) -- its literal form turns the fp32 norm error of the stored quaternions into
     # spurious angles (oracle/ref_c/diffphys_ref.c fixed_ang_h).  For the other joint types the switch changes nothing in float64.
+    # literal=True: the device model runs under PD_NUM_LITERAL -- the kernels evaluate the reference's text, so the float64 reference does too
     has_fixed = 3 in set(int(t) for t in np.asarray(tpl["joint_type"]))
-    rc.set_twist_eval(has_fixed)
+    rc.set_twist_eval(has_fixed and not literal)
     try:
         st = rc.trajectory_state(traj, inp)
         g64 = rc.rollout_backward_forced(st, inp["adj_pos"], inp["adj_vel"], clamp_mask=mask, pinned_touch=True)

@@ -1491,8 +1491,10 @@ def test_other_model_constants(name, family, dev, oracle_libs):
 
 def test_reduce_loss_inside_the_launch_on_awkward_tables(dev):
     """reduce_loss(clip=True) as the launch after the rollout does it (pd_trajloss.h), against the reference's per-env loop
-    (oracle/pose_torch.reduce_loss_loop = dp_utils.py:93-110) on the SAME table, for tables built to be awkward: the first envs without
-    a positive entry (outseq everywhere / NaN targets), every entry out of sequence (the "mean of all entries" branch), one env, a
+    (oracle/pose_torch.reduce_loss_loop = dp_utils.py:93-110, itself held to the reference's own outputs in tests/test_ref_fixtures.py)
+    on the SAME table, for tables built to be awkward: env 0 without a positive entry (outseq everywhere / NaN targets: the reference's
+    threshold is then NaN and NOTHING is clipped in the whole batch, however large another env's loss), the same batch with env 0 in
+    sequence (then that env IS clipped), every entry out of sequence (the "mean of all entries" branch), one env, a
     threshold that clips many envs at different frames, 40 frames.  Also the shares: scale = d loss / d table entry (autograd on
     the loop)."""
     from diffphys_amd import hip_backend, robots, synth
@@ -1502,7 +1504,7 @@ def test_reduce_loss_inside_the_launch_on_awkward_tables(dev):
     nb = int(tpl["nb"])
     dm = hip_backend.DeviceModel(tpl)
     g = torch.Generator().manual_seed(31)
-    cases = [("first envs empty", 12, 6), ("all out of sequence", 5, 4), ("one env", 1, 7), ("many clipped", 40, 8), ("forty frames", 6, 40), ("far first env", 9, 5)]
+    cases = [("first envs empty", 12, 6), ("first envs empty but env 0", 12, 6), ("all out of sequence", 5, 4), ("one env", 1, 7), ("many clipped", 40, 8), ("forty frames", 6, 40), ("far first env", 9, 5)]
     for tag, bs, F in cases:
         T = F - 1
         inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=23, steps_per_frame=1, penetration=0.002)
@@ -1511,8 +1513,8 @@ def test_reduce_loss_inside_the_launch_on_awkward_tables(dev):
         pos0 = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s)[0]
         tgt = (pos0.view(F, bs, nb, 7).permute(1, 0, 2, 3) + 0.01 * torch.randn(bs, F, nb, 7, generator=g).to(dev)).contiguous()
         outseq = torch.zeros(bs, F, dtype=torch.bool, device=dev)
-        if tag == "first envs empty":
-            outseq[0] = True
+        if tag.startswith("first envs empty"):
+            outseq[0] = tag == "first envs empty"
             tgt[1] = float("nan")
             outseq[2, : F - 1] = True
             tgt[5, 3:, :, :3] += 1.0
@@ -1534,6 +1536,10 @@ def test_reduce_loss_inside_the_launch_on_awkward_tables(dev):
         print("%-20s bs=%d F=%d: loss %.6e (loop %.6e) th %.3e positives %d clipped envs %d" % (tag, bs, F, red[0], float(ref), red[1], red[2], red[3]))
         assert abs(red[0] - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-12, tag
         assert float((tl["scale"].double() - gref).abs().max()) <= 1e-6 * float(gref.abs().max()) + 1e-12, tag
+        if tag == "first envs empty":   # env 0 has no positive entry: NaN threshold, no env clipped (dp_utils.py:98-103 on torch >= 1.8)
+            assert np.isnan(red[1]) and red[3] == 0 and float(tl["table"][5].max()) > 0.5
+        if tag == "first envs empty but env 0":
+            assert np.isfinite(red[1]) and red[3] >= 1
         if tag == "all out of sequence":
             assert red[0] == 0.0 and red[2] == 0
         if tag == "many clipped":
