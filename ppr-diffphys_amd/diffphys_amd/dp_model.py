@@ -205,7 +205,12 @@ def _traj_loss_forward(ctx, rollout_inputs, target_position, outseq_idx, self, q
     fk = None if queried is None else (c(queried[0]), c(queried[1]))
     wp_pos, wp_vel, grf, jaf, ws, tl = dm.rollout_forward_traj_loss(bs, nsteps, self.dt, *inp, frame2step=frame2step, target_pos=tgt,
                                                                     outseq=outseq, rot_ratio=0.1, want_seed_gt=need_gt, fk=fk)
-    ctx.dm, ctx.meta, ctx.tl = dm, (bs, nsteps, float(self.dt), frame2step), tl
+    # What the backward needs of tl -- WITHOUT the Function's outputs: an output kept on ctx closes the cycle ctx -> tensor -> grad_fn ->
+    # ctx through C++ references that Python's collector cannot see, and every iteration would then pin its buffers for good (ADVICE r4:
+    # ~30 MB per iteration at 4096 envs).  The FK outputs' shapes are all the backward wants of them.
+    ctx.dm, ctx.meta = dm, (bs, nsteps, float(self.dt), frame2step)
+    ctx.tl = {k: v for k, v in tl.items() if k not in ("fk_body_q", "fk_body_qd", "reduced")}
+    ctx.fk_shapes = None if fk is None else (tuple(tl["fk_body_q"].shape), tuple(tl["fk_body_qd"].shape))
     ctx.save_for_backward(ws, *inp, *(fk or ()))
     ctx.mass_shape, ctx.tgt_shape = body_mass.shape, target_position.shape
     has_f = [f for f, s in enumerate(frame2step) if s < nsteps]
@@ -229,18 +234,22 @@ def _traj_loss_backward(ctx, g_loss, g_queried):
     fk = None
     if g_queried is not None and (g_queried[0] is not None or g_queried[1] is not None):
         jq, jqd = ctx.saved_tensors[11:13]
-        aq = torch.zeros_like(tl["fk_body_q"]) if g_queried[0] is None else g_queried[0].to(torch.float32).contiguous()
-        aqd = torch.zeros_like(tl["fk_body_qd"]) if g_queried[1] is None else g_queried[1].to(torch.float32).contiguous()
+        z = lambda sh: torch.zeros(sh, dtype=torch.float32, device=ws.device)
+        aq = z(ctx.fk_shapes[0]) if g_queried[0] is None else g_queried[0].to(torch.float32).contiguous()
+        aqd = z(ctx.fk_shapes[1]) if g_queried[1] is None else g_queried[1].to(torch.float32).contiguous()
         fk = (jq, jqd, aq, aqd)
     g = ctx.dm.rollout_backward_traj_loss(bs, nsteps, dt, q_init, qd_init, torques, refs, ke, kd, inv_m, inertia, inv_inertia,
                                           frame2step, ws, tl, gl, fk=fk)
     g_tgt = None
     if ctx.needs_input_grad[11] and tl["seed_gt"] is not None:  # d loss_traj / d target pose = g x share / nb x d se3 / d gt
-        g_tgt = (tl["seed_gt"] * (tl["scale"] * (gl / ctx.dm.nb))[:, :, None, None]).view(ctx.tgt_shape)
+        # a zero share is an ASSIGNMENT in the reference (loss_seq[i, idx:] = 0, loss_traj[outseq_idx] = 0): nothing flows there, not 0 * inf
+        k = (tl["scale"] * (gl / ctx.dm.nb))[:, :, None, None]
+        g_tgt = torch.where(k != 0, tl["seed_gt"] * k, torch.zeros_like(tl["seed_gt"])).view(ctx.tgt_shape)
     out = (g["q_init"], g["qd_init"], g["torques"].view_as(torques), g["res_f"].view_as(res_f),
            g["refs"].view_as(refs), g["target_ke"], g["target_kd"],
            torch.zeros(ctx.mass_shape, dtype=torch.float32, device=ws.device), g["body_inv_mass"],
            g["body_inertia"].view_as(inertia), g["body_inv_inertia"].view_as(inv_inertia), g_tgt, None)
     if g_queried is not None:
         out += (g.get("fk_joint_q"), g.get("fk_joint_qd"))
+    ctx.tl = None  # the sweep's buffers go with it (a second backward through the same graph is not supported, as with saved tensors)
     return out
