@@ -243,7 +243,9 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q_dev, const flo
 /* Fused per-frame pose loss and its gradients (replaces the torch composition of
  * se3_loss, diffphys/dp_utils.py:113-138):  n elements of `dim` floats, dim = 7 (p, real-last quaternion) or 6
  * (p, axis-angle).  loss[n]; g_pred / g_gt [n][dim] = d loss / d input (either may be NULL).  Entries with a NaN input
- * give loss 0 and zero gradients, like the reference. */
+ * give loss 0 and gradients 0 x (the raw gradient), i.e. NaN where the local derivative is not finite and 0 elsewhere -- what autograd
+ * makes of the reference's `loss[nanid] = 0` (dp_utils.py:137): the NaN reaches the adjoint rollout as a seed there too and is scrubbed
+ * at that boundary (remove_nan), which drops the env's whole gradient. */
 int pd_se3_loss(int n, int dim, const float *pred_dev, const float *gt_dev, float rot_ratio, float *loss_dev,
                 float *g_pred_dev, float *g_gt_dev, void *stream);
 

@@ -73,7 +73,11 @@ __device__ __forceinline__ void store_rot_grad(const Rot &r, const float *gq, fl
 }
 
 
-// value and both gradients of one element; want_grad = false skips the gradient arithmetic.  NaN inputs: value 0, zero gradients.
+// value and both gradients of one element; want_grad = false skips the gradient arithmetic.  NaN inputs: value 0 and gradients
+// 0 x (the raw gradient) -- what autograd makes of the reference's masked assignment `loss[nanid] = 0` (dp_utils.py:137): the upstream
+// gradient of a masked entry is zero, and zero times a non-finite local derivative is NaN (0 where the derivative is finite).  A NaN
+// target or pose therefore seeds NaN into the adjoint rollout exactly as in the reference, where it spreads over the env and is scrubbed
+// to 0 at the boundary (remove_nan): the env's gradient is dropped, not just the one entry (rounds 1-4 returned exact zeros here).
 template <int DIM>
 __device__ __forceinline__ float se3_loss_eval(const float *p, const float *g, float rot_ratio, bool want_grad, float *out_pred, float *out_gt) {
   float sp = 0.f, sg = 0.f;
@@ -98,14 +102,14 @@ __device__ __forceinline__ float se3_loss_eval(const float *p, const float *g, f
       out_pred[0] = 2.0f * d[0]; out_pred[1] = 2.0f * d[1]; out_pred[2] = 2.0f * d[2];
       store_rot_grad<DIM>(A, gq, dT, out_pred);
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) out_pred[k] = bad ? 0.0f : out_pred[k];  // (0 * NaN would still be NaN)
+      for (int k = 0; k < DIM; ++k) out_pred[k] = bad ? 0.0f * out_pred[k] : out_pred[k];  // NaN stays NaN, like autograd
     }
     if (out_gt) {
       trace_grad(B, A.R, gq);
       out_gt[0] = -2.0f * d[0]; out_gt[1] = -2.0f * d[1]; out_gt[2] = -2.0f * d[2];
       store_rot_grad<DIM>(B, gq, dT, out_gt);
 #pragma unroll
-      for (int k = 0; k < DIM; ++k) out_gt[k] = bad ? 0.0f : out_gt[k];
+      for (int k = 0; k < DIM; ++k) out_gt[k] = bad ? 0.0f * out_gt[k] : out_gt[k];
     }
   }
   return bad ? 0.0f : value;

@@ -526,6 +526,13 @@ def pose_op(op, a, b):
     return out
 
 
+def colsum(x):
+    """x [n, k] -> [k], the column sums as ONE GEMM (ones[1, n] @ x) instead of torch's reduction kernel: torch's multi-block reductions
+    of this shape (many rows, few columns) replay STALE inside a captured HIP graph on this stack (scripts/micro/torch_graph_replay2.py),
+    and everything on phys_model's iteration path must survive ``phys_model.capture_iteration``."""
+    return (torch.ones(1, x.shape[0], dtype=x.dtype, device=x.device) @ x).reshape(-1)
+
+
 def pose_op_vjp(op, a, b, g_out, need_a=True, need_b=True):
     """``pd_pose_op_vjp``: (g_a, g_b) for the upstream gradient g_out; g_a is already summed when ``a`` was broadcast."""
     n, bcast, no = _pose_n(op, a, b)
@@ -538,7 +545,7 @@ def pose_op_vjp(op, a, b, g_out, need_a=True, need_b=True):
     if rc != 0:
         raise RuntimeError("pd_pose_op_vjp failed (rc %d)" % rc)
     if need_a:
-        g_a = g_a.reshape(-1, na).sum(0).reshape(a.shape) if bcast else g_a.reshape(a.shape)
+        g_a = colsum(g_a.reshape(-1, na)).reshape(a.shape) if bcast else g_a.reshape(a.shape)
     return g_a, g_b
 
 

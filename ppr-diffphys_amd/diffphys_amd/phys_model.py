@@ -38,6 +38,13 @@ def get_local_rank():
         return 0
 
 
+def _mean_sq(x):
+    """x.pow(2).mean() as a dot product (rocBLAS): torch's multi-block full reduction of a tensor this size replays stale inside a captured
+    HIP graph on this stack (scripts/micro/torch_graph_replay2.py; hip_backend.colsum has the column-sum case)."""
+    v = x.reshape(-1)
+    return torch.dot(v, v) / v.numel()
+
+
 class _FootHeightHip(torch.autograd.Function):
     @staticmethod
     def forward(ctx, body_q, c_body, c_point, c_dist):
@@ -152,9 +159,14 @@ class phys_model(nn.Module):
     def reinit_envs(self, num_envs, frames_per_wdw, is_eval=False, overwrite=False):
         self.num_envs, self.frames_per_wdw = num_envs, frames_per_wdw
         self.steps_idx = range(self.steps_per_fr_interval * (frames_per_wdw - 1) + 1)
-        self.steps_idx_fr = torch.tensor(list(self.steps_idx), device=self.device) / self.steps_per_fr_interval
         self.frame2step = [i for i in range(len(self.steps_idx)) if i % self.steps_per_fr_interval == 0]
-        self._f2s_t = torch.tensor(self.frame2step, dtype=torch.long, device=self.device)  # device copy for indexing (no upload per use)
+        # device tensors of this window shape, made once per shape: main.py alternates between the evaluation and the training shape, and a
+        # captured iteration (capture_iteration) reads them BY ADDRESS -- they must neither move nor be freed
+        cache = self.__dict__.setdefault("_wdw_cache", {})
+        if frames_per_wdw not in cache:
+            cache[frames_per_wdw] = (torch.tensor(list(self.steps_idx), device=self.device) / self.steps_per_fr_interval,
+                                     torch.tensor(self.frame2step, dtype=torch.long, device=self.device))
+        self.steps_idx_fr, self._f2s_t = cache[frames_per_wdw]  # (_f2s_t: device copy of frame2step for indexing, no upload per use)
         env_name = "eval_env" if is_eval else "train_env"
         if hasattr(self, env_name) and not overwrite and getattr(self, env_name).num_envs == num_envs:
             self.env = getattr(self, env_name)
@@ -300,14 +312,36 @@ class phys_model(nn.Module):
     def get_net_pred(self, steps_fr):
         bs, nstep = steps_fr.shape
         t = steps_fr.reshape(-1)
-        torques = self.torque_mlp(t)
-        torques = torch.cat([torch.zeros_like(torques[:, :1].repeat(1, 6)), torques], 1).view(bs, nstep, -1) * 0
-        res_f = self.residual_f_mlp(t).view(bs, nstep, -1, 6)
-        res_f = torch.cat([res_f[..., :3] * 10, res_f[..., 3:]], -1).view(bs, nstep, -1) * 0
+        if getattr(self, "skip_zeroed_mlps", True):
+            # The reference evaluates torque_mlp and residual_f_mlp and then multiplies both outputs by zero (`torques *= 0`, `res_f *= 0`,
+            # dp_model.py:526-536): the rollout sees zeros and every parameter of the two MLPs gets an exactly-zero gradient (AdamW then
+            # only applies its weight decay to them).  Same values without the two MLPs' forward and backward -- 2 of the 5 time-MLPs,
+            # ~40 % of an iteration's GEMMs: zeros here, zero gradients attached in backward() / iteration() (_attach_zero_grads).
+            # skip_zeroed_mlps = False evaluates them as the reference does (tests compare the two bit for bit).
+            torques = torch.zeros(bs, nstep, 6 + self.n_dof, dtype=torch.float32, device=steps_fr.device)
+            res_f = torch.zeros(bs, nstep, 6 * self.n_links, dtype=torch.float32, device=steps_fr.device)
+        else:
+            torques = self.torque_mlp(t)
+            torques = torch.cat([torch.zeros_like(torques[:, :1].repeat(1, 6)), torques], 1).view(bs, nstep, -1) * 0
+            res_f = self.residual_f_mlp(t).view(bs, nstep, -1, 6)
+            res_f = torch.cat([res_f[..., :3] * 10, res_f[..., 3:]], -1).view(bs, nstep, -1) * 0
         delta_root = self.root_pose_mlp(t).view(bs, nstep, -1)
         delta_ja_ref = self.joint_angle_mlp(t).view(bs, nstep, -1)
         state_qd = self.vel_mlp(t).view(bs, nstep, -1)
         return torques, delta_root, delta_ja_ref, state_qd, res_f
+
+    def _attach_zero_grads(self):
+        """the exactly-zero gradients of the two MLPs whose outputs the reference multiplies by zero (get_net_pred), from buffers made once"""
+        if not getattr(self, "skip_zeroed_mlps", True):
+            return
+        z = self.__dict__.setdefault("_zero_grad_bufs", {})
+        for mlp in (self.torque_mlp, self.residual_f_mlp):
+            for p in mlp.parameters():
+                if p.requires_grad and p.grad is None:
+                    b = z.get(p)
+                    if b is None or b.shape != p.shape or b.device != p.device:
+                        b = z[p] = torch.zeros_like(p)
+                    p.grad = b   # (update()'s zero_grad(set_to_none=True) detaches it again; the guards scale it in place: still zero)
 
     @staticmethod
     def rearrange_pred(queried_q, queried_ja, queried_qd, torques, res_f):
@@ -325,8 +359,8 @@ class phys_model(nn.Module):
             raise TypeError("get_foot_height needs float32 GPU poses (the product path has no CPU fallback; oracle/pose_torch.py foot_height is the checker)")
         return _FootHeightHip.apply(state_body_q, self.c_body_i32, self.c_point, self.c_dist)
 
-    def compute_frame_start(self):
-        fs = torch.tensor(np.random.rand(self.num_envs), device=self.device)
+    def compute_frame_start(self, rng=np.random):
+        fs = torch.tensor(rng.rand(self.num_envs), device=self.device)
         return (fs * (self.total_frames - self.frames_per_wdw)).round().long()
 
     def fk_pos_vel(self, target_q, target_ja, target_qd, target_jad):
@@ -353,15 +387,15 @@ class phys_model(nn.Module):
         return target_position, ref_ja, queried_q, queried_qd, torques, res_f
 
     # ---------------------------------------------------------------- forward
-    def make_q_init_noise(self):
+    def make_q_init_noise(self, rng=np.random):
         """The init noise of this iteration (dp_model.py:702-712): N(0, noise_std * ratio), none on the root translation, x5 on
         the root rotation; None when the model is not training or the noise is off.  A separate method so that a captured
-        iteration (scripts/gpu_iter_graph.py) can feed it through a static buffer."""
+        iteration (capture_iteration) can feed it through a static buffer."""
         if not (self.training and self.noise_std > 0):
             return None
         noise_ratio = np.clip(1 - 1.5 * self.progress, 0, 1)
         nq = self.n_dof + 7
-        noise = torch.tensor(np.random.normal(size=self.num_envs * nq, scale=self.noise_std * noise_ratio), dtype=torch.float32,
+        noise = torch.tensor(rng.normal(size=self.num_envs * nq, scale=self.noise_std * noise_ratio), dtype=torch.float32,
                              device=self.device).view(self.num_envs, -1)
         noise[:, :3] = 0
         noise[:, 3:7] *= 5
@@ -390,14 +424,10 @@ class phys_model(nn.Module):
         body_mass = self.body_mass[None].repeat(n, 1).view(-1)
         body_inv_mass = 1.0 / body_mass
         body_inertia = self.norm_body_inertia[None].repeat(n, 1, 1, 1).view(-1, 3, 3) * body_mass[..., None, None]
-        if torch.cuda.is_current_stream_capturing():
-            # (experiment scripts/gpu_iter_graph.py) the batched LU is not capturable; inverse(norm_inertia * m) =
-            # inverse(norm_inertia) / m exactly in exact arithmetic, with the constant factor inverted once, eagerly
-            body_inv_inertia = (self._inv_norm_inertia()[None].repeat(n, 1, 1, 1).view(-1, 3, 3) / body_mass[..., None, None]).contiguous()
-        else:
-            # the reference's body_inertia.inverse() (dp_model.py:730) without its singular-matrix check, which is a host
-            # synchronisation per forward(): same LU, same values
-            body_inv_inertia = torch.linalg.inv_ex(body_inertia).inverse.contiguous()
+        # body_inertia.inverse() of the reference (dp_model.py:730) as inverse(norm_inertia) / m: inverse(N m) = inverse(N) / m exactly, the
+        # constant factor inverted once (LU, eagerly) -- torch's batched LU is a host synchronisation per forward() with its singular-matrix
+        # check and is not capturable in a HIP graph; the eager and the captured iteration run this one formula (bit-identical losses)
+        body_inv_inertia = (self._inv_norm_inertia()[None].repeat(n, 1, 1, 1).view(-1, 3, 3) / body_mass[..., None, None]).contiguous()
         qd_init = convert_ppr_warp(qd_init)  # quirk (i): flat vector
         res_fin = convert_ppr_warp(res_fin)
         F_ = self.frames_per_wdw
@@ -437,8 +467,8 @@ class phys_model(nn.Module):
         loss_dict["pos_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_pos), loss_pos))
         loss_vel = se3_loss(queried_velocity, sim_velocity.detach()).mean(-1)
         loss_dict["vel_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_vel), loss_vel))
-        loss_dict["reg_torque"] = torques.pow(2).mean()
-        loss_dict["reg_res_f"] = res_f.pow(2).mean()
+        loss_dict["reg_torque"] = _mean_sq(torques)
+        loss_dict["reg_res_f"] = _mean_sq(res_f)
         loss_dict["reg_foot"] = foot_height.pow(2).mean()
 
         total_loss = 0
@@ -481,6 +511,120 @@ class phys_model(nn.Module):
 
     def backward(self, loss):
         loss.backward()
+        self._attach_zero_grads()
+
+    # ------------------------------------------------------- one iteration as ONE HIP graph
+    # main.py:96-103 of the reference at accu_steps = 1 is  forward() -> backward() -> update().  forward() + backward() are ~620 of
+    # the iteration's ~650 launches (five time-MLPs, pose algebra, the two rollout launches, the loss terms and autograd's backward of
+    # all that) on 10 envs x 760 steps: host-bound at 16 ms.  Nothing in them talks to the host (rounds 2-4), so they are captured once
+    # and replayed; update() -- the gradient guards with their ONE host transfer, AdamW, the LR schedule -- stays as it is, eager,
+    # ~25 launches.  The window starts and the init noise are drawn on the host exactly as before (same random stream as the eager
+    # path) and reach the graph through two static buffers.
+    def capture_iteration(self, validate=True, verbose=False):
+        """Captures forward() + backward() at the current window shape (reinit_envs) into a HIP graph.  Returns True when the graph is in
+        use afterwards.  ``validate``: two replays on fresh window starts / noise are compared BIT FOR BIT (total loss, every loss term,
+        every parameter gradient) with eager forward() + backward() on the same inputs; on any difference the graph is dropped and
+        iteration() stays eager (torch's own multi-block reductions replay stale on this stack: scripts/micro/torch_graph_replay2.py --
+        everything on this path goes through GEMMs / the library's kernels instead, and this check is what holds that)."""
+        self._graph = None
+        if not (self.training and str(self.device).startswith("cuda") and torch.cuda.is_available()):
+            return False
+        n, nq = self.num_envs, self.n_dof + 7
+        dev = self.device
+        g_fs = torch.zeros(n, dtype=torch.long, device=dev)
+        g_noise = torch.zeros(n * nq, dtype=torch.float32, device=dev)
+        self._inv_norm_inertia(); self._frame_index()
+        rng = np.random.RandomState(20261003)   # (a private stream: capturing must not move the run's own random numbers)
+        keep_pending = getattr(self, "_pending_nan", None)
+        params = [p for p in self.parameters() if p.requires_grad]
+        weights = {k: v for k, v in self.opts.items() if k.endswith("_wt")}
+
+        def draw():
+            g_fs.copy_(self.compute_frame_start(rng))
+            noise = self.make_q_init_noise(rng)
+            g_noise.copy_(noise) if noise is not None else g_noise.zero_()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        mt = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)   # (the capture must see every backward launch on the capturing stream)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):   # warm-up on the capturing stream: allocator, frame tables of the rollout, rocBLAS handles
+                    draw()
+                    self.optimizer.zero_grad(set_to_none=True)
+                    self._pending_nan = None
+                    self.forward(frame_start=g_fs, q_init_noise=g_noise)["total_loss"].backward()
+                self.optimizer.zero_grad(set_to_none=True)
+                self._pending_nan = None
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    out = self.forward(frame_start=g_fs, q_init_noise=g_noise)
+                    out["total_loss"].backward()
+            torch.cuda.current_stream().wait_stream(side)
+        finally:
+            torch.autograd.set_multithreading_enabled(mt)
+        st = dict(graph=graph, fs=g_fs, noise=g_noise, out=out, nan=self._pending_nan, grads=[(p, p.grad) for p in params if p.grad is not None],
+                  side=dict(grfs=self.grfs, jafs=self.jafs, sim=self.sim_trajs._dev, tgt=self.target_trajs._dev, pid=self.pid_ref._dev,
+                            info=self.traj_loss_info), shape=(n, self.frames_per_wdw), weights=weights, env=self.env, replays=0)
+        ok = True
+        if validate:
+            for trial in range(2):
+                draw()
+                graph.replay()
+                got = {k: v.detach().clone() for k, v in out.items()}
+                got_g = [g.clone() for _, g in st["grads"]]
+                for p in params:
+                    p.grad = None
+                self._pending_nan = None
+                ref = self.forward(frame_start=g_fs.clone(), q_init_noise=g_noise.clone())
+                ref["total_loss"].backward()
+                bad = [k for k in got if not torch.equal(got[k], ref[k].detach())]
+                names = {id(p): nme for nme, p in self.named_parameters()}
+                bad += [names[id(p)] for (p, _), g in zip(st["grads"], got_g) if p.grad is None or not torch.equal(g, p.grad)]
+                if verbose or bad:
+                    print("capture_iteration: replay %d vs eager: %s" % (trial, "bit-identical (%d loss terms, %d gradients)" % (len(got), len(got_g)) if not bad
+                                                                         else "DIFFERENT in %s" % bad[:12]))
+                ok = ok and not bad
+        for p in params:
+            p.grad = None
+        self._pending_nan = keep_pending
+        if ok:
+            self._graph = st
+        elif get_local_rank() == 0:
+            print("capture_iteration: the captured iteration does not replay bit for bit on this stack -- staying eager")
+        return ok
+
+    def _graph_usable(self):
+        st = getattr(self, "_graph", None)
+        return (st is not None and self.training and st["shape"] == (self.num_envs, self.frames_per_wdw) and st["env"] is self.env
+                and all(self.opts.get(k) == v for k, v in st["weights"].items()))
+
+    def iteration(self):
+        """forward() + backward() of one optimisation iteration; returns forward()'s dict.  The replay of the captured graph when there is
+        one for the current window shape and loss weights (capture_iteration), eager otherwise -- same random numbers, same kernels on
+        the same data, bit-identical results either way (tests/test_gpu_workload.py)."""
+        if not self._graph_usable():
+            out = self.forward()
+            self.backward(out["total_loss"])
+            return out
+        self._attach_zero_grads()
+        st = self._graph
+        st["fs"].copy_(self.compute_frame_start(), non_blocking=True)
+        noise = self.make_q_init_noise()
+        st["noise"].copy_(noise, non_blocking=True) if noise is not None else st["noise"].zero_()
+        st["graph"].replay()
+        st["replays"] += 1
+        for p, g in st["grads"]:   # (update() detaches them with zero_grad(set_to_none=True); the buffers are the graph's)
+            p.grad = g
+        prev = getattr(self, "_pending_nan", None)
+        self._pending_nan = st["nan"] if prev is None else (prev | st["nan"])
+        side = st["side"]
+        from .dp_model import HostFrames
+        self.grfs, self.jafs, self.traj_loss_info = side["grfs"], side["jafs"], side["info"]
+        self.sim_trajs, self.target_trajs, self.pid_ref = HostFrames(side["sim"]), HostFrames(side["tgt"]), HostFrames(side["pid"])
+        return st["out"]
 
     @torch.no_grad()
     def query(self, img_size=None):

@@ -8,6 +8,60 @@ import torch
 from torch import nn
 
 
+class _LinearGemmBias(torch.autograd.Function):
+    """y = x W^T + b with the bias gradient taken by a GEMM (ones[1, N] @ g) instead of torch's column reduction.  Same forward as
+    F.linear.  Why: on this stack (ROCm 7.x / torch 2.10) torch's multi-block reductions -- e.g. ``g.sum(0)`` over [1024, 128] -- come
+    out STALE from the second replay of a captured HIP graph on (their semaphore memset is not re-executed; pure-torch reproducer
+    scripts/micro/torch_graph_replay2.py), and the bias gradients of these MLPs are exactly that shape.  A GEMM has no such state, so
+    an iteration captured by ``phys_model.capture_iteration`` replays bit for bit; the eager path runs the same code."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = _gemm_long_k(g.t(), x) if ctx.needs_input_grad[1] else None
+        gb = (_ones_row(g.shape[0], g) @ g).reshape(-1) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+_ONES = {}
+
+
+def _ones_row(n, like):
+    """ones[1, n] on like's device, made once per (n, device): the bias-gradient GEMM's left operand (a fill per layer and backward otherwise)"""
+    key = (n, like.device, like.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        if len(_ONES) > 16:
+            _ONES.clear()
+        t = _ONES[key] = torch.ones(1, n, dtype=like.dtype, device=like.device)
+    return t
+
+
+def _gemm_long_k(a, b):
+    """a [m, K] @ b [K, n] with K >> m, n (the weight gradient: K = samples): on MI355X / ROCm 7 rocBLAS has a 24 us kernel for
+    256 x 7600 x 256 where hipBLASLt, torch's default, picks a 55 us one (scripts/micro/gemm_shapes.py) -- routed there when K is long.
+    The choice depends on shapes only, so the eager and the captured iteration take the same kernel."""
+    if a.is_cuda and a.shape[1] >= 2048 and torch.version.hip is not None:
+        prev = torch.backends.cuda.preferred_blas_library()
+        try:
+            torch.backends.cuda.preferred_blas_library("hipblas")
+            return a @ b
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev)
+    return a @ b
+
+
+def _linear(layer, x):
+    return _LinearGemmBias.apply(x, layer.weight, layer.bias)
+
+
 class TimeMLPWrapper(nn.Module):
     def __init__(self, num_frames, frame_info=None, D=5, W=256, num_freq_t=6, out_channels=1, skips=(1, 2, 3, 4),
                  activation=None, time_scale=1.0, output_scale=1.0):
@@ -38,10 +92,10 @@ class TimeMLPWrapper(nn.Module):
         if frame_id is None:
             frame_id = torch.arange(self.num_frames, device=self.head.weight.device)
         e = self.embed(frame_id)
-        h = self.act(self.inp(e))
+        h = self.act(_linear(self.inp, e))
         for i, layer in enumerate(self.layers):
-            h = self.act(layer(torch.cat([h, e], -1) if i in self.skips else h))
-        return self.head(h) * self.output_scale
+            h = self.act(_linear(layer, torch.cat([h, e], -1) if i in self.skips else h))
+        return _linear(self.head, h) * self.output_scale
 
 
 def interp_wt(x, y, x2, type="linear"):

@@ -47,6 +47,8 @@ def get_opts(argv=None):
     ap.add_argument("--num_envs", type=int, default=10, help="envs per training iteration (main.py:86 of the reference)")
     ap.add_argument("--frames_per_wdw", type=int, default=24)
     ap.add_argument("--urdf_root", default=None, help="directory with laikago/laikago.urdf etc. (default: compiled templates)")
+    ap.add_argument("--no_graph", action="store_true", help="run forward() + backward() eagerly instead of replaying them as one captured HIP "
+                    "graph (the default at accu_steps = 1; phys_model.capture_iteration validates the capture and falls back by itself)")
     return vars(ap.parse_args(argv))
 
 
@@ -63,14 +65,20 @@ def main(argv=None):
                 ev = model.forward(frame_start=torch.zeros(1, dtype=torch.long, device=model.device))
             print("[eval %4d] traj loss %.5f" % (it, float(ev["loss_traj"])))
             model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"], is_eval=False)
+            if it == 0 and opts["accu_steps"] == 1 and not opts["no_graph"]:
+                model.capture_iteration()   # forward() + backward() of the training window as ONE HIP graph from here on
         t0 = time.time()
         model.set_progress(it)
-        loss = 0
-        for _ in range(opts["accu_steps"]):  # gradient accumulation over several windows (main.py:95-99 of the reference)
-            loss_dict = model.forward()
-            loss = loss + loss_dict["total_loss"]
-        loss = loss / float(opts["accu_steps"])
-        model.backward(loss)
+        if opts["accu_steps"] == 1:
+            loss_dict = model.iteration()   # = forward() + backward(): the captured graph's replay, or eager (same numbers)
+            loss = loss_dict["total_loss"]
+        else:
+            loss = 0
+            for _ in range(opts["accu_steps"]):  # gradient accumulation over several windows (main.py:95-99 of the reference)
+                loss_dict = model.forward()
+                loss = loss + loss_dict["total_loss"]
+            loss = loss / float(opts["accu_steps"])
+            model.backward(loss)
         model.update()
         torch.cuda.synchronize()
         print("[iter %4d] total %.6f traj %.5f pos_state %.5f  (%.3f s)" % (

@@ -1,71 +1,45 @@
 #!/usr/bin/env python3
-"""EXPERIMENT (not product code): one optimisation iteration of phys_model eager vs forward() + backward() captured in one HIP
-graph (static frame_start / noise buffers, documented whole-network pattern), then update() eagerly.  Possible because
-nothing between forward() and backward() synchronises the host any more.  Measured on MI355X / ROCm 7.2 / torch 2.10,
-256 envs: eager 33.4 ms, captured 21.9 ms per iteration -- but the captured gradients are WRONG from the second replay on
-(torch's own multi-block reductions, e.g. nn.Linear bias gradients: pure-torch reproducer scripts/micro/torch_graph_replay.py)
-and capture_end can crash after eager iterations on the default stream, so the whole-iteration graph is not shipped.  The
-library's own launches (FK, rollout, fused losses, adjoint) capture and replay bit-exactly:
-tests/test_gpu_parity.py::test_empty_batch_and_graph_capture.   Usage: gpu_iter_graph.py [num_envs]"""
-import os, sys, time
+"""One optimisation iteration of phys_model on the reference's own training window (main.py:86: 10 envs x 760 steps, 24 frames):
+eager forward() + backward() + update() against phys_model.iteration() replaying the captured HIP graph (capture_iteration) + update().
+Prints ms per iteration of both, and whether the losses of 20 iterations and the parameters after them are bit-identical.
+    python scripts/gpu_iter_graph.py [num_envs] [frames_per_wdw] [iterations]"""
+import importlib.util
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ppr-diffphys_amd"))
-import importlib.util
-import numpy as np, torch
+import numpy as np
+import torch
+
 from diffphys_amd.dataloader import DataLoader
 from diffphys_amd.phys_model import phys_model
 
-nenv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+nenv = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+fpw = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 spec = importlib.util.spec_from_file_location("pd_main", os.path.join(ROOT, "ppr-diffphys_amd", "main.py"))
 pd_main = importlib.util.module_from_spec(spec); spec.loader.exec_module(pd_main)
 opts = pd_main.get_opts(["--seqname", "mi-pace", "--urdf_template", "laikago", "--logroot", "/tmp/pprdp_prof/", "--logname", "g",
-                         "--num_envs", str(nenv), "--frames_per_wdw", "4"])
-
-
-def make():
-    torch.manual_seed(0); np.random.seed(0)
-    m = phys_model(opts, DataLoader(opts)).cuda(); m.train()
-    m.reinit_envs(nenv, frames_per_wdw=4)
-    return m
-
-
-fs = (torch.arange(nenv, device="cuda") * 3) % 40
-K = 20
+                         "--num_envs", str(nenv), "--frames_per_wdw", str(fpw)])
 res = {}
-for mode in ("eager", "graph"):
-    model = make()
+for mode in ("eager-all-mlps", "eager", "graph"):
+    torch.manual_seed(0); np.random.seed(0)
+    model = phys_model(opts, DataLoader(opts)).cuda(); model.train()
+    model.skip_zeroed_mlps = mode != "eager-all-mlps"   # False: torque_mlp / residual_f_mlp evaluated and multiplied by zero, as the reference does
+    model.reinit_envs(nenv, frames_per_wdw=fpw)
     if mode == "graph":
-        nq = model.n_dof + 7
-        g_fs = torch.zeros(nenv, dtype=torch.long, device="cuda")
-        g_noise = torch.zeros(nenv * nq, device="cuda")
-        model._inv_norm_inertia(); model._frame_index()
-        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                model.optimizer.zero_grad(set_to_none=True)
-                model.forward(frame_start=g_fs, q_init_noise=g_noise)["total_loss"].backward()
-            model.optimizer.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                g_out = model.forward(frame_start=g_fs, q_init_noise=g_noise)
-                g_out["total_loss"].backward()
-        torch.cuda.current_stream().wait_stream(side)
-        model.optimizer.zero_grad = lambda set_to_none=True: None  # the captured backward ASSIGNS its static gradient buffers
+        t0 = time.perf_counter()
+        ok = model.capture_iteration(validate=True, verbose=True)
+        torch.cuda.synchronize()
+        print("capture_iteration: %s in %.2f s" % ("captured + validated" if ok else "REJECTED (eager fallback)", time.perf_counter() - t0), flush=True)
+    np.random.seed(100)
     losses = []
 
     def one(it):
         model.set_progress(it)
-        np.random.seed(100 + it)  # the init noise is drawn on the host: same stream of numbers in both modes
-        if mode == "graph":
-            g_fs.copy_(fs)
-            noise = model.make_q_init_noise()
-            g_noise.copy_(noise) if noise is not None else g_noise.zero_()
-            graph.replay()
-            out = g_out
-            model._pending_loss = out["total_loss"].detach()
-        else:
-            out = model.forward(frame_start=fs)
-            model.backward(out["total_loss"])
+        out = model.iteration()
         losses.append(out["total_loss"].detach().clone())
         model.update()
 
@@ -78,9 +52,37 @@ for mode in ("eager", "graph"):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K * 1e3
     res[mode] = (dt, torch.stack(losses).cpu().numpy(), {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters()})
-    print("ITER %-5s num_envs=%d: %.2f ms per iteration (forward + backward + update)" % (mode, nenv, dt), flush=True)
+    print("ITER %-14s %d envs x %d steps: %.2f ms per iteration (forward + backward + update)%s" % (
+        mode, nenv, len(model.steps_idx), dt, "  [%d replays]" % model._graph["replays"] if getattr(model, "_graph", None) else ""), flush=True)
+le, lg = res["eager-all-mlps"][1], res["eager"][1]
+same = all(np.array_equal(res["eager-all-mlps"][2][n], res["eager"][2][n]) for n in res["eager"][2])
+print("the two zeroed MLPs evaluated (as the reference) vs skipped: losses %s, parameters after %d iterations %s" % (
+    "BIT-IDENTICAL" if np.array_equal(le, lg) else "max rel diff %.2e" % (np.abs(le - lg).max() / np.abs(le).max()), len(le), "BIT-IDENTICAL" if same else "different"))
 le, lg = res["eager"][1], res["graph"][1]
-print("loss trajectory eager vs graph: first %.6e / %.6e  last %.6e / %.6e  max rel diff %.2e" % (
-    le[0], lg[0], le[-1], lg[-1], np.abs(le - lg).max() / np.abs(le).max()))
-worst = max((np.abs(res["eager"][2][n] - res["graph"][2][n]).max() / (np.abs(res["eager"][2][n]).max() + 1e-12), n) for n in res["eager"][2])
-print("parameters after %d iterations: max rel diff %.2e (%s)" % (K + 5, worst[0], worst[1]))
+print("losses of %d iterations, eager vs graph: %s  (first %.9e / %.9e, last %.9e / %.9e)" % (
+    len(le), "BIT-IDENTICAL" if np.array_equal(le, lg) else "max rel diff %.2e" % (np.abs(le - lg).max() / np.abs(le).max()), le[0], lg[0], le[-1], lg[-1]))
+same = all(np.array_equal(res["eager"][2][n], res["graph"][2][n]) for n in res["eager"][2])
+print("parameters after %d iterations: %s" % (len(le), "BIT-IDENTICAL" if same else "different"))
+
+# ---- where the captured iteration's time goes (the last model is the graph one)
+if getattr(model, "_graph", None):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    acc = np.zeros(5)
+    R = 20
+    for it in range(R):
+        model.set_progress(30 + it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record()
+        out = model.iteration()
+        ev[1].record()
+        t1 = time.perf_counter()
+        model.update()
+        ev[2].record()
+        t2 = time.perf_counter()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        acc += [ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t0) * 1e3]
+    acc /= R
+    print("captured iteration: device time of iteration() %.2f ms, of update() %.2f ms; host time to enqueue iteration() %.2f ms, update() incl. its "
+          "host transfer %.2f ms; wall %.2f ms" % tuple(acc))

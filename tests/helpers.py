@@ -291,3 +291,38 @@ def own_trajectory_check(dm, tpl, inp, dev, hitlog_check=True, abs_floor=0.0, li
         out.update(hitlog_missing=missing, hitlog_overflow=int((~ok).sum()), touches=int(n_t.sum()),
                    log_entries=int(np.maximum(log[..., 0], 0).sum()))
     return out
+
+
+def toy_template(tmp_path, attach_ke=8000.0, attach_kd=200.0):
+    """The toy robot of tests/test_host.py (free + revolute + compound + fixed joints; box / sphere / mesh / capsule contacts) through the
+    model compiler: the GENERIC kernel instantiation, which none of the three shipped robots uses."""
+    from test_host import OBJ, URDF
+    from diffphys_amd import sim
+    from diffphys_amd.import_urdf import parse_urdf
+
+    (tmp_path / "toy.urdf").write_text(URDF)
+    (tmp_path / "tet.obj").write_text(OBJ)
+    b = sim.ModelBuilder()
+    parse_urdf(str(tmp_path / "toy.urdf"), b, xform=sim.transform((0, 0.5, 0), sim.quat_identity()), floating=True, density=1000.0,
+               armature=0.01, stiffness=220.0, damping=2.0, shape_ke=1e4, shape_kd=10.0, shape_kf=1e2, shape_mu=0.7, limit_ke=50.0, limit_kd=1.0)
+    return build_template(b, attach_ke=attach_ke, attach_kd=attach_kd)
+
+
+def toy_inputs(tpl, bs, T, frame2step, seed=0):
+    """float32 rollout inputs for the toy robot: feet in the ground, joints off their references, non-zero twists / torques / residuals"""
+    nb, nq, nqd = int(tpl["nb"]), int(tpl["nq"]), int(tpl["nqd"])
+    rng = np.random.RandomState(seed)
+    q = np.tile(tpl["joint_q"].astype(np.float64), (bs, 1))
+    q[:, 1] = 0.13 + rng.rand(bs) * 0.02
+    q[:, 7:] = rng.uniform(-0.4, 0.4, (bs, nq - 7))
+    mass = np.tile(tpl["body_mass"].astype(np.float64), bs)
+    inertia = np.tile(tpl["body_inertia"].astype(np.float64), (bs, 1, 1))
+    ke = np.tile(np.r_[np.zeros(6), np.full(nqd - 6, 60.0)], bs)
+    F = len(frame2step)
+    inp = dict(q_init=q.reshape(-1), qd_init=rng.randn(bs * nqd) * 0.2, torques=rng.randn(T, bs * nqd) * 0.3,
+               res_f=rng.randn(T, bs * nb, 6) * 0.3, refs=rng.uniform(-0.3, 0.3, (T, bs * nqd)), target_ke=ke, target_kd=ke * 0.02,
+               body_mass=mass, body_inv_mass=1 / mass, body_inertia=inertia, body_inv_inertia=np.linalg.inv(inertia),
+               adj_pos=rng.randn(F, bs * nb, 7) * 1e-3, adj_vel=rng.randn(F, bs * nb, 6) * 1e-3)
+    inp = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in inp.items()}
+    inp.update(frame2step=list(frame2step), nsteps=T, dt=5e-4)
+    return inp

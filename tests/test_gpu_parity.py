@@ -791,10 +791,13 @@ def test_fused_se3_loss_matches_the_torch_composition(dim, dev):
     p64, g64 = pred.double().to(dev).requires_grad_(True), gt.double().to(dev).requires_grad_(True)
     ref = pose_torch.se3_loss(p64, g64, 0.1)
     ok = torch.ones(n, dtype=torch.bool, device=dev); ok[50] = False; ok[51] = False
-    (ref[ok] * w.double()[ok]).sum().backward()
+    (ref * w.double()).sum().backward()
     assert loss[50].item() == 0.0 and loss[51].item() == 0.0
-    assert p32.grad[50].abs().max().item() == 0.0 and g32.grad[51].abs().max().item() == 0.0
-    assert torch.isfinite(loss).all() and torch.isfinite(p32.grad).all() and torch.isfinite(g32.grad).all()
+    # NaN inputs: the loss is 0 and the gradient is 0 x (the local derivative) -- NaN where that is not finite, as autograd makes of the
+    # reference's `loss[nanid] = 0` (dp_utils.py:137): the same NaN pattern as autograd through the float64 restatement
+    assert torch.equal(p32.grad.isnan(), p64.grad.isnan()) and torch.equal(g32.grad.isnan(), g64.grad.isnan())
+    assert p32.grad[50].isnan().tolist() == [False, True] + [False] * (dim - 2) and g32.grad[51, 3:].isnan().all()
+    assert torch.isfinite(loss).all() and torch.isfinite(p32.grad[ok]).all() and torch.isfinite(g32.grad[ok]).all()
     rel = lambda a, b: float((a.detach().double() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
     assert rel(loss[ok], ref[ok]) < 2e-5
     assert rel(p32.grad[ok], p64.grad[ok]) < 5e-4 and rel(g32.grad[ok], g64.grad[ok]) < 5e-4
@@ -863,7 +866,8 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     tgt = pos0.reshape(F, bs, nb, 7).permute(1, 0, 2, 3).clone()
     tgt = tgt + (torch.randn(tgt.shape, generator=g) * 0.02).to(dev)
     tgt[3, 2:, :, :3] += 0.8                # env 3: far from its targets from frame 2 on => clipped at frame 2
-    tgt[1, 4, 5, 2] = float("nan")           # one NaN target pose: its se3_loss is 0, no gradient
+    tgt[1, 4, 5, 2] = float("nan")           # one NaN target pose: its se3_loss is 0; its gradient is 0 x NaN = NaN like autograd's, which
+                                             # seeds NaN into env 1's adjoint (scrubbed to 0 at the stores, as the reference's remove_nan does)
     outseq = torch.zeros(bs, F, dtype=torch.bool, device=dev)
     outseq[2, 3:] = True                     # env 2: frames 3.. belong to another clip
     tgt = tgt.contiguous().requires_grad_(True)
@@ -901,7 +905,10 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     # the seeds the adjoint kernel builds for itself = what autograd computed for adj_body_qs, to 1e-6 ...
     tl = out[5]
     seed = tl["seed_pos"].view(F, bs, nb, 7) * (tl["scale"].t() * (wt / nb))[:, :, None, None]
-    assert float((seed.view_as(ref_seed) - ref_seed).abs().max()) <= 1e-6 * float(ref_seed.abs().max())
+    nan_seed = ref_seed.isnan()
+    assert int(nan_seed.sum()) == 1 and torch.equal(seed.view_as(ref_seed).isnan(), nan_seed)    # the z of body 5, env 1, frame 4
+    ref_seed = ref_seed.nan_to_num(nan=0.0)
+    assert float((seed.view_as(ref_seed).nan_to_num(nan=0.0) - ref_seed).abs().max()) <= 1e-6 * float(ref_seed.abs().max())
     # ... and the gradients they give, to 1e-4 of each tensor's max: the two seed tensors differ in their last bits (another order of
     # the scalings), and a 70-step adjoint amplifies that (tests/test_gpu_tight.py: ONE ulp on a stored Laikago state moves these
     # gradients by ~1e-2 over 100 steps); measured 8e-6 (Laikago), 2e-7 (human)
@@ -910,8 +917,10 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
         sc = float(b.abs().max())
         print("   %-18s fused vs torch sequence: %.1e of the tensor's max" % (k, float((a - b).abs().max()) / (sc + 1e-30)))
         assert float((a - b).abs().max()) <= 1e-4 * sc + 1e-30, (k, float((a - b).abs().max()), sc)
-    assert float((tgt.grad - ref_tgt).abs().max()) <= 1e-6 * float(ref_tgt.abs().max())
-    assert float(tgt.grad[3, 2:].abs().max()) == 0 and float(tgt.grad[2, 3:].abs().max()) == 0 and float(tgt.grad[1, 4, 5].abs().max()) == 0
+    assert torch.equal(tgt.grad.isnan(), ref_tgt.isnan()) and int(ref_tgt.isnan().sum()) == 1 and bool(tgt.grad[1, 4, 5, 2].isnan())
+    assert float((tgt.grad.nan_to_num(nan=0.0) - ref_tgt.nan_to_num(nan=0.0)).abs().max()) <= 1e-6 * float(ref_tgt.nan_to_num(nan=0.0).abs().max())
+    assert float(tgt.grad[3, 2:].abs().max()) == 0 and float(tgt.grad[2, 3:].abs().max()) == 0
+    assert float(t["q_init"].grad.view(bs, -1)[1].abs().max()) == 0, "the NaN seed spreads over env 1 and is scrubbed: that env's gradient is dropped"
     # other terms may still reach the poses: adj_pos / adj_vel rows are ADDED to the loss seeds
     ap = torch.from_numpy(inp["adj_pos"][:1].repeat(F, 0)).to(dev).contiguous()
     av = torch.from_numpy(inp["adj_vel"][:1].repeat(F, 0)).to(dev).contiguous()
@@ -922,11 +931,15 @@ def test_traj_loss_inside_the_rollout_equals_forwardwarp_se3_loss_reduce_loss(na
     g_adj = dm.rollout_backward(bs, T, inp["dt"], *ins, f2s, out[4], ap, av)
     # the seeds pd_rollout_backward_traj_loss built on the device for that last sweep = autograd's adj_body_qs, and no twist seeds
     work = out[5]["work"]
-    assert float((work[: F * bs * nb * 7].view_as(ref_seed) - ref_seed).abs().max()) <= 1e-6 * float(ref_seed.abs().max())
+    assert torch.equal(work[: F * bs * nb * 7].view_as(ref_seed).isnan(), nan_seed)
+    assert float((work[: F * bs * nb * 7].view_as(ref_seed).nan_to_num(nan=0.0) - ref_seed).abs().max()) <= 1e-6 * float(ref_seed.abs().max())
     assert float(work[F * bs * nb * 7:].abs().max()) == 0
+    keep = torch.ones(bs, dtype=torch.bool, device=dev); keep[1] = False   # (env 1: NaN seed => its gradient is dropped whenever the loss seeds are in)
+    envs = lambda x, k: (x.reshape(x.shape[0], bs, -1) if GRAD_LEAD[k] else x.reshape(1, bs, -1))[:, keep]
     for k in g_both:
-        s_ = g_seed[k] + g_adj[k]
-        assert float((g_both[k] - s_).abs().max()) <= 2e-4 * float(s_.abs().max()) + 1e-30, k   # linear in the seeds (fp32 sums in another order; measured 3e-5)
+        s_ = envs(g_seed[k] + g_adj[k], k)
+        assert float((envs(g_both[k], k) - s_).abs().max()) <= 2e-4 * float(s_.abs().max()) + 1e-30, k   # linear in the seeds (fp32 sums in another order; measured 3e-5)
+        assert float(envs(g_both[k], k).abs().max()) > 0, k
 
 
 @pytest.mark.parametrize("name,bs", [("laikago", 37), ("human", 9), ("laikago", 6700), ("laikago", 2100)])

@@ -309,3 +309,54 @@ def test_training_iterations_hold_no_device_memory(dev):
     finally:
         for cls, f in originals.items():
             cls.forward = f
+
+
+def _run_iterations(n_iter, capture, skip_zeroed=True, seq="mi-pace", eval_between=False):
+    model, opts = _model(seq, "graph")
+    model.skip_zeroed_mlps = skip_zeroed
+    model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"])
+    if capture:
+        assert model.capture_iteration(validate=True), "the captured iteration must replay bit for bit (capture_iteration validates itself)"
+    np.random.seed(321)
+    losses = []
+    for it in range(n_iter):
+        if eval_between and it == n_iter // 2:   # main.py's evaluation pass in between: another window shape, another env, then back
+            model.reinit_envs(1, frames_per_wdw=model.total_frames, is_eval=True)
+            with torch.no_grad():
+                model.forward(frame_start=torch.zeros(1, dtype=torch.long, device=model.device))
+            model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"], is_eval=False)
+        model.set_progress(it)
+        out = model.iteration()
+        losses.append(torch.stack([out[k].detach() for k in sorted(out)]).clone())
+        model.update()
+    params = {n: p.detach().clone() for n, p in model.named_parameters()}
+    return torch.stack(losses).cpu(), params, model
+
+
+def test_captured_iteration_is_bit_identical_to_eager(dev):
+    """forward() + backward() of the reference's training iteration (main.py:96-103; 10 envs x 760 steps, 24 frames)
+    replayed as ONE HIP graph (phys_model.capture_iteration / iteration; main.py's default) against the eager path: every loss term of
+    20 iterations and every parameter after them BIT FOR BIT -- with the evaluation pass of main.py (another window shape and env)
+    in between, after which the graph must still be the one in use."""
+    le, pe, _ = _run_iterations(20, capture=False, eval_between=True)
+    lg, pg, mg = _run_iterations(20, capture=True, eval_between=True)
+    assert mg._graph is not None and mg._graph["replays"] == 20
+    assert torch.equal(le, lg), float((le - lg).abs().max())
+    assert all(torch.equal(pe[n], pg[n]) for n in pe)
+    assert bool(torch.isfinite(le).all()) and float(le[-1, -1]) != float(le[0, -1])   # the optimisation moves
+    # a changed loss weight is baked into the captured graph: iteration() must notice and run eagerly instead of replaying stale weights
+    mg.opts["traj_wt"] = mg.opts["traj_wt"] * 2
+    n = mg._graph["replays"]
+    mg.iteration(); mg.update()
+    assert mg._graph["replays"] == n
+
+
+def test_skipping_the_two_zeroed_mlps_changes_no_bit(dev):
+    """torque_mlp / residual_f_mlp: the reference evaluates them and multiplies the outputs by zero (dp_model.py:526-536).  phys_model
+    skips both by default (zeros in, exactly-zero gradients attached); evaluated as the reference does: the same losses and the same
+    parameters -- including the two MLPs' own, which only see AdamW's weight decay either way."""
+    la, pa, _ = _run_iterations(6, capture=False, skip_zeroed=True)
+    lb, pb, _ = _run_iterations(6, capture=False, skip_zeroed=False)
+    assert torch.equal(la, lb)
+    assert all(torch.equal(pa[n], pb[n]) for n in pa)
+    assert any(n.startswith("torque_mlp") for n in pa)
