@@ -133,15 +133,51 @@ def self_launch(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # Poll ALL children: a rank that dies early (no GPU of its own, RCCL failure) leaves the others blocked in init_process_group until
+    # the c10d timeout -- once any rank has exited non-zero the rest are terminated instead of waited for.  Rank 0's stdout is drained by
+    # a thread so that a full pipe can never block it.
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         print("bench.py: ranks failed (rank, rc): %s" % bad, file=sys.stderr)
         return 1
     return 0
+
+
+def device_identity(dev):
+    """what tells two GPUs apart: UUID and PCI address of this rank's device (whatever of it this torch build exposes)"""
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"index": dev.index, "name": p.name}
+    for k in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"):
+        v = getattr(p, k, None)
+        if v is not None:
+            ident[k] = str(v)
+    return ident
 
 
 def main():
@@ -196,6 +232,15 @@ def main():
         one = torch.ones(1, dtype=torch.float64, device=red_dev)  # how many ranks the collective really spans
         dist.all_reduce(one, op=dist.ReduceOp.SUM)
         ranks_seen = int(one.item())
+    # which DEVICES the ranks run on: a scaling line must prove N distinct GPUs
+    devices_seen = [device_identity(dev)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices_seen[0])
+        devices_seen = gathered
+        keys = {tuple(sorted((k, v) for k, v in d.items() if k not in ("index", "name"))) or ("index", d["index"]) for d in devices_seen}
+        if len(keys) != world and not os.environ.get("PPR_BENCH_SHARE_GPU"):
+            raise SystemExit("bench.py: %d ranks but %d distinct GPUs (%s); one process per GPU" % (world, len(keys), devices_seen))
 
     from diffphys_amd import hip_backend, robots, synth
 
@@ -392,6 +437,8 @@ def main():
             "n_gpus": world,
             "collective_backend": backend,   # "nccl" (= RCCL) | "gloo" (RCCL could not come up) | null at N = 1: barrier + MAX only
             "ranks_seen": ranks_seen,        # all-reduced count of ranks behind that backend
+            "devices_seen": devices_seen,    # all-gathered identity (UUID / PCI address) of each rank's GPU: N distinct unless PPR_BENCH_SHARE_GPU (a test hook)
+            "devices_distinct": len({json.dumps({k: v for k, v in d.items() if k not in ("index", "name")} or d, sort_keys=True) for d in devices_seen}),
             "launcher": "self" if os.environ.get("PPR_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "none"),
             "steps": args.steps,
             "warmup": args.warmup,
@@ -435,6 +482,11 @@ def main():
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --steps 10`), NOT measured in "
                                    "this run" % prof.get("tag", "pmc_summary.json")) if (same_cfg and pb) else None,
                 "avg_launch_ms": bwd_ms,
+                # the event pass against the timed region: its forward + adjoint launch durations / the timed ms per step.  Above 1 = the
+                # event pass runs slower than the timed blocks (the event records sit between the launches), i.e. `frac` UNDERSTATES the
+                # kernel by about that factor; pair_frac_timed = the whole pair's algorithmic bytes / the TIMED step against 8 TB/s
+                "event_pass_over_timed": (fwd_ms + bwd_ms) / (elapsed / args.steps * 1e3),
+                "pair_frac_timed": bs * T * (bf + bb) / (elapsed / args.steps) / HBM_PEAK_BYTES,
                 "algorithmic_bytes_per_env_step": bb,
                 "secondary": secondary(geo_b, pb),
                 "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,

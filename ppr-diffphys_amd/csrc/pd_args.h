@@ -48,7 +48,10 @@ inline int pd_groups_per_wg(int n_groups, int cu_count) {
   return g < 1 ? 1 : (g > PD_BWAVES ? PD_BWAVES : g);
 }
 inline int pd_kernel_variant(int kind, int jt, int n_groups, int cu_count, int variant) {
-  if (kind == PD_K_ROLLOUT_FWD) return (pd_split(jt) || n_groups <= PD_BWAVES * cu_count) ? PD_KV_FWD_SPLIT : PD_KV_FWD_UNSPLIT;
+  // (the unsplit forward exists for compound-only robots alone: the generic instantiation, all joint types in one kernel, needs 7-14
+  // VGPRs more than a wave may have at two waves per SIMD -- scratch traffic in its step loop -- so generic robots take the split kernel
+  // at every batch size: no shipped rollout kernel spills vector registers, round 5)
+  if (kind == PD_K_ROLLOUT_FWD) return (jt != PD_JT_COMPOUND || n_groups <= PD_BWAVES * cu_count) ? PD_KV_FWD_SPLIT : PD_KV_FWD_UNSPLIT;
   if (kind == PD_K_ROLLOUT_BWD) {
 #ifdef PD_EXPERIMENT  // rejected variants (pd_debug_set_variant), timing builds only
     if (pd_split(jt) && variant == 3) return PD_KV_BWD_3ROLE;

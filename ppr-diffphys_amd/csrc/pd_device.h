@@ -441,7 +441,7 @@ PD_DEV void joint_force_adj(float q, float qd, float target, float ke, float kd,
 // the |second angle| < pi/2 range in which quat_decompose is a chart at all.  Stated in INTEGRATION.md section 4.)
 PD_DEV void quat_decompose(qt q, float *ang, v3 &c0, v3 &c1, v3 &c2) {  // :245-258; also returns the rotated basis
   c0 = qrot(q, V3(1, 0, 0)); c1 = qrot(q, V3(0, 1, 0)); c2 = qrot(q, V3(0, 0, 1));
-  ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
+  ang[0] = -atan2_any(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2_any(c1.x, c0.x);
 }
 PD_DEV void quat_decompose(qt q, float *ang) {
   v3 c0, c1, c2;
@@ -454,7 +454,9 @@ PD_DEV void quat_decompose_cols(qt q, float *ang, v3 &c0, v3 &c1, v3 &c2) {
   c0 = V3(s + q.x * tx, q.z * tw + q.y * tx, q.z * tx - q.y * tw);
   c1 = V3(q.x * ty - q.z * tw, s + q.y * ty, q.x * tw + q.z * ty);
   c2 = V3(q.y * tw + q.x * tz, q.y * tz - q.x * tw, s + q.z * tz);
-  ang[0] = -atan2f(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2f(c1.x, c0.x);
+  // (round 5: atan2_any, pd_math.h, instead of libdevice's atan2f: the same function to 2e-7 relative, ~20 instructions less per call on the
+  // one wave whose instruction stream IS the step of a compound robot's small-batch rollout)
+  ang[0] = -atan2_any(c2.y, c2.z); ang[1] = -asin_c(-c2.x); ang[2] = -atan2_any(c1.x, c0.x);
 }
 PD_DEV void quat_decompose_adj(qt q, v3 c0, v3 c1, v3 c2, const float *g, qt &adj_q) {  // c* = the rotated basis of the forward pass
   float gphi = -g[0], gth = -g[1], gpsi = -g[2];
@@ -533,9 +535,10 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     v3 b0, b1, b2;
     quat_decompose_cols(q_pc, ang, b0, b1, b2);
     float s0, c0;
-    sincosf(ang[0] * 0.5f, &s0, &c0);
+    sincos_half_pi(ang[0] * 0.5f, s0, c0);  // |ang / 2| <= pi / 2: no range reduction needed (round 5; was sincosf, ~25 instructions more each)
     const v3 ax1 = V3(0.f, 2.0f * c0 * c0 - 1.0f, s0 * (2.0f * c0));
-    qt q_1 = q_axis_angle(ax1, ang[1]);
+    float2 sc1_;
+    qt q_1 = q_axis_angle_sc(ax1, ang[1], sc1_);
     q_1.x = 0.f;
     const qt q10 = Q4(q_1.w * s0, c0 * q_1.y + q_1.z * s0, c0 * q_1.z - q_1.y * s0, q_1.w * c0);
     const v3 ax2 = V3(q10.y * (2.0f * q10.w) + q10.x * (2.0f * q10.z), q10.y * (2.0f * q10.z) - q10.x * (2.0f * q10.w),
@@ -559,9 +562,10 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     quat_decompose(q_pc, ang);
     v3 ax[3];
     ax[0] = V3(1, 0, 0);
-    qt q_0 = q_axis_angle(ax[0], ang[0]);
+    float2 sc_;  // (the decomposition's angles lie in [-pi, pi]: half of one needs no range reduction)
+    qt q_0 = q_axis_angle_sc(ax[0], ang[0], sc_);
     ax[1] = qrot(q_0, V3(0, 1, 0));
-    qt q_1 = q_axis_angle(ax[1], ang[1]);
+    qt q_1 = q_axis_angle_sc(ax[1], ang[1], sc_);
     ax[2] = qrot(qmul(q_1, q_0), V3(0, 0, 1));
     qt q_w = qmul(j.q_p, c.q_off);
     t_total = V3(0, 0, 0);

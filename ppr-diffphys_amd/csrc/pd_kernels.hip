@@ -2522,15 +2522,16 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
           return hipErrorInvalidValue;
         }
       }
+      // (unsplit: compound-only robots above 4 x CUs env groups -- pd_kernel_variant; no other joint mix has that instantiation)
       if (((const RolloutArgs *)args)->loss_target) {  // trajectory loss at the frame states (pd_rollout_forward_traj_loss)
-        if (cfg.kernel == PD_KV_FWD_SPLIT)
+        if (cfg.kernel == PD_KV_FWD_SPLIT || JT != PD_JT_COMPOUND)
           hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
         else
-          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-      } else if (cfg.kernel == PD_KV_FWD_SPLIT)
+          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, JT != PD_JT_COMPOUND, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+      } else if (cfg.kernel == PD_KV_FWD_SPLIT || JT != PD_JT_COMPOUND)
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
       else
-        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, JT != PD_JT_COMPOUND>), g, t, lds, st, m, *(const RolloutArgs *)args);
       break;
     case PD_K_ROLLOUT_BWD:
       if constexpr (pd_split(JT)) {
@@ -2587,13 +2588,13 @@ template <int JT>
 static hipError_t set_lds_jt(int bytes) {
   hipError_t e;
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT)>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, JT != PD_JT_COMPOUND>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   }
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, pd_split(JT), true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, JT != PD_JT_COMPOUND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {

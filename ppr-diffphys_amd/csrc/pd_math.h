@@ -111,6 +111,12 @@ PD_DEV float atan2_pos(float y, float x) {
   r = x < 0.0f ? 3.14159265359f - r : r;
   return (x != x || y != y) ? x + y : r;
 }
+// atan2 for either sign of y: +-atan2_pos(|y|, x), in [-pi, pi] (atan2(+-0, negative) = +pi: the sign of a zero is not defined in this
+// library, Makefile).  ~34 instructions where libdevice's atan2f executes ~55; used by the compound joint's angle decomposition.
+PD_DEV float atan2_any(float y, float x) {
+  const float r = atan2_pos(fabsf(y), x);
+  return y < 0.0f ? -r : r;
+}
 PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq_dw) {
 #if PD_POLICY == 1  // the reference's text: twist = normalize((axis da, w)), q = 2 acos(twist.w) sign(axis . twist.xyz); adjoint through
   {                              // acos' (guarded: 0 at |twist.w| = 1) and the normalisation

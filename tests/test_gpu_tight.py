@@ -424,14 +424,16 @@ def test_against_frozen_bits(name, dev):
     from diffphys_amd import hip_backend, robots, synth
 
     refs = {}
-    for tag in ("r01", "r02", "r03", "r03b"):
+    for tag in ("r01", "r02", "r03", "r03b", "r05"):
         path = os.path.join(GOLDEN, "%s_bits_%s.npz" % (tag, name))
         if os.path.exists(path):
             with np.load(path) as z:
                 refs[tag] = {k: z[k] for k in z.files}
     if not refs:
         pytest.skip("no bit fixtures recorded")
-    newest = [t for t in ("r03b", "r03") if t in refs][0] if ("r03b" in refs or "r03" in refs) else None
+    # r05 (human / quad only): the compound joint's angle decomposition moved from libdevice's atan2f / sincosf to the library's own
+    # bounded-range forms (pd_math.h atan2_any, sincos_half_pi): the same functions to 2e-7, other bits
+    newest = ([t for t in ("r05", "r03b", "r03") if t in refs] or [None])[0]
     tpl = robots.load_template(name)
     dm = hip_backend.DeviceModel(tpl)
     dm.set_kernel_family(1)   # the fixtures pin the lane-per-body kernels (these small batches would take the quad-lane ones by default)
