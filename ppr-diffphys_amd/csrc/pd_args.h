@@ -26,8 +26,8 @@ enum { PD_K_ROLLOUT_FWD = 0, PD_K_ROLLOUT_BWD = 1, PD_K_FK_FWD = 2, PD_K_FK_BWD 
 //   forward : revolute-only robots always; other joint mixes while a CU holds at most one full workgroup (the latency
 //             regime: human at 1024 envs -32 %), else the unsplit kernel packs twice as many body waves per SIMD
 //   adjoint : revolute-only robots the 2-role kernel (body + contact wave); other joint mixes the 2-role k_rollout_bwd3
-//             (integrate + contacts wave, joint wave).  The rejected variants (3-role, early hand-over, unsplit compound adjoint:
-//             DESIGN.md section 4) are compiled and reachable in -DPD_EXPERIMENT builds only.
+//             (integrate + contacts wave, joint wave).  The variants that were measured and rejected (3-role, early hand-over, unsplit
+//             compound adjoint: EXPERIMENTS.md) left the sources in round 5; `git log` has them (commit 837bfbd and before).
 constexpr bool pd_split(int jt) { return jt == PD_JT_REVOLUTE; }
 // the specialised instantiations (one joint type) are only launched for PLAIN models: non-FREE joints all hang on a body, child
 // joint frames are not rotated (pd_host.hip)
@@ -47,18 +47,12 @@ inline int pd_groups_per_wg(int n_groups, int cu_count) {
   int g = cu_count > 0 ? (n_groups + cu_count - 1) / cu_count : PD_BWAVES;
   return g < 1 ? 1 : (g > PD_BWAVES ? PD_BWAVES : g);
 }
-inline int pd_kernel_variant(int kind, int jt, int n_groups, int cu_count, int variant) {
+inline int pd_kernel_variant(int kind, int jt, int n_groups, int cu_count) {
   // (the unsplit forward exists for compound-only robots alone: the generic instantiation, all joint types in one kernel, needs 7-14
   // VGPRs more than a wave may have at two waves per SIMD -- scratch traffic in its step loop -- so generic robots take the split kernel
   // at every batch size: no shipped rollout kernel spills vector registers, round 5)
   if (kind == PD_K_ROLLOUT_FWD) return (jt != PD_JT_COMPOUND || n_groups <= PD_BWAVES * cu_count) ? PD_KV_FWD_SPLIT : PD_KV_FWD_UNSPLIT;
   if (kind == PD_K_ROLLOUT_BWD) {
-#ifdef PD_EXPERIMENT  // rejected variants (pd_debug_set_variant), timing builds only
-    if (pd_split(jt) && variant == 3) return PD_KV_BWD_3ROLE;
-    if (pd_split(jt) && variant == 1) return PD_KV_BWD_2ROLE_EARLY;
-    if (!pd_split(jt) && variant == 9) return PD_KV_BWD_UNSPLIT;
-#endif
-    (void)variant;
     return pd_split(jt) ? PD_KV_BWD_2ROLE : PD_KV_BWD3_2ROLE;
   }
   return PD_KV_FK;
@@ -89,10 +83,6 @@ struct RolloutArgs {
   float loss_rot_ratio;
   float *loss_seed_pos, *loss_seed_gt, *loss_table;
   unsigned long long *dbg;  // diagnostic builds only (-DPD_STAMPS): per-phase cycle sums, [block][8]
-#ifdef PD_EXPERIMENT        // timing builds only (make experiment): rejected variants, DESIGN.md section 4 / EXPERIMENTS.md
-  int own_joint;            // adjoint, 2-role kernel: the body wave recomputes its joint's state-only half itself (measured: slower)
-  int variant;              // pd_debug_set_variant: which adjoint kernel a revolute robot runs
-#endif
 };
 
 

@@ -315,11 +315,7 @@ struct ContactOut { v3 t, f; };
 PD_DEV bool contact_point_fwd(const float *r, float4 cv, float4 P, float4 mat, ContactOut &o) {
   const v3 p = ld3(r), w = ld3(r + 7), v = ld3(r + 10), rc = ld3(r + 13);
   const qt q = ld4(r + 3);
-#ifdef PD_AB_QROTY
-  const float c = (p.y + qrot_y(q, V3(P.x, P.y, P.z))) - P.w;
-#else
   const float c = contact_height(cv, P);
-#endif
   const v3 rp = qrot(q, V3(P.x, P.y, P.z));
   const v3 cp = V3(p.x + rp.x, c, p.z + rp.z);
   v3 rr = cp - (p + rc);
@@ -356,11 +352,7 @@ PD_DEV bool contact_point_adj(const float *r, float4 cv, float4 P, float4 mat, v
     com = qrot_inv(q, rc);  // body-frame COM back from the staged rc = rot(q, com): no table read on the hit path
     cp = (p + qrot(q, cpt)) - V3(0.f, P.w, 0.f);
   }
-#ifdef PD_AB_QROTY
-  cp.y = (p.y + qrot_y(q, cpt)) - P.w;
-#else
   cp.y = contact_height(cv, P);  // the height decides "touching": exactly the forward pass's arithmetic
-#endif
   float c = cp.y;
   if (c > 0.0f) return false;
   v3 rr = cp - (p + rc);

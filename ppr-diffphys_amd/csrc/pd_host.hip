@@ -318,18 +318,14 @@ static void build_quad(pd_model *m) {
   m->quad = new pd_model::Quad{tmp.blob, tmp.dev, tmp.lds_tables, tmp.jt};
 }
 
-static int g_variant = 0;  // -DPD_EXPERIMENT builds only (pd_debug_set_variant); the shipped launch_cfg always sees 0
-static int g_groups = 0;   // -DPD_EXPERIMENT / -DPD_STAMPS builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
-#ifdef PD_EXPERIMENT
-static int g_own_joint = -1;  // pd_debug_set_own_joint
-#endif
+static int g_groups = 0;   // -DPD_STAMPS diagnostic builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
 
 // Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
 static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
   const PdDevModel &d = m->dev;
   const int epw = 64 / m->segw, n_groups = (n_envs + epw - 1) / epw;
   PdLaunchCfg c{};
-  c.kernel = pd_kernel_variant(kind, m->jt, n_groups, d.cu_count, g_variant);
+  c.kernel = pd_kernel_variant(kind, m->jt, n_groups, d.cu_count);
   c.roles = pd_variant_roles(c.kernel);
   c.groups = kind <= PD_K_ROLLOUT_BWD ? (g_groups ? g_groups : pd_groups_per_wg(n_groups, d.cu_count)) : PD_BWAVES;
   c.nblocks = (n_groups + c.groups - 1) / c.groups;
@@ -698,10 +694,6 @@ static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float d
   a.frame_of_step = fos; a.ws = const_cast<float *>(ws); a.adj_pos = adj_pos; a.adj_vel = adj_vel;
   a.g_q_init = g_q_init; a.g_qd_init = g_qd_init; a.g_torques = g_torques; a.g_res_f = g_res_f; a.g_refs = g_refs;
   a.g_ke = g_ke; a.g_kd = g_kd; a.g_inv_mass = g_inv_mass; a.g_inertia = g_inertia; a.g_inv_inertia = g_inv_inertia; a.dbg = g_dbg;
-#ifdef PD_EXPERIMENT
-  a.variant = g_variant;
-  a.own_joint = g_own_joint > 0 ? 1 : 0;  // rev_forward on the body wave: measured slower, experiment switch only
-#endif
   a.hitlog = (int *)(const_cast<float *>(ws) + (size_t)nsteps * PD_TRAJ_FLOATS * (size_t)bs * m->nb);
   hipStream_t st = (hipStream_t)stream;
   timing_begin(m, 1, st);
@@ -768,16 +760,10 @@ int pd_fk_backward(const pd_model *m, int n, const float *joint_q, const float *
   return e == hipSuccess ? 0 : hip_fail(e, "fk_backward launch");
 }
 
-#if defined(PD_STAMPS) || defined(PD_EXPERIMENT)
-// Diagnostic builds only (never in the shipped library, not in the public header).
+#ifdef PD_STAMPS
+// Diagnostic build only (make stamps; never in the shipped library, not in the public header).
 // buffer for the in-kernel phase stamps ([blocks*waves][16] u64)
 void pd_debug_set_buffer(void *dev) { g_dbg = (unsigned long long *)dev; }
-// adjoint kernel of revolute-only robots for A/B timing (scripts/gpu_time.py): 0 = shipped (2-role, hand-over A after
-// integrate_adj), 1 = 2-role with the early hand-over, 3 = 3-role (k_rollout_bwd3<3>); other joint mixes: 9 = the unsplit kernel
-void pd_debug_set_variant(int v) { g_variant = v; }
-#ifdef PD_EXPERIMENT
-void pd_debug_set_own_joint(int v) { g_own_joint = v; }
-#endif
 void pd_debug_set_groups(int g) { g_groups = g < 0 ? 0 : (g > PD_BWAVES ? PD_BWAVES : g); }
 #endif
 

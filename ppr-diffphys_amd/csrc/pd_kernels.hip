@@ -1271,14 +1271,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   const bool is_body = env_ok && l < m.nb;
   const int b = l < m.nb ? l : m.nb - 1;
   const int nb = m.nb, N = a.bs * nb;
-  // own_joint (rejected, -DPD_EXPERIMENT timing builds only): the body wave recomputes the state-only half of its joint's adjoint
-  // (rev_forward) itself instead of taking it from the contact wave -- measured slower at every batch size; a constant false in
-  // the shipped library, so none of its branches exist there
-#ifdef PD_EXPERIMENT
-  const bool own_joint = a.own_joint != 0;
-#else
-  constexpr bool own_joint = false;
-#endif
+  // (the state-only half of a revolute joint's adjoint, rev_forward, comes from the contact wave through LDS; the body wave recomputing it
+  // itself was measured slower at every batch size -- EXPERIMENTS.md round 3 -- and is gone from the sources since round 5)
 
   SweepTables tabs;
   const int env_stride = m.env_lds_floats + (SPLIT ? 2 * m.env_lds_jc : 0);
@@ -1324,7 +1318,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     //           summed per body in hit order by a lane-per-component pass
     // A log that did not fit (count -1) or holds more hits than the segment has lanes takes the generic sweep.
     STAMP_DECL;
-    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE && !own_joint;
+    const bool rev = is_body && c.type == PD_JOINT_REVOLUTE;
     const size_t qd_off = (size_t)ec * m.nqd + c.qdstart;
     const float ke1 = rev ? a.target_ke[qd_off] : 0.f, kd1 = rev ? a.target_kd[qd_off] : 0.f;
     const int lq = l < PD_HITLOG - 1 ? l : PD_HITLOG - 2;
@@ -1384,7 +1378,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       const int nh = fast && env_ok ? cnt_c : 0;
       STAMP(7);
       // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
-      if (!own_joint) pair_signal(sig + 1, a.nsteps - step);
+      pair_signal(sig + 1, a.nsteps - step);
       pair_wait(sig, a.nsteps - step);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for these contact adjoints
       STAMP(9);
@@ -1780,7 +1774,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
     }
     if (SPLIT) {
-      if (!own_joint) pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
+      pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
     } else {
       WAVE_SYNC();
     }
@@ -1793,16 +1787,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (is_body && c.type != PD_JOINT_FREE) {
       v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
       if ((SPLIT && pd_parented(JT)) || c.parent >= 0) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-      if (SPLIT)  // revolute only: the state-only half comes from the contact wave, or (own_joint) is recomputed here
+      if (SPLIT)  // revolute only: the state-only half comes from the contact wave
       {
-        RevCache R;
-        if (own_joint) {  // wave-uniform (experiment builds only)
-          WAVE_SYNC();      // the parent's record was staged by another lane of this wave
-          const float *pr = rec + (pd_parented(JT) || c.parent >= 0 ? c.parent : b) * PD_REC;
-          R = rev_forward<pd_parented(JT)>(m, c, s.r, s.w, ld3(pr), ld4(pr + 3), ld3(pr + 7), tgt[0], act[0], ke[0], kd[0]);
-        } else {
-          R = rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC);
-        }
+        const RevCache R = rev_cache_load(jc + (step & 1) * m.env_lds_jc + b * PD_JC);
         rev_adjoint<pd_parented(JT)>(m, c, s, rc, rec, R, tgt[0], ke[0], kd[0], adj_t0, adj_f0, gp_t, gp_f, ga, par, aR, a_tgt[0], a_act[0], a_ke[0], a_kd[0]);
       }
       else
@@ -1917,14 +1904,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 //   C  contact wave   : adjoint of eval_body_contacts for the logged hits, one lane per hit (as in the 2-role kernel)
 // Per step the critical chain is  phase 1 (I) -> max(rev_adjoint (J), contacts (C), phase 2 (I)) -> gather (I)  instead of
 // integrate_adj + rev_adjoint + gather on one wave.  Arithmetic and summation order are those of the 2-role kernel.
-#ifdef PD_ROLE_PROBE  // diagnostic (scripts/dump_isa.sh): compile ONE role without the register cap to see what it needs
-#ifndef PD_ROLE_PROBE_BOUND
-#define PD_ROLE_PROBE_BOUND 256
-#endif
-#define PD_BWD3_BOUNDS(roles) PD_ROLE_PROBE_BOUND
-#else
 #define PD_BWD3_BOUNDS(roles) ((roles) * PD_BWAVES * 64)
-#endif
 // ROLES = 3: I, C, J waves (<= 168 VGPRs each).  ROLES = 2: the integrate wave also replays the contacts (between its phase 2
 // and the wait for the joint wave) -- compound-joint robots, whose joint adjoint needs more than 168 registers but whose
 // box contacts are a handful of points: two waves per env group, <= 256 VGPRs each.
@@ -1936,12 +1916,8 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   static_assert(ROLES == 2 || ROLES == 3, "two or three roles");
   const int bw = (int)blockDim.x / (64 * ROLES);  // env groups per workgroup (host's choice per launch)
   const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
-#ifdef PD_ROLE_PROBE
-  const int role = PD_ROLE_PROBE, wave = wave_id % bw;
-#else
   // 0: I (+ contacts when ROLES == 2), 1: C, 2: J   (wave-uniform)
   const int role = ROLES == 3 ? wave_id / bw : (wave_id / bw ? 2 : 0), wave = wave_id % bw;
-#endif
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
@@ -2535,16 +2511,6 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
       break;
     case PD_K_ROLLOUT_BWD:
       if constexpr (pd_split(JT)) {
-#ifdef PD_EXPERIMENT  // rejected variants, kept for A/B timing builds only
-        if (cfg.kernel == PD_KV_BWD_3ROLE) {
-          hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 3>), g, t, lds, st, m, *(const RolloutArgs *)args);
-          break;
-        }
-        if (cfg.kernel == PD_KV_BWD_2ROLE_EARLY) {
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-          break;
-        }
-#endif
         if (cfg.kernel == PD_KV_BWD_QUAD) {
           if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
             hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
@@ -2555,12 +2521,6 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
         }
         hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, true, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else {
-#ifdef PD_EXPERIMENT
-        if (cfg.kernel == PD_KV_BWD_UNSPLIT) {  // the unsplit round-1 kernel
-          hipLaunchKernelGGL((k_rollout_bwd<PD_SEGW, JT, false>), g, t, lds, st, m, *(const RolloutArgs *)args);
-          break;
-        }
-#endif
         hipLaunchKernelGGL((k_rollout_bwd3<PD_SEGW, JT, 2>), g, t, lds, st, m, *(const RolloutArgs *)args);
       }
       break;
@@ -2600,15 +2560,8 @@ static hipError_t set_lds_jt(int bytes) {
     if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
       if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     }
-#ifdef PD_EXPERIMENT
-    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-#endif
   } else {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd3<PD_SEGW, JT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-#ifdef PD_EXPERIMENT
-    if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-#endif
   }
 #if PD_POLICY == 0
   if ((e = hipFuncSetAttribute((const void *)k_fk<PD_SEGW, JT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;

@@ -49,12 +49,6 @@ PD_DEV v3 qrot(qt q, v3 v) {
   v3 u = qvec(q);
   return v * (2.0f * q.w * q.w - 1.0f) + cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
 }
-// y component of qrot(q, v), the same expression: where a branch of the forward pass hangs on it (a contact point's height),
-// code that otherwise rotates by rotm(q) takes the decision from this, bit for bit like the forward pass
-PD_DEV float qrot_y(qt q, v3 v) {
-  v3 u = qvec(q);
-  return v.y * (2.0f * q.w * q.w - 1.0f) + (u.z * v.x - u.x * v.z) * (2.0f * q.w) + u.y * (2.0f * dot(u, v));
-}
 PD_DEV v3 qrot_inv(qt q, v3 v) {
   v3 u = qvec(q);
   return v * (2.0f * q.w * q.w - 1.0f) - cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
@@ -289,20 +283,8 @@ PD_DEV v3 mat_vec(const float *M, v3 a) {
 PD_DEV v3 matT_vec(const float *M, v3 a) {
   return V3(M[0] * a.x + M[3] * a.y + M[6] * a.z, M[1] * a.x + M[4] * a.y + M[7] * a.z, M[2] * a.x + M[5] * a.y + M[8] * a.z);
 }
-#ifdef PD_PK_OUTER  // experiment, NOT taken (EXPERIMENTS.md round 4): the (x, y) columns of each row as one v_pk_fma_f32 -- 33 instructions
-                    // fewer in the adjoint body loop, no re-pairing moves, three VGPRs less, and the Laikago adjoint is 2 % SLOWER
-typedef float pd_pk2 __attribute__((ext_vector_type(2)));
-PD_DEV void add_outer(float *M, v3 a, v3 b) {
-  const pd_pk2 bxy = {b.x, b.y};
-  pd_pk2 r0 = {M[0], M[1]}, r1 = {M[3], M[4]}, r2 = {M[6], M[7]};
-  r0 += bxy * a.x; r1 += bxy * a.y; r2 += bxy * a.z;
-  M[0] = r0.x; M[1] = r0.y; M[3] = r1.x; M[4] = r1.y; M[6] = r2.x; M[7] = r2.y;
-  M[2] += a.x * b.z; M[5] += a.y * b.z; M[8] += a.z * b.z;
-}
-#else
 PD_DEV void add_outer(float *M, v3 a, v3 b) {
   M[0] += a.x * b.x; M[1] += a.x * b.y; M[2] += a.x * b.z;
   M[3] += a.y * b.x; M[4] += a.y * b.y; M[5] += a.y * b.z;
   M[6] += a.z * b.x; M[7] += a.z * b.y; M[8] += a.z * b.z;
 }
-#endif

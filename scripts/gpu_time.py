@@ -9,15 +9,6 @@ from diffphys_amd import robots, synth, hip_backend, dp_model
 
 cfgs = [("laikago", 4096, 16), ("laikago", 4096, 32), ("laikago", 4096, 64), ("laikago", 512, 16), ("laikago", 16384, 16),
         ("human", 1024, 32), ("quad", 8192, 32)]
-# PD_VARIANT=n selects an experimental adjoint kernel (pd_debug_set_variant; 0 = shipped default)
-variant = int(os.environ.get("PD_VARIANT", "0"))
-if hasattr(hip_backend.lib(), "pd_debug_set_variant"):  # `make experiment` builds only (PPR_DIFFPHYS_LIB=..._experiment.so)
-    hip_backend.lib().pd_debug_set_variant(variant)
-    hip_backend.lib().pd_debug_set_groups(int(os.environ.get("PD_GROUPS", "0")))  # env groups per workgroup, 0 = automatic
-    if "PD_OWN_JOINT" in os.environ:
-        hip_backend.lib().pd_debug_set_own_joint(int(os.environ["PD_OWN_JOINT"]))  # adjoint: rev_forward on the body wave (1) / contact wave (0)
-elif variant or os.environ.get("PD_GROUPS"):
-    raise SystemExit("PD_VARIANT / PD_GROUPS need the experiment build (make -C ppr-diffphys_amd/csrc experiment)")
 if len(sys.argv) > 1:
     cfgs = [(a.split(":")[0], int(a.split(":")[1]), int(a.split(":")[2])) for a in sys.argv[1:]]
 dev = torch.device("cuda:0")

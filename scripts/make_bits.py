@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Records what the CURRENT library computes on the committed golden inputs and on the 8-env x 100-step bench-like batch:
-tests/golden/<tag>_bits_<robot>.npz (raw fp32 outputs and gradients), the way scripts/make_r01_bits.py did for the round-1
-library.  tests/test_gpu_tight.py::test_against_round1_bits freezes arithmetic against such fixtures: Laikago against r01;
+tests/golden/<tag>_bits_<robot>.npz (raw fp32 outputs and gradients), the way the round-1 library's outputs were recorded
+(r01_bits_*: from a build of the r01 commit's sources; that one-off script left the tree in round 5).  tests/test_gpu_tight.py::test_against_round1_bits freezes arithmetic against such fixtures: Laikago against r01;
 human / quad against r02 (their forward pass was restructured in round 2 -- same terms without the products with exact
 zeros of identity frames and basis vectors -- and differs from r01 by 1 ulp).  Run on the GPU box; fixtures are data.
 usage: make_bits.py <tag> [robot ...]   ->  gpurun_out/<tag>_bits/"""

@@ -401,8 +401,8 @@ def test_timing_is_per_model_and_launch_info(dev):
 
 @pytest.mark.parametrize("name", ["laikago", "human", "quad"])
 def test_against_frozen_bits(name, dev):
-    """A/B against frozen libraries: tests/golden/<tag>_bits_<robot>.npz hold the raw fp32 outputs of the round-1 kernels (r01,
-    scripts/make_r01_bits.py), of the round-2 kernels (r02, human / quad only) and of this round's (scripts/make_bits.py: r03, and r03b =
+    """A/B against frozen libraries: tests/golden/<tag>_bits_<robot>.npz hold the raw fp32 outputs of the round-1 kernels (r01: a build
+    of the r01 commit's sources), of the round-2 kernels (r02, human / quad only) and of this round's (scripts/make_bits.py: r03, and r03b =
     the same sources built with -fno-signed-zeros, which the library has used since: values equal except where the compiler now folds a
     product into a zero-initialised sum, an ulp here and there) on the golden inputs and on an 8-env x 100-step batch.
 
