@@ -1,7 +1,8 @@
-"""Time-conditioned MLPs that parameterise the control references (out of the hot path: 5 small MLPs on
-<= bs*T scalars).  Same constructor surface as the reference's ``TimeMLPWrapper``
-(/root/reference/diffphys/torch_utils.py:120-180): Fourier features of normalised time, a skip-connected
-MLP trunk of width W and depth D, a linear head and an output scale."""
+"""Time-conditioned MLPs that parameterise the control references (out of the hot path: 5 small MLPs on <= bs*T scalars): the reference's
+``TimeMLPWrapper`` (/root/reference/diffphys/torch_utils.py:116-180) with its lab4d building blocks (diffphys/lab4d_utils.py: PosEmbedding,
+TimeEmbedding, InstEmbedding, BaseMLP, ScaleLayer) restated -- same architecture, parameter names, construction order and initialisation, so
+that the reference's checkpoints load and its initial weights are reproduced; held to the reference's own module by
+tests/test_ref_fixtures.py."""
 import math
 
 import torch
@@ -62,40 +63,149 @@ def _linear(layer, x):
     return _LinearGemmBias.apply(x, layer.weight, layer.bias)
 
 
+class ScaleLayer(nn.Module):
+    """x * scale, the scale a persistent buffer (lab4d_utils.py:321-327 of the reference: it is in the checkpoints)"""
+
+    def __init__(self, scale):
+        super().__init__()
+        self.register_buffer("scale", torch.tensor([float(scale)], dtype=torch.float32))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class _InstCode(torch.autograd.Function):
+    """One instance: every sample reads row 0 of the embedding table.  Forward = an expand; the gradient of the row = the column sums of
+    the upstream gradient, as ONE GEMM (nn.Embedding's backward and torch's column reduction do not survive a HIP-graph replay here)."""
+
+    @staticmethod
+    def forward(ctx, weight, n):
+        ctx.n = n
+        return weight[0].unsqueeze(0).expand(n, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gw = (_ones_row(g.shape[0], g) @ g)
+        return gw, None
+
+
+class PosEmbedding(nn.Module):
+    """x -> (x, sin(2^0 x), cos(2^0 x), sin(2^1 x), cos(2^1 x), ...) per input channel, frequency-major, sin before cos
+    (lab4d_utils.py:11-110 of the reference; its annealing window `alpha` stays -1 = off in this code base but is a persistent buffer)."""
+
+    def __init__(self, in_channels, N_freqs):
+        super().__init__()
+        self.N_freqs, self.in_channels = N_freqs, in_channels
+        self.out_channels = in_channels * (2 * N_freqs + 1)
+        self.register_buffer("freq_bands", 2 ** torch.linspace(0, N_freqs - 1, N_freqs), persistent=False)
+        self.register_buffer("alpha", torch.tensor(-1.0, dtype=torch.float32))
+
+    def forward(self, x):  # (B, in_channels)
+        sig = self.freq_bands[None, :, None] * x[:, None, :]                      # (B, N_freqs, in_channels)
+        bands = torch.stack([torch.sin(sig), torch.cos(sig)], 2)                  # (B, N_freqs, 2, in_channels)
+        return torch.cat([x, bands.reshape(x.shape[0], -1)], -1)
+
+
+class InstEmbedding(nn.Module):
+    """a learnable code per video (lab4d_utils.py:253-318); one video here -> every sample gets row 0"""
+
+    def __init__(self, num_inst, inst_channels):
+        super().__init__()
+        self.num_inst, self.out_channels = num_inst, inst_channels
+        self.mapping = nn.Embedding(num_inst, inst_channels)
+
+    def forward(self, inst_id):
+        if self.num_inst == 1:
+            return _InstCode.apply(self.mapping.weight, inst_id.shape[0])
+        return self.mapping(inst_id)
+
+
+class TimeEmbedding(nn.Module):
+    """frame id -> W features: Fourier features of the frame's normalised time inside its video through `mapping1`, concatenated with
+    the video's instance code, through `mapping2` (lab4d_utils.py:137-229).  Time of frame f of a video [s, e): ((f - s) - (e - s) / 2) /
+    max_video_length * 2 * time_scale; fractional frame ids keep their fraction (the table lookups use floor(f))."""
+
+    def __init__(self, num_freq_t, frame_info, out_channels=128, time_scale=1.0):
+        super().__init__()
+        self.fourier_embedding = PosEmbedding(1, num_freq_t)
+        off = torch.as_tensor(frame_info["frame_offset_raw"]).long()
+        self.frame_offset, self.frame_offset_raw = frame_info["frame_offset"], frame_info["frame_offset_raw"]
+        self.num_vids = len(off) - 1
+        self.max_ts = float((off[1:] - off[:-1]).max())
+        self.time_scale = time_scale
+        fid = torch.arange(0, int(off[-1]))
+        vid = torch.zeros_like(fid)
+        for i in range(self.num_vids):
+            vid = torch.where((fid >= off[i]) & (fid < off[i + 1]), torch.full_like(vid, i), vid)
+        self.register_buffer("raw_fid_to_vid", vid, persistent=False)
+        self.register_buffer("raw_fid_to_vstart", off[vid], persistent=False)
+        self.register_buffer("raw_fid_to_vidlen", off[vid + 1] - off[vid], persistent=False)
+        self.inst_embedding = InstEmbedding(self.num_vids, inst_channels=out_channels)
+        self.mapping1 = nn.Linear(self.fourier_embedding.out_channels, out_channels)
+        self.mapping2 = nn.Linear(2 * out_channels, out_channels)
+
+    def frame_to_tid(self, frame_id):
+        k = frame_id.long()
+        tid_sub = frame_id - self.raw_fid_to_vstart[k]
+        return (tid_sub - self.raw_fid_to_vidlen[k] / 2) / self.max_ts * 2 * self.time_scale
+
+    def forward(self, frame_id):
+        frame_id = frame_id.reshape(-1)
+        inst_id = self.raw_fid_to_vid[frame_id.long()]
+        coeff = _linear(self.mapping1, self.fourier_embedding(self.frame_to_tid(frame_id)[:, None].float()))
+        return _linear(self.mapping2, torch.cat([coeff, self.inst_embedding(inst_id)], -1))
+
+
 class TimeMLPWrapper(nn.Module):
+    """The reference's ``TimeMLPWrapper`` (torch_utils.py:116-180 over lab4d_utils.TimeMLP / BaseMLP / TimeEmbedding): SAME modules in the SAME
+    construction order with the SAME parameter names -- ``time_embedding.{mapping1, mapping2, inst_embedding.mapping}``, ``linear_1 ..
+    linear_D`` (each ``Sequential(Linear, act)``: keys ``linear_k.0.*``), ``linear_final.0``, ``head.0`` / ``head.1.scale`` -- so that a
+    checkpoint of the reference loads with strict=True, the default initialisation consumes torch's generator exactly as the reference's
+    does (identical initial weights, incl. the re-seeding at the end of the constructor), and the outputs agree with the reference's OWN
+    module to fp32 round-off (tests/golden/ref_host_timemlp.npz, made by scripts/make_ref_fixtures.py from the reference's code).
+    Skip connections concatenate the time embedding in FRONT of the features (BaseMLP.forward); the number of Fourier frequencies follows
+    the clip length (num_freq_t + log2(max_video_length / 64), rounded).  What differs is how it runs: every Linear goes through
+    _LinearGemmBias (bias gradient by a GEMM), the one-video instance code through _InstCode -- both so that a captured iteration
+    replays correctly (phys_model.capture_iteration)."""
+
     def __init__(self, num_frames, frame_info=None, D=5, W=256, num_freq_t=6, out_channels=1, skips=(1, 2, 3, 4),
                  activation=None, time_scale=1.0, output_scale=1.0):
         super().__init__()
-        self.num_frames, self.time_scale, self.output_scale, self.skips, self.D = num_frames, time_scale, output_scale, set(skips), D
-        self.register_buffer("freqs", 2.0 ** torch.arange(num_freq_t, dtype=torch.float32) * math.pi, persistent=False)
-        in_ch = 1 + 2 * num_freq_t
-        self.inp = nn.Linear(in_ch, W)
-        self.layers = nn.ModuleList([nn.Linear(W + (in_ch if i in self.skips else 0), W) for i in range(D)])
-        self.act = activation if activation is not None else nn.ReLU(True)
-        self.head = nn.Linear(W, out_channels)
-        gen = torch.Generator().manual_seed(8)  # the reference seeds here "to reproduce results"
-        with torch.no_grad():
-            for mod in self.modules():
-                if isinstance(mod, nn.Linear):
-                    bound = 1.0 / math.sqrt(mod.weight.shape[1])
-                    mod.weight.copy_((torch.rand(mod.weight.shape, generator=gen) * 2 - 1) * bound)
-                    mod.bias.copy_((torch.rand(mod.bias.shape, generator=gen) * 2 - 1) * bound)
-            self.head.weight.mul_(0.1)
-            self.head.bias.zero_()
+        import numpy as np
 
-    def embed(self, frame_id):
-        t = (frame_id.float().reshape(-1, 1) / max(1, self.num_frames - 1) * 2 - 1) * self.time_scale
-        x = t * self.freqs.to(t.device)
-        return torch.cat([t, torch.sin(x), torch.cos(x)], -1)
+        if frame_info is None:
+            frame_info = {"frame_offset": np.asarray([0, num_frames]), "frame_mapping": list(range(num_frames)),
+                          "frame_offset_raw": np.asarray([0, num_frames])}
+        act = activation if activation is not None else nn.ReLU(True)
+        self.num_frames, self.D, self.W, self.skips = num_frames, D, W, list(skips)
+        if num_freq_t > 0:  # lab4d_utils.py:423-431: scale the frequency count with the clip length (64 frames -> num_freq_t)
+            off = np.asarray(frame_info["frame_offset"])
+            num_freq_t = int(np.rint(np.log2((off[1:] - off[:-1]).max() / 64) + num_freq_t))
+        # construction order = the reference's (BaseMLP layers, then the time embedding, then the head): the initial weights are a
+        # function of torch's generator state at entry, as there
+        for i in range(D):
+            layer = nn.Linear(W, W) if i == 0 else (nn.Linear(W + W, W) if i in self.skips else nn.Linear(W, W))
+            setattr(self, "linear_%d" % (i + 1), nn.Sequential(layer, act))
+        self.linear_final = nn.Sequential(nn.Linear(W, W), act)
+        self.time_embedding = TimeEmbedding(num_freq_t, frame_info, out_channels=W, time_scale=time_scale)
+        self.head = nn.Sequential(nn.Linear(W, out_channels), ScaleLayer(output_scale))
+        torch.manual_seed(8)  # "to reproduce results" (torch_utils.py:160-161)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(1)
 
     def forward(self, frame_id=None):
         if frame_id is None:
-            frame_id = torch.arange(self.num_frames, device=self.head.weight.device)
-        e = self.embed(frame_id)
-        h = self.act(_linear(self.inp, e))
-        for i, layer in enumerate(self.layers):
-            h = self.act(_linear(layer, torch.cat([h, e], -1) if i in self.skips else h))
-        return _linear(self.head, h) * self.output_scale
+            frame_id = torch.arange(self.num_frames, device=self.head[0].weight.device)
+        x = self.time_embedding(frame_id)
+        out = x
+        for i in range(self.D):
+            if i in self.skips:
+                out = torch.cat([x, out], -1)
+            seq = getattr(self, "linear_%d" % (i + 1))
+            out = seq[1](_linear(seq[0], out))
+        out = self.linear_final[1](_linear(self.linear_final[0], out))
+        return self.head[1](_linear(self.head[0], out))
 
 
 def interp_wt(x, y, x2, type="linear"):

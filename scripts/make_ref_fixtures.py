@@ -10,6 +10,8 @@ never touch a placeholder are called; a function that did would raise AttributeE
     diffphys.dp_utils     reduce_loss, remove_nan, bullet2gl, compute_com, parse_rtk, project_bodies
     diffphys.geom_utils   rot_angle, fid_reindex, quaternion_to_axis_angle, quaternion_invert, se3_vec2mat (numpy branch), se3_mat2rt
     diffphys.dataloader   DataLoader, parse_amp  (on the five AMP files the reference ships)
+    diffphys.torch_utils  TimeMLPWrapper (over diffphys.lab4d_utils: the time-MLPs phys_model is made of) -- initial weights under a fixed
+                          seed, outputs and parameter gradients at fractional frame ids, one and two videos
 
 Writes tests/golden/ref_host_*.npz : inputs and what the reference returned / left in place.  torch version recorded (median of an
 empty selection is NaN on torch 2.x and the reference's reduce_loss relies on whatever torch does there).
@@ -217,6 +219,37 @@ def run_mocap(rdu, rdl, out):
         os.chdir(here)
 
 
+def run_timemlp(out):
+    """the reference's TimeMLPWrapper as phys_model builds it (dp_model.py:292-315), at width 32 to keep the fixture small: the weights
+    torch's default initialisation gives it under torch.manual_seed(0) (the constructor re-seeds with 8 at its end, so the SECOND module's
+    weights follow from the first's), outputs at fractional frame ids, gradients of sum(y^2)"""
+    import numpy as onp
+    import diffphys.torch_utils as rtu
+
+    assert os.path.realpath(rtu.__file__).startswith(os.path.realpath(REF))
+    cfgs = {"root": dict(out_channels=6, D=8, skips=[4], time_scale=0.1, output_scale=0.5, W=32),
+            "joint": dict(out_channels=12, W=32),
+            "two_videos": dict(out_channels=5, W=32, output_scale=5.0,
+                               frame_info={"frame_offset": onp.asarray([0, 39, 72]), "frame_mapping": list(range(72)),
+                                           "frame_offset_raw": onp.asarray([0, 39, 72])})}
+    torch.manual_seed(0)
+    fid = torch.tensor([0.0, 0.5, 3.27, 17.0, 25.75, 38.0])
+    for name, kw in cfgs.items():
+        n = 72 if name == "two_videos" else 39
+        m = rtu.TimeMLPWrapper(n, **kw)
+        f = torch.cat([fid, torch.tensor([39.0, 55.5, 71.0])]) if name == "two_videos" else fid
+        for k, v in m.state_dict().items():
+            out["mlp/%s/state/%s" % (name, k)] = v.detach().numpy().copy()
+        y = m(f)
+        (y * y).sum().backward()
+        out["mlp/%s/frame_id" % name] = f.numpy()
+        out["mlp/%s/out" % name] = y.detach().numpy()
+        for k, p_ in m.named_parameters():
+            out["mlp/%s/grad/%s" % (name, k)] = p_.grad.detach().numpy().copy()
+        print("TimeMLPWrapper %-10s %d state entries, out %s, |out| max %.4f" % (name, len(m.state_dict()), tuple(y.shape), float(y.abs().max())))
+    out["mlp/names"] = onp.asarray(list(cfgs))
+
+
 def main():
     rdu, rgu, rdl = import_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -232,7 +265,10 @@ def main():
     c = {"note": np.asarray(note)}
     run_mocap(rdu, rdl, c)
     np.savez_compressed(os.path.join(OUT, "ref_host_mocap.npz"), **c)
-    for f in ("ref_host_reduce_loss.npz", "ref_host_small.npz", "ref_host_mocap.npz"):
+    d = {"note": np.asarray(note.replace("dp_utils.py, geom_utils.py, dataloader.py", "torch_utils.py, lab4d_utils.py"))}
+    run_timemlp(d)
+    np.savez_compressed(os.path.join(OUT, "ref_host_timemlp.npz"), **d)
+    for f in ("ref_host_reduce_loss.npz", "ref_host_small.npz", "ref_host_mocap.npz", "ref_host_timemlp.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
 

@@ -223,10 +223,11 @@ def test_fused_traj_loss_equals_the_torch_sequence_on_the_training_window(seq, d
     for variant in ("plain", "clipped"):
         nz = noise
         if variant == "clipped":
-            # envs 5.. start 0.4 rad off their reference in every joint: they never get near their targets, their frame losses pass
-            # 10 x the median of env 0's => reduce_loss clips them
+            # envs 5.. start 0.4 rad off their reference in every joint and 0.6 m above it (a 0.35 s fall: most of the window): they never get
+            # near their targets, their frame losses pass 10 x the median of env 0's => reduce_loss clips them
             nz = noise.clone()
             nz.view(10, 19)[5:, 7:] += 0.4
+            nz.view(10, 19)[5:, 1] += 0.6
         lf, gf, info = run(True, nz)
         lu, gu, _ = run(False, nz)
         print("%s %s: loss_traj fused %.6e torch %.6e; threshold %.3e, positives left %d, clipped envs %d" % (seq, variant, lf["loss_traj"], lu["loss_traj"], info[1], info[2], info[3]))

@@ -190,3 +190,39 @@ def test_hip_reduce_kernel_against_the_reference(rl, dev):
         red, _ = hip_backend.reduce_loss(d, clip=True)
         assert abs(float(red[0]) - float(ref)) <= 2e-6 * float(ref) and torch.equal(d.cpu(), ref_tab)
         assert (int(red[3]) == 0) == env0_empty
+
+
+# ------------------------------------------------------------------------------------------------ the time-MLPs of phys_model (row f3)
+_MLP_CFG = {"root": dict(out_channels=6, D=8, skips=[4], time_scale=0.1, output_scale=0.5, W=32),
+            "joint": dict(out_channels=12, W=32),
+            "two_videos": dict(out_channels=5, W=32, output_scale=5.0,
+                               frame_info={"frame_offset": np.asarray([0, 39, 72]), "frame_mapping": list(range(72)),
+                                           "frame_offset_raw": np.asarray([0, 39, 72])})}
+
+
+def test_time_mlp_is_the_references_module():
+    """diffphys_amd.time_mlp.TimeMLPWrapper against the reference's OWN module (diffphys/torch_utils.py:116-180 over lab4d_utils.py, run by
+    scripts/make_ref_fixtures.py): (i) built under the same seed in the same order, its default initialisation gives the SAME weights bit
+    for bit -- incl. the constructor's re-seeding, which makes the second module's weights a function of the first having been built;
+    (ii) the reference's state_dict loads with strict=True; (iii) outputs at fractional frame ids and every parameter gradient of
+    sum(y^2) agree to fp32 round-off (one and two videos; the root-pose configuration D=8, skips=[4], time_scale, output_scale)."""
+    from diffphys_amd.time_mlp import TimeMLPWrapper
+
+    with np.load(os.path.join(GOLD, "ref_host_timemlp.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    assert "outputs of the reference's own code" in str(ref["note"])
+    torch.manual_seed(0)
+    for name in ref["mlp/names"]:
+        n = 72 if name == "two_videos" else 39
+        m = TimeMLPWrapper(n, **_MLP_CFG[name])
+        sd = {k[len("mlp/%s/state/" % name):]: torch.from_numpy(v) for k, v in ref.items() if k.startswith("mlp/%s/state/" % name)}
+        assert set(sd) == set(m.state_dict()), (sorted(set(sd) ^ set(m.state_dict())))
+        for k, v in m.state_dict().items():   # (i) the same initial weights, bit for bit
+            assert torch.equal(v, sd[k]), (name, k)
+        m.load_state_dict(sd, strict=True)    # (ii)
+        y = m(torch.from_numpy(ref["mlp/%s/frame_id" % name]))
+        assert np.allclose(y.detach().numpy(), ref["mlp/%s/out" % name], rtol=2e-5, atol=2e-7), (name, np.abs(y.detach().numpy() - ref["mlp/%s/out" % name]).max())
+        (y * y).sum().backward()
+        for k, p in m.named_parameters():     # (iii)
+            g = ref["mlp/%s/grad/%s" % (name, k)]
+            assert np.allclose(p.grad.numpy(), g, rtol=1e-4, atol=1e-6 * max(1.0, np.abs(g).max())), (name, k, np.abs(p.grad.numpy() - g).max())
