@@ -26,8 +26,16 @@ class _LinearGemmBias(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = _gemm_long_k(g.t(), x) if ctx.needs_input_grad[1] else None
-        gb = (_ones_row(g.shape[0], g) @ g).reshape(-1) if ctx.needs_input_grad[2] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            # weight AND bias gradient as ONE GEMM over the samples: g^T @ [x | 1] -- the last column is the bias gradient (a 5 us copy for
+            # the ones column instead of a second, 25 us, GEMM; scripts/micro/gemm_shapes.py)
+            gwb = _gemm_long_k(g.t(), torch.cat([x, _ones_row(x.shape[0], x).t()], 1))
+            gw, gb = gwb[:, :-1], gwb[:, -1]
+        elif ctx.needs_input_grad[1]:
+            gw = _gemm_long_k(g.t(), x)
+        elif ctx.needs_input_grad[2]:
+            gb = (_ones_row(g.shape[0], g) @ g).reshape(-1)
         return gx, gw, gb
 
 

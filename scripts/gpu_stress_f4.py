@@ -68,7 +68,9 @@ for case in range(ncases):
         gr = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], tl, gain, fk=(jq, jqd, aq, aqd))
         wgq, wgqd = dm.fk_backward(jq.view(Ff * bsf, nq), jqd.view(Ff * bsf, nqd), aq.permute(1, 0, 2, 3).contiguous(), aqd.permute(1, 0, 2, 3).contiguous())
         if not (torch.equal(gr["fk_joint_q"].view(Ff * bsf, nq), wgq) and torch.equal(gr["fk_joint_qd"].view(Ff * bsf, nqd), wgqd)): why.append("fk bwd")
-        seeds = (tl["seed_pos"].view(F, bs, nb, 7) * (tl["scale"].t() * (0.37 / nb))[:, :, None, None]).reshape(F, bs * nb, 7).contiguous()
+        k_ = (tl["scale"].t() * (0.37 / nb))[:, :, None, None]   # a zero share is an assignment (nothing flows, not 0 x NaN: pd_trajloss.h); a NaN
+        sp_ = tl["seed_pos"].view(F, bs, nb, 7)                   # target's own seed IS NaN (0 x NaN, as autograd in the reference) and goes in
+        seeds = torch.where(k_ != 0, sp_ * k_, torch.zeros_like(sp_)).reshape(F, bs * nb, 7).contiguous()
         g2 = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, o[4], seeds, torch.zeros(F, bs * nb, 6, device=dev))
         for k in g2:
             if g2[k].numel() == 0: continue

@@ -43,6 +43,9 @@ def test_bench_line_contract_and_consistency():
     v = r["valu"]
     assert abs(v["frac_of_vector_peak"] - v["insts_per_launch"] * 128 / (r["avg_launch_ms"] * 1e-3) / 157.3e12) < 1e-9 and 0.2 < v["frac_of_vector_peak"] < 0.6
     assert d["collective_backend"] is None and d["ranks_seen"] == 1 and d["launcher"] == "none"
+    assert len(d["devices_seen"]) == 1 and d["devices_distinct"] == 1 and d["devices_seen"][0]["index"] == 0
+    # the HIP-event pass against the timed region: reported, and the two agree within 15 %
+    assert 0.9 < r["event_pass_over_timed"] < 1.15 and abs(r["pair_frac_timed"] - 4096 * 100 * 2720 / (d["ms_per_step"] * 1e-3) / 8e12) < 1e-9
     b = d["boundary"]
     assert 0.8 < b["ratio_to_value"] < 1.1 and b["nan_grads"] == 0
 
@@ -60,8 +63,15 @@ def test_bench_self_launches_two_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["launcher"] == "self" and d["collective_backend"] in ("nccl", "gloo")
+    # both ranks say which GPU they ran on; here (test hook) it is the same one, and the line shows that -- without the hook the run aborts
+    assert len(d["devices_seen"]) == 2 and d["devices_distinct"] == 1 and d["devices_seen"][0] == d["devices_seen"][1]
     assert d["scaling"] == "strong" and d["config"]["global_batch"] == 4096 and d["config"]["envs_per_gpu"] == 2048
     assert abs(d["value"] - 4096 * 100 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     o = d["other_scaling"]
     assert o["scaling"] == "weak" and o["global_batch"] == 8192 and o["envs_per_gpu"] == 4096
     assert "cpu_baseline" not in d and "boundary" not in d   # N = 1 only
+    # two ranks that would share a GPU WITHOUT the test hook: refused, and quickly (a dead rank no longer leaves the other in the rendezvous)
+    env2 = {k: v for k, v in os.environ.items() if k != "PPR_BENCH_SHARE_GPU"}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=300, env=env2)
+    assert out.returncode != 0 and "no GPU of its own" in out.stderr
