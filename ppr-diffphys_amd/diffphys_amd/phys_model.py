@@ -527,6 +527,8 @@ class phys_model(nn.Module):
         iteration() stays eager (torch's own multi-block reductions replay stale on this stack: scripts/micro/torch_graph_replay2.py --
         everything on this path goes through GEMMs / the library's kernels instead, and this check is what holds that)."""
         self._graph = None
+        self._graph_wanted = True   # iteration() captures again (a few times at most) when the window shape, the env or a loss weight changes
+        self._graph_captures = getattr(self, "_graph_captures", 0) + 1
         if not (self.training and str(self.device).startswith("cuda") and torch.cuda.is_available()):
             return False
         n, nq = self.num_envs, self.n_dof + 7
@@ -605,6 +607,8 @@ class phys_model(nn.Module):
         """forward() + backward() of one optimisation iteration; returns forward()'s dict.  The replay of the captured graph when there is
         one for the current window shape and loss weights (capture_iteration), eager otherwise -- same random numbers, same kernels on
         the same data, bit-identical results either way (tests/test_gpu_workload.py)."""
+        if not self._graph_usable() and getattr(self, "_graph_wanted", False) and self.training and getattr(self, "_graph_captures", 0) < 8:
+            self.capture_iteration()   # another window shape / env (reinit_envs(overwrite=True)) / loss weight than the graph was captured with
         if not self._graph_usable():
             out = self.forward()
             self.backward(out["total_loss"])

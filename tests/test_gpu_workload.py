@@ -118,9 +118,13 @@ def test_reference_training_window_and_eval_pass(seq, dev, oracle_libs):
     model.backward(out["total_loss"])
     gd = model.update()
     assert len(gd) > 0 and all(torch.isfinite(v) for v in gd.values())
-    # ---- 20 optimisation iterations on the reference's window: the loss goes down, everything stays physical
+    # ---- 40 optimisation iterations on the reference's window: the loss goes down, everything stays physical.  (40, not 20: with the
+    # reference's time-MLPs (round 5) AdamW's first ~10 normalised steps overshoot on the long clips -- mi-turn 1.2e-3 -> 2.1e-3 at iteration 8
+    # -> 5.6e-4 at 40 -- while a small step along -grad lowers the loss by what the gradient predicts, 2.3462e-3 measured against 2.3465e-3 on
+    # mi-pace.  The init noise stays ON as in the reference's training: with deterministic inputs one rejected update -- the global-norm
+    # guard of check_grad -- repeats forever, the same gradient being rejected again and again.)
     losses, t_iter = [], []
-    for it in range(20):
+    for it in range(40):
         model.set_progress(it)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -131,8 +135,8 @@ def test_reference_training_window_and_eval_pass(seq, dev, oracle_libs):
         t_iter.append(time.perf_counter() - t0)
         losses.append(float(out["total_loss"].detach()))
         assert np.isfinite(losses[-1])
-    assert np.mean(losses[-3:]) < np.mean(losses[:3]), losses
-    print("%s: 10 x %d window," % (seq, WT) + " iteration %.1f ms (median of 20), loss %.4f -> %.4f" % (1e3 * np.median(t_iter), losses[0], losses[-1]))
+    assert np.mean(losses[-8:]) < np.mean(losses[:8]), losses
+    print("%s: 10 x %d window," % (seq, WT) + " iteration %.1f ms (median of 40), loss %.4f -> %.4f" % (1e3 * np.median(t_iter), losses[0], losses[-1]))
     q = model.query()
     assert q["sim_traj"].shape == (24, 3838, 3) and q["target_traj"].shape == (24, 3838, 3) and q["control_ref"].shape == (24, 3838, 3)
     assert q["grf"].shape == (24, 130, 6) and len(q["com_k"]) == 24 and np.isfinite(q["sim_traj"]).all() and q["max_w"] > 0
@@ -345,11 +349,16 @@ def test_captured_iteration_is_bit_identical_to_eager(dev):
     assert torch.equal(le, lg), float((le - lg).abs().max())
     assert all(torch.equal(pe[n], pg[n]) for n in pe)
     assert bool(torch.isfinite(le).all()) and float(le[-1, -1]) != float(le[0, -1])   # the optimisation moves
-    # a changed loss weight is baked into the captured graph: iteration() must notice and run eagerly instead of replaying stale weights
+    # a changed loss weight is baked into the captured graph: iteration() must notice -- it captures again (validated like the first time)
+    # instead of replaying stale weights, and the new graph's loss carries the new weight
+    old = mg._graph
+    before = float(mg.iteration()["loss_traj"].detach())
+    mg.update()
     mg.opts["traj_wt"] = mg.opts["traj_wt"] * 2
-    n = mg._graph["replays"]
-    mg.iteration(); mg.update()
-    assert mg._graph["replays"] == n
+    out = mg.iteration()
+    assert mg._graph is not old and mg._graph["replays"] == 1 and mg._graph["weights"]["traj_wt"] == mg.opts["traj_wt"]
+    assert torch.isfinite(out["total_loss"]) and before > 0
+    mg.update()
 
 
 def test_skipping_the_two_zeroed_mlps_changes_no_bit(dev):
