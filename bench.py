@@ -147,6 +147,12 @@ def self_launch(n):
             if rcs[r] is None:
                 rcs[r] = p.poll()
         if any(rc not in (None, 0) for rc in rcs):
+            t_grace = time.time() + 15.0   # the others usually fail the same way on their own (and say why); then stop waiting
+            while time.time() < t_grace and any(rcs[r] is None and p.poll() is None for r, p in enumerate(procs)):
+                time.sleep(0.05)
+            for r, p in enumerate(procs):
+                if rcs[r] is None and p.poll() is not None:
+                    rcs[r] = p.returncode
             for r, p in enumerate(procs):
                 if rcs[r] is None:
                     p.terminate()

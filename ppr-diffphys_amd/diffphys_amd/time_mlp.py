@@ -217,22 +217,30 @@ class TimeMLPWrapper(nn.Module):
 
 
 def interp_wt(x, y, x2, type="linear"):
-    """piecewise-linear (or log-linear) schedule between two anchors   (lab4d_utils.py:622-660 of the reference)"""
-    assert len(x) == 2 and len(y) == 2
-    if x2 <= x[0]:
-        return y[0]
-    if x2 >= x[1]:
-        return y[1]
-    a = (x2 - x[0]) / (x[1] - x[0])
-    if type == "log":
-        return math.exp(math.log(y[0]) * (1 - a) + math.log(y[1]) * a)
-    return y[0] * (1 - a) + y[1] * a
+    """map x2 from [x0, x1] to [y0, y1]: linear, log (in y) or exp (log in x, x clipped to the range first); the result is clipped to the
+    range of y   (lab4d_utils.py:622-672 of the reference; held to its outputs in tests/test_ref_fixtures.py)"""
+    import numpy as np
+
+    (x0, x1), (y0, y1) = x, y
+    if type == "linear":
+        y2 = y0 + (x2 - x0) * (y1 - y0) / (x1 - x0)
+    elif type == "log":
+        y2 = 10 ** (np.log10(y0) + (x2 - x0) * (np.log10(y1) - np.log10(y0)) / (x1 - x0))
+    elif type == "exp":
+        assert x0 >= 1 and x1 >= 1
+        x2 = np.clip(x2, x0, x1)
+        y2 = y0 + (np.log10(x2) - np.log10(x0)) * (y1 - y0) / (np.log10(x1) - np.log10(x0))
+    else:
+        raise ValueError("interpolation_type must be 'linear' or 'log'")
+    return np.clip(y2, np.min(y), np.max(y))
 
 
 def match_param_name(name, param_lr, type):
-    """how many keys of param_lr match `name` ("with" = substring, "startwith" = prefix) and the matched value"""
-    matched, lr = 0, 0.0
-    for k, v in param_lr.items():
-        if (type == "with" and k in name) or (type == "startwith" and name.startswith(k)):
-            matched, lr = matched + 1, v
-    return matched, lr
+    """(matched, lr): does a key of param_lr match `name` ("with" = substring, "startwith" = prefix), and its value; more than one matching
+    key is an error, as in the reference   (lab4d_utils.py:587-619)"""
+    if type not in ("with", "startwith"):
+        raise ValueError("type not found")
+    hits = [(k, v) for k, v in param_lr.items() if (k in name if type == "with" else name.startswith(k))]
+    if len(hits) > 1:
+        raise ValueError("multiple matches found", [k for k, _ in hits])
+    return (True, hits[0][1]) if hits else (False, 0.0)

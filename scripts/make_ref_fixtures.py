@@ -248,6 +248,23 @@ def run_timemlp(out):
             out["mlp/%s/grad/%s" % (name, k)] = p_.grad.detach().numpy().copy()
         print("TimeMLPWrapper %-10s %d state entries, out %s, |out| max %.4f" % (name, len(m.state_dict()), tuple(y.shape), float(y.abs().max())))
     out["mlp/names"] = onp.asarray(list(cfgs))
+    # the two schedule helpers phys_model takes from lab4d_utils (dp_model.py:38-41,341,492-497)
+    import diffphys.lab4d_utils as rl4
+
+    xs = onp.asarray([-0.3, 0.0, 0.1, 0.25, 0.5, 0.77, 1.0, 1.4])
+    out["interp/x2"] = xs
+    out["interp/linear"] = onp.asarray([rl4.interp_wt((0, 0.5), (1, 0), float(t)) for t in xs])
+    out["interp/linear_up"] = onp.asarray([rl4.interp_wt((0.2, 1.0), (0.01, 0.3), float(t), type="linear") for t in xs])
+    out["interp/log"] = onp.asarray([rl4.interp_wt((0, 1), (1e-4, 1e-1), float(t), type="log") for t in xs])
+    out["interp/exp"] = onp.asarray([rl4.interp_wt((1, 100), (0.0, 2.0), float(t), type="exp") for t in (0.5, 1.0, 3.0, 10.0, 100.0, 250.0)])
+    lr = {"root_pose_mlp": 1e-4, "vel_mlp": 2e-4, "global_q": 1e-3}
+    q = [("root_pose_mlp.head.0.weight", "startwith"), ("global_q", "startwith"), ("body_mass", "startwith"), ("x.vel_mlp.y", "with"), ("x.vel_mlp.y", "startwith")]
+    out["match/result"] = onp.asarray([[float(a), float(b)] for a, b in (rl4.match_param_name(n, lr, t) for n, t in q)])
+    try:
+        rl4.match_param_name("root_pose_mlp.vel_mlp", lr, "with")
+        out["match/multiple_raises"] = onp.bool_(False)
+    except ValueError:
+        out["match/multiple_raises"] = onp.bool_(True)
 
 
 def main():

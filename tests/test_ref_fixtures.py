@@ -226,3 +226,23 @@ def test_time_mlp_is_the_references_module():
         for k, p in m.named_parameters():     # (iii)
             g = ref["mlp/%s/grad/%s" % (name, k)]
             assert np.allclose(p.grad.numpy(), g, rtol=1e-4, atol=1e-6 * max(1.0, np.abs(g).max())), (name, k, np.abs(p.grad.numpy() - g).max())
+
+
+def test_schedule_helpers_against_the_reference():
+    """interp_wt / match_param_name of the reference's lab4d_utils (what set_loss_weight and the per-parameter learning rates run on)"""
+    from diffphys_amd.time_mlp import interp_wt, match_param_name
+
+    with np.load(os.path.join(GOLD, "ref_host_timemlp.npz")) as z:
+        ref = {k: z[k] for k in z.files if k.startswith(("interp/", "match/"))}
+    xs = ref["interp/x2"]
+    assert np.allclose([interp_wt((0, 0.5), (1, 0), float(t)) for t in xs], ref["interp/linear"], atol=1e-15)
+    assert np.allclose([interp_wt((0.2, 1.0), (0.01, 0.3), float(t), type="linear") for t in xs], ref["interp/linear_up"], atol=1e-15)
+    assert np.allclose([interp_wt((0, 1), (1e-4, 1e-1), float(t), type="log") for t in xs], ref["interp/log"], rtol=1e-12)
+    assert np.allclose([interp_wt((1, 100), (0.0, 2.0), float(t), type="exp") for t in (0.5, 1.0, 3.0, 10.0, 100.0, 250.0)], ref["interp/exp"], atol=1e-14)
+    lr = {"root_pose_mlp": 1e-4, "vel_mlp": 2e-4, "global_q": 1e-3}
+    q = [("root_pose_mlp.head.0.weight", "startwith"), ("global_q", "startwith"), ("body_mass", "startwith"), ("x.vel_mlp.y", "with"), ("x.vel_mlp.y", "startwith")]
+    got = np.asarray([[float(a), float(b)] for a, b in (match_param_name(n, lr, t) for n, t in q)])
+    assert np.array_equal(got, ref["match/result"])
+    assert bool(ref["match/multiple_raises"])
+    with pytest.raises(ValueError):
+        match_param_name("root_pose_mlp.vel_mlp", lr, "with")
