@@ -550,6 +550,9 @@ class phys_model(nn.Module):
         side.wait_stream(torch.cuda.current_stream())
         mt = torch.autograd.is_multithreading_enabled()
         torch.autograd.set_multithreading_enabled(False)   # (the capture must see every backward launch on the capturing stream)
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:  # the parameters' AccumulateGrad nodes were made on the default stream (eager iterations, the constructor's FK):
+            quiet(False)       # intended here -- the warm-up below runs them on the capturing stream before anything is captured
         try:
             with torch.cuda.stream(side):
                 for _ in range(3):   # warm-up on the capturing stream: allocator, frame tables of the rollout, rocBLAS handles
