@@ -190,6 +190,9 @@ def test_hip_reduce_kernel_against_the_reference(rl, dev):
         red, _ = hip_backend.reduce_loss(d, clip=True)
         assert abs(float(red[0]) - float(ref)) <= 2e-6 * float(ref) and torch.equal(d.cpu(), ref_tab)
         assert (int(red[3]) == 0) == env0_empty
+    # an empty table: value 0 (the header says so), nothing written anywhere else
+    red, sc = hip_backend.reduce_loss(torch.zeros(0, 4, device=dev), clip=True)
+    assert float(red[0]) == 0.0 and int(red[2]) == 0 and sc.numel() == 0
 
 
 # ------------------------------------------------------------------------------------------------ the time-MLPs of phys_model (row f3)
