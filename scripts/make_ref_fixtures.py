@@ -29,7 +29,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("PPR_REFERENCE", "/root/reference")
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.path.join(ROOT, "tests", "golden")   # (--out DIR writes elsewhere: tests/test_reference_text.py regenerates and compares)
+if "--out" in sys.argv:
+    OUT = sys.argv[sys.argv.index("--out") + 1]
 SEQS = ("mi-pace", "mi-trot", "mi-spin", "mi-turn", "mi-sidesteps")
 
 
