@@ -46,9 +46,7 @@ def _ones_row(n, like):
     """ones[1, n] on like's device, made once per (n, device): the bias-gradient GEMM's left operand (a fill per layer and backward otherwise)"""
     key = (n, like.device, like.dtype)
     t = _ONES.get(key)
-    if t is None:
-        if len(_ONES) > 16:
-            _ONES.clear()
+    if t is None:  # never evicted: a captured iteration reads these BY ADDRESS (one entry per distinct sample count: a handful, n floats each)
         t = _ONES[key] = torch.ones(1, n, dtype=like.dtype, device=like.device)
     return t
 
