@@ -9,7 +9,10 @@ rows f2 / f4).  Any dtype, any device; the tests evaluate them in float64.  Foll
     /root/reference/diffphys/dp_model.py:574-579  get_foot_height (on the contact candidates instead of posed visual meshes)
 PARITY UNPINNED against the reference's own runs: dqtorch (its quaternion kernels, diffphys/geom_utils.py:5) is absent here; the
 conventions are pytorch3d's (real part FIRST inside these helpers, LAST in the 7-vectors at the boundary) and are pinned to
-scipy.spatial.transform.Rotation in tests/test_host_plumbing.py.  Only tests/ and scripts/ import this module."""
+scipy.spatial.transform.Rotation in tests/test_host_plumbing.py.  PINNED since round 5, by outputs of the reference's OWN code
+(tests/golden/ref_host_*.npz, scripts/make_ref_fixtures.py, tests/test_ref_fixtures.py): reduce_loss_loop (33 tables), rot_angle,
+quaternion_to_axis_angle, quaternion_invert, se3_vec2mat -- the functions of the reference that run here without dqtorch.  Only tests/ and
+scripts/ import this module."""
 import numpy as np
 import torch
 
