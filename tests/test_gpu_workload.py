@@ -396,3 +396,60 @@ def test_skipping_the_two_zeroed_mlps_changes_no_bit(dev):
     assert torch.equal(la, lb)
     assert all(torch.equal(pa[n], pb[n]) for n in pa)
     assert any(n.startswith("torque_mlp") for n in pa)
+
+
+def test_forward_against_the_reference_text_over_standins(dev):
+    """phys_model.forward against the reference's phys_model.forward TEXT (dp_model.py:664-838), which scripts/check_phys_model_vs_reference_text.py
+    executed in the build container over stand-ins -- rollouts and FK by the float64 oracle, dqtorch's kernels by geom_utils -- and whose
+    loss terms it stored (tests/golden/ref_text_phys_model_forward.npz).  Same torch seed => the same initial MLP weights (time_mlp
+    reproduces the reference's initialisation bit for bit), same numpy seed => the same init noise, same window starts and global_q: the
+    mirrored plumbing (window / out-of-sequence bookkeeping, mocap pipeline, pose algebra, rearrange_pred, the quirks of SURVEY N4,
+    loss assembly) on the HIP rollout must give the same trajectory / pos_state / vel_state / total losses.  A stand-in pins nothing; this
+    compares ~500 lines of mirror with the reference's text by machine."""
+    from diffphys_amd.dataloader import DataLoader
+    from diffphys_amd.phys_model import phys_model
+
+    with np.load(os.path.join(ROOT, "tests", "golden", "ref_text_phys_model_forward.npz")) as z:
+        ref = {k: z[k] for k in z.files}
+    assert "stand-in pins nothing" in str(ref["note"])
+    for i in range(int(ref["n_cases"])):
+        p = "case%d/" % i
+        seq, seed = str(ref[p + "seq"]), int(ref[p + "seed"])
+        opts = _main().get_opts(["--seqname", seq, "--urdf_template", "laikago", "--logroot", "/tmp/pprdp_workload/", "--logname", "reftext"])
+        for k in ("traj_wt", "pos_state_wt", "vel_state_wt", "noise_std"):
+            assert opts[k] == float(ref["opts/" + k]), k
+        torch.manual_seed(seed)
+        model = phys_model(opts, DataLoader(opts)).cuda()
+        model.train()
+        with torch.no_grad():
+            model.global_q.copy_(torch.tensor(ref["global_q"], dtype=torch.float32))
+        model.reinit_envs(int(ref[p + "num_envs"]), frames_per_wdw=int(ref[p + "frames_per_wdw"]))
+        assert len(model.steps_idx) == int(ref[p + "n_steps"])
+        np.random.seed(1000 + seed)
+        out = model.forward(frame_start=torch.tensor(ref[p + "frame_start"], dtype=torch.long, device=model.device))
+        got = {k: float(v.detach()) for k, v in out.items()}
+        print("%s: " % seq + "  ".join("%s %.6e (reference text %.6e)" % (k, got[k], float(ref[p + k])) for k in ("loss_traj", "loss_pos_state", "loss_vel_state", "total_loss")))
+        sim0 = np.stack([np.asarray(model.sim_trajs[f]) for f in range(len(model.sim_trajs))], 0)
+        assert relmax(sim0, ref[p + "sim_env0"]) < 5e-5, relmax(sim0, ref[p + "sim_env0"])        # env 0's simulated poses at the frames
+        for k in ("loss_traj", "loss_pos_state", "loss_vel_state", "total_loss"):
+            assert abs(got[k] - float(ref[p + k])) <= 1e-4 * abs(float(ref[p + k])), (seq, k, got[k], float(ref[p + k]))
+        assert got["loss_reg_torque"] == 0.0 and got["loss_reg_res_f"] == 0.0
+        # ... and backward(): the gradient of every parameter the reference's text + autograd through the oracle gave (norms; the small
+        # tensors -- global_q, gains, masses -- entry by entry), ForwardKinematics.backward's "> 1 -> 1" clamp included on both sides
+        model.backward(out["total_loss"])
+        worst = 0.0
+        for n in ref[p + "param_names"]:
+            n = str(n)
+            q = dict(model.named_parameters())[n]
+            g = q.grad if q.grad is not None else torch.zeros_like(q)
+            want = float(ref[p + "gradnorm/" + n])
+            have = float(g.double().norm())
+            scale = max(want, 1e-9)
+            worst = max(worst, abs(have - want) / scale if want > 1e-12 else abs(have))
+            assert abs(have - want) <= 5e-3 * scale + 1e-12, (seq, n, have, want)
+            if (p + "grad/" + n) in ref:
+                w = ref[p + "grad/" + n]
+                assert np.abs(g.detach().cpu().double().numpy() - w).max() <= 5e-3 * max(np.abs(w).max(), 1e-9) + 1e-12, (seq, n)
+        print("   parameter gradients: %d tensors, worst norm difference %.1e" % (len(ref[p + "param_names"]), worst))
+        model.optimizer.zero_grad(set_to_none=True)
+        model._pending_nan = None

@@ -35,3 +35,17 @@ def test_oracle_follows_the_reference_text():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "the restatement follows the reference's text" in out.stdout
     assert out.stdout.count("contacts active") == 4   # Laikago, human, quad, the toy robot with a FIXED joint: ground contacts loaded in each
+
+
+def test_phys_model_forward_fixture_is_reproducible(tmp_path):
+    """tests/golden/ref_text_phys_model_forward.npz IS what the reference's phys_model.forward / backward text gives over the stand-ins today"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_phys_model_vs_reference_text.py"), "--out", str(tmp_path / "f.npz")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    with np.load(os.path.join(ROOT, "tests", "golden", "ref_text_phys_model_forward.npz")) as a, np.load(str(tmp_path / "f.npz")) as b:
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            if a[k].dtype.kind == "f":
+                assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-15), k   # (float64 oracle on a multi-threaded torch: sums may reorder)
+            else:
+                assert np.array_equal(a[k], b[k]), k
