@@ -68,7 +68,7 @@ def main(argv=None):
             if it == 0 and opts["accu_steps"] == 1 and not opts["no_graph"]:
                 model.capture_iteration()   # forward() + backward() of the training window as ONE HIP graph from here on
         t0 = time.time()
-        model.set_progress(it)
+        model.progress = it / (opts["num_rounds"] * opts["iters_per_round"])   # main.py:64 of the reference (not set_progress: that divides by total_iters)
         if opts["accu_steps"] == 1:
             loss_dict = model.iteration()   # = forward() + backward(): the captured graph's replay, or eager (same numbers)
             loss = loss_dict["total_loss"]

@@ -176,6 +176,34 @@ def main():
         out[p + "n_steps"] = np.int64(len(m.steps_idx))
         print("%s  %d envs x %d steps, %d frames:" % (case["seq"], case["num_envs"], len(m.steps_idx), case["frames_per_wdw"]),
               "  ".join("%s %.6e" % (k, float(v.detach())) for k, v in res.items()))
+    # ---- the training loop of main.py:62-105 (progress, forward, backward, update = check_grad + AdamW + OneCycleLR) for a few iterations,
+    # the reference's text throughout: add_optimizer / get_optimizable_param_list / get_lr_dict / update / check_grad (dp_model.py:407-520, 904-1000)
+    case = CASES[0]
+    m = reference_model(rdm, rdl, tpl, case)
+    m.opts.update(phys_learning_rate=1e-4, num_rounds=5, iters_per_round=20)
+    m.total_iters = 101                      # int(num_rounds * iters_per_round * ratio_phys_cycle) + warmup_iters + 1   (dp_model.py:60-66)
+    m.grad_queue, m.model_cache, m.optimizer_cache, m.scheduler_cache = {}, [None, None], [None, None], [None, None]
+    m.add_optimizer(m.opts)
+    np.random.seed(2000 + case["seed"])
+    K = 8
+    starts = [[(3 * it + 5 * e) % (m.total_frames - m.frames_per_wdw) for e in range(m.num_envs)] for it in range(K)]
+    hist = {k: [] for k in ("total_loss", "loss_traj", "loss_pos_state", "loss_vel_state")}
+    for it in range(K):
+        m.progress = it / (m.opts["num_rounds"] * m.opts["iters_per_round"])     # main.py:64
+        ld = m.forward(frame_start=torch.tensor(starts[it], dtype=torch.long))
+        m.backward(ld["total_loss"])
+        m.update()
+        for k in hist:
+            hist[k].append(float(ld[k].detach()))
+    out["train/frame_starts"] = np.asarray(starts)
+    for k, v in hist.items():
+        out["train/" + k] = np.asarray(v)
+    out["train/lr_last"] = np.asarray(sorted(set(g["lr"] for g in m.optimizer.param_groups)))
+    for n_ in ("global_q", "target_kd", "body_mass"):
+        out["train/param/" + n_] = getattr(m, n_).detach().double().numpy()
+    for n_, q_ in m.named_parameters():
+        out["train/paramnorm/" + n_] = np.float64(float(q_.detach().double().norm()))
+    print("training loop, %d iterations: total_loss" % K, " ".join("%.6e" % v for v in hist["total_loss"]))
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
