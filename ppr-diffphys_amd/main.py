@@ -62,7 +62,8 @@ def main(argv=None):
             model.save_checkpoint(it)
             model.reinit_envs(1, frames_per_wdw=model.total_frames, is_eval=True)  # evaluation rollout over the whole clip
             with torch.no_grad():
-                ev = model.forward(frame_start=torch.zeros(1, dtype=torch.long, device=model.device))
+                ev = model.forward()   # (the window start is DRAWN, as in the reference, main.py:77 -- rand(1) x 0 frames of slack = 0: the same
+                #                        pass, and numpy's generator moves exactly as the reference's does)
             print("[eval %4d] traj loss %.5f" % (it, float(ev["loss_traj"])))
             model.reinit_envs(opts["num_envs"], frames_per_wdw=opts["frames_per_wdw"], is_eval=False)
             if it == 0 and opts["accu_steps"] == 1 and not opts["no_graph"]:
