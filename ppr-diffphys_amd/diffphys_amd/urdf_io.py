@@ -64,7 +64,9 @@ class Collision:
                 self.mesh_scale = _floats(m.get("scale"), 3, (1, 1, 1))
 
     def mesh(self):
-        """(vertices, faces) with the URDF <mesh scale> applied (urdfpy applies it on load)."""
+        """(vertices, faces) with the URDF <mesh scale> applied.  (urdfpy keeps `scale` as an attribute beside the meshes and the reference's
+        parse_urdf reads the meshes only, import_urdf.py:77-90; every URDF the reference ships says scale="1 1 1", where the two readings
+        agree -- a user file with another scale gets the geometry it describes.)"""
         if self._mesh is None:
             fn = self.mesh_file
             if fn.startswith("package://"):

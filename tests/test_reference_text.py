@@ -49,3 +49,12 @@ def test_phys_model_forward_fixture_is_reproducible(tmp_path):
                 assert np.allclose(a[k], b[k], rtol=1e-9, atol=1e-15), k   # (float64 oracle on a multi-threaded torch: sums may reorder)
             else:
                 assert np.array_equal(a[k], b[k]), k
+
+
+def test_import_urdf_follows_the_reference_text():
+    """row f1: the reference's parse_urdf, imported unchanged over an urdfpy adapter on this package's XML reader and this package's
+    ModelBuilder, fills the builder exactly as diffphys_amd.import_urdf does -- every URDF the reference ships, floating / fixed base,
+    URDF inertials / density (scripts/check_import_urdf_vs_reference_text.py)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_import_urdf_vs_reference_text.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "SAME builders" in out.stdout and out.stdout.count(".urdf") >= 13
