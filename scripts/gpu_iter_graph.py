@@ -66,23 +66,33 @@ print("parameters after %d iterations: %s" % (len(le), "BIT-IDENTICAL" if same e
 
 # ---- where the captured iteration's time goes (the last model is the graph one)
 if getattr(model, "_graph", None):
+    import contextlib, io
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    acc = np.zeros(5)
-    R = 20
-    for it in range(R):
-        model.set_progress(30 + it)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev[0].record()
-        out = model.iteration()
-        ev[1].record()
-        t1 = time.perf_counter()
-        model.update()
-        ev[2].record()
-        t2 = time.perf_counter()
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        acc += [ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t0) * 1e3]
-    acc /= R
-    print("captured iteration: device time of iteration() %.2f ms, of update() %.2f ms; host time to enqueue iteration() %.2f ms, update() incl. its "
-          "host transfer %.2f ms; wall %.2f ms" % tuple(acc))
+    R = 15   # (the schedule of this configuration has 101 steps: 25 + 2 x 15 fit)
+    it0 = 30
+    for block in range(2):
+        rows, verdicts = [], []
+        for it in range(R):
+            model.set_progress(it0 + it)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev[0].record()
+            out = model.iteration()
+            ev[1].record()
+            t1 = time.perf_counter()
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                model.update()
+            verdicts.append("large grad" in buf.getvalue())
+            ev[2].record()
+            t2 = time.perf_counter()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            rows.append([ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t0) * 1e3])
+        it0 += R
+        rows, verdicts = np.asarray(rows), np.asarray(verdicts)
+        acc = np.median(rows[~verdicts], 0)   # (the all-clear iterations: a verdict costs its host path, the same either way)
+        n_out = int(verdicts.sum())
+        print("captured iteration: device time of iteration() %.2f ms, of update() %.2f ms; host time to enqueue iteration() %.2f ms, "
+              "update() incl. its host transfer %.2f ms; wall %.2f ms  (medians over the all-clear iterations; %d of %d had another gradient-guard verdict)" % (
+                  tuple(acc) + (n_out, R)), flush=True)
