@@ -127,7 +127,10 @@ int pd_model_bind_joint_X_p(pd_model *m, const float *joint_X_p_dev, int n_envs)
  * (a violation returns non-zero, nothing is written).  State `nsteps` (the state after the last step) is a legal frame
  * for wp_pos / wp_vel; its grf / jaf rows are zero -- the reference appends no force snapshot for it (:1225-1228).
  * The device-side step->frame table is cached per model and (nsteps, frame2step); the first call with a new key uploads
- * it with one synchronous copy, later calls neither allocate nor synchronise (warm up before capturing a graph). */
+ * it with one synchronous copy, later calls neither allocate nor synchronise (warm up before capturing a graph).
+ * Sizes: bs = 0 and nsteps = 0 are legal (nothing / FK only).  Largest batch of ONE call: bs x bodies < 2^27 and bs < 2^24 (the kernels
+ * add 32-bit lane offsets to 64-bit step bases; 10 M Laikago envs) -- a larger bs is refused (non-zero, "batch too large"), never
+ * wrapped; the workspace and every tensor may lie past 4 GiB (tests: 1 048 576 envs x 8 steps, 9.8 GB of workspace). */
 int pd_rollout_forward(const pd_model *m, int bs, int nsteps, float dt,
                        const float *q_init_dev, const float *qd_init_dev, const float *torques_dev,
                        const float *res_f_dev, const float *refs_dev, const float *target_ke_dev,

@@ -532,6 +532,15 @@ extern "C" __attribute__((visibility("hidden"))) int pd_traj_loss_reduce_launch(
 extern "C" __attribute__((visibility("hidden"))) int pd_traj_seeds_launch(int bs, int nb, int nframes, const float *seed_pos, const float *scale, const float *gain, const float *adj_pos,
                                                                          const float *adj_vel, float *work, hipStream_t st);
 
+// The rollout kernels address a lane's element of a step's tensors as a 64-bit step base + a 32-bit lane offset (idx * 16 bytes at most;
+// idx * 9 as an int for the inertia gradients; env * 128 bytes into the hit log): bs x bodies < 2^27 and bs < 2^24 keep all of them in
+// range -- 10 M Laikago envs, far more than 288 GB holds at any useful horizon (1.2 KB of saved trajectory per env-step).  Refused, not wrapped.
+static int batch_too_large(const pd_model *m, int bs) {
+  if ((size_t)bs * (size_t)m->nb >= ((size_t)1 << 27) || bs >= (1 << 24))
+    return fail("batch too large: " + std::to_string(bs) + " envs x " + std::to_string(m->nb) + " bodies (supported: bs x bodies < 2^27 and bs < 2^24; split the batch)");
+  return 0;
+}
+
 // Row f4, second half: the FK of the control reference (and its adjoint) as extra workgroups of the launch that sits between the
 // rollout launches anyway -- k_reduce_fk = [reduce_loss | FK forward ...], k_seeds_fk = [seeds ... | FK backward ...] (pd_kernels.hip)
 static int check_fk_ride(const pd_fk_ride *fk, bool backward) {
@@ -584,6 +593,7 @@ static int rollout_forward_impl(const pd_model *cm, int bs, int nsteps, float dt
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
+  if (batch_too_large(m, bs)) return 1;
   if (check_fk_ride(fk, false)) return 1;
   const int *fos = nullptr;
   if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;
@@ -654,6 +664,7 @@ static int rollout_backward_impl(const pd_model *cm, int bs, int nsteps, float d
   pd_model *m = const_cast<pd_model *>(cm);
   if (!m) return fail("null model");
   if (bs < 0 || nsteps < 0) return fail("negative size");
+  if (batch_too_large(m, bs)) return 1;
   if (check_fk_ride(fk, true)) return 1;
   const int *fos = nullptr;
   if (frame_table(m, nsteps, nframes, frame2step, &fos, (hipStream_t)stream)) return 1;

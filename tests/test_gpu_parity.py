@@ -1693,3 +1693,150 @@ def test_a_nan_env_stays_in_its_lanes(name, family, dev):
     per_env = lambda k, v: v.reshape(T, bs, -1).transpose(1, 0, 2).reshape(bs, -1) if k in ("torques", "res_f", "refs") else v.reshape(bs, -1)
     for k in out["grads"]:
         assert np.array_equal(per_env(k, clean["grads"][k])[good], per_env(k, out["grads"][k])[good]), k
+
+
+@pytest.mark.parametrize("R,T,f2s,need_gb", [(256, 8, [3, 8], 30), (2500, 2, [1], 110)], ids=["1M-envs-8-steps", "10M-envs-2-steps"])
+def test_a_million_envs_past_four_gib(R, T, f2s, need_gb, dev):
+    """Maximum sizes.  (a) 1 048 576 Laikago envs -- 256 copies of 4 096 distinct ones -- x 8 steps, 2 frames.  13.6 M bodies; the saved
+    trajectory + hit log is 9.8 GB, so every step base from the fourth on lies past 4 GiB (64-bit bases under the kernels' 32-bit lane
+    offsets), the frame outputs and per-step gradients are 0.3-0.6 GB each.  Envs are independent: every copy must reproduce copy 0 BIT
+    FOR BIT (outputs and all 10 gradients, compared on the device), and copy 0 must be the 4 096-env launch on its own.  The library
+    refuses a batch whose lane offsets would not fit 32 bits (bs x bodies >= 2^27 or bs >= 2^24) instead of wrapping around.
+    (b) 10 240 000 envs x 2 steps, 133 M bodies: just under that limit -- the largest lane offsets the kernels ever form (2.1e9 bytes
+    into a step's planes, 1.3e9 into its hit log), 12 GB per step of workspace, ~80 GB in all."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < need_gb * 1e9:
+        pytest.skip("needs ~%d GB of device memory" % need_gb)
+    tpl = robots.load_template("laikago")
+    bs0 = 4096
+    inp = synth.make_inputs(tpl, "laikago", bs=bs0, nsteps=T, seed=12, seqs=("mi-trot", "mi-spin"), penetration=0.003)
+    inp["frame2step"] = f2s
+    F, nb = len(f2s), 13
+    rng = np.random.RandomState(5)
+    inp["adj_pos"] = (rng.randn(F, bs0 * nb, 7) * 1e-2).astype(np.float32)
+    inp["adj_vel"] = (rng.randn(F, bs0 * nb, 6) * 1e-2).astype(np.float32)
+    lead = dict(GRAD_LEAD, body_mass=0, adj_pos=1, adj_vel=1)
+    t0 = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES + ("adj_pos", "adj_vel")}
+
+    def tiled(k):   # the env axis (after the step / frame axis where there is one) repeated R times
+        x = t0[k]
+        if lead[k]:
+            y = x.reshape(x.shape[0], bs0, -1).repeat(1, R, 1)
+            return y.reshape((x.shape[0], R * x.shape[1]) + tuple(x.shape[2:]))
+        y = x.reshape(bs0, -1).repeat(R, 1)
+        return y.reshape((R * x.shape[0],) + tuple(x.shape[1:]))
+
+    dm = hip_backend.DeviceModel(tpl)
+    pos0, vel0, grf0, jaf0, ws0 = dm.rollout_forward(bs0, T, inp["dt"], *[t0[k] for k in FWD], frame2step=f2s)
+    g0 = dm.rollout_backward(bs0, T, inp["dt"], *[t0[k] for k in BWD], f2s, ws0, t0["adj_pos"], t0["adj_vel"])
+    assert float(grf0.abs().max()) > 1.0, "contacts must be active"
+    t = {k: tiled(k) for k in t0}
+    bs = bs0 * R
+    assert dm.workspace_floats(bs, T) * 4 > 2 * 2 ** 32 and bs * nb < 2 ** 27
+    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s)
+    g = dm.rollout_backward(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, ws, t["adj_pos"], t["adj_vel"])
+    torch.cuda.synchronize()
+
+    def copies_equal(big, small, has_lead, what):
+        a = big.reshape(big.shape[0], R, -1) if has_lead else big.reshape(R, -1)
+        b = small.reshape(small.shape[0], 1, -1) if has_lead else small.reshape(1, -1)
+        same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same.all()), (what, int((~same).sum()))
+
+    for name, big, small in (("wp_pos", pos, pos0), ("wp_vel", vel, vel0), ("grf", grf, grf0), ("jaf", jaf, jaf0)):
+        copies_equal(big, small, True, name)
+    for k in g0:
+        assert bool(torch.isfinite(g[k]).all()), k
+        copies_equal(g[k], g0[k], bool(GRAD_LEAD[k]), "grad " + k)
+    del pos, vel, grf, jaf, ws, g, t
+    torch.cuda.empty_cache()
+    # past the supported range: refused with a message before anything is looked at or launched
+    import ctypes
+
+    lib = hip_backend.lib()
+    f2s_c = (ctypes.c_int * 1)(0)
+    for too_many in ((2 ** 27 + nb - 1) // nb, 2 ** 24):
+        assert lib.pd_rollout_forward(dm.h, too_many, 1, ctypes.c_float(5e-4), *([None] * 10), 0, f2s_c, *([None] * 5), None) != 0
+        assert "batch too large" in lib.pd_last_error().decode()
+        assert lib.pd_rollout_backward(dm.h, too_many, 1, ctypes.c_float(5e-4), *([None] * 9), 0, f2s_c, *([None] * 13), None) != 0
+        assert "batch too large" in lib.pd_last_error().decode()
+
+
+def test_a_million_envs_through_the_fused_loss_and_fk_entries(dev):
+    """Maximum sizes, row f4's entries: 1 048 576 envs (256 copies of 4 096) x 8 steps through pd_rollout_forward_traj_loss_fk /
+    pd_rollout_backward_traj_loss_fk -- the [bs, F] loss table (8 MB: the global-memory path of the reduce launch, not the LDS one),
+    2 M FK chains riding on the reduce / seeds launches.  Every copy equals copy 0 bit for bit (table, seeds, FK poses, the 10 + 2
+    gradients); the threshold is env 0's -- the same as the 4 096-env launch's; the reduced loss agrees with it to summation order;
+    the gradients are the small launch's / 256 exactly (the mean's 1 / entries, a power of two)."""
+    from diffphys_amd import hip_backend, robots, synth
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs ~30 GB of device memory")
+    tpl = robots.load_template("laikago")
+    bs0, R, T, f2s = 4096, 256, 8, [3, 8]
+    inp = synth.make_inputs(tpl, "laikago", bs=bs0, nsteps=T, seed=13, seqs=("mi-trot", "mi-spin"), penetration=0.003)
+    F, nb, nq, nqd = len(f2s), 13, 19, 18
+    rng = np.random.RandomState(6)
+    t0 = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES}
+    dm = hip_backend.DeviceModel(tpl)
+    pos_plain = dm.rollout_forward(bs0, T, inp["dt"], *[t0[k] for k in FWD], frame2step=f2s)[0]
+    tgt0 = pos_plain.reshape(F, bs0, nb, 7).permute(1, 0, 2, 3).contiguous().clone()
+    tgt0[..., :3] += torch.from_numpy((rng.randn(bs0, F, nb, 3) * 0.02).astype(np.float32)).to(dev)
+    tgt0[7, :, :, 1] += 3.0          # one env far off: clipped by reduce_loss
+    outseq0 = torch.zeros(bs0, F, dtype=torch.bool, device=dev)
+    outseq0[11, 1] = True
+    jq0 = torch.from_numpy(np.tile(inp["q_init"].reshape(1, bs0, nq), (F, 1, 1)).astype(np.float32)).to(dev)
+    jq0[1, :, 7:] += 0.05
+    jqd0 = torch.from_numpy((rng.randn(F, bs0, nqd) * 0.1).astype(np.float32)).to(dev)
+    aq0 = torch.from_numpy((rng.randn(bs0, F, nb, 7) * 1e-2).astype(np.float32)).to(dev)
+    aqd0 = torch.from_numpy((rng.randn(bs0, F, nb, 6) * 1e-2).astype(np.float32)).to(dev)
+    g_loss = torch.ones(1, device=dev)
+
+    def run(bs, t, tgt, outseq, jq, jqd, aq, aqd):
+        pos, vel, grf, jaf, ws, tl = dm.rollout_forward_traj_loss(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=f2s, target_pos=tgt, outseq=outseq,
+                                                                  fk=(jq, jqd))
+        g = dm.rollout_backward_traj_loss(bs, T, inp["dt"], *[t[k] for k in BWD], f2s, ws, tl, g_loss, fk=(jq, jqd, aq, aqd))
+        return pos, tl, g
+
+    pos_s, tl_s, g_s = run(bs0, t0, tgt0, outseq0, jq0, jqd0, aq0, aqd0)
+    red_s = tl_s["reduced"].cpu().numpy()
+    assert red_s[3] >= 1 and np.isfinite(red_s).all()       # something was clipped in the small launch
+    lead = dict(GRAD_LEAD, body_mass=0)
+
+    def tiled(x, has_lead):
+        if has_lead:
+            y = x.reshape(x.shape[0], bs0, -1).repeat(1, R, 1)
+            return y.reshape((x.shape[0], R * x.shape[1]) + tuple(x.shape[2:]))
+        y = x.reshape(bs0, -1).repeat(R, 1)
+        return y.reshape((R * x.shape[0],) + tuple(x.shape[1:]))
+
+    t = {k: tiled(t0[k], bool(lead[k])) for k in t0}
+    bs = bs0 * R
+    pos, tl, g = run(bs, t, tiled(tgt0, False), tiled(outseq0.to(torch.uint8), False).to(torch.bool), tiled(jq0, True), tiled(jqd0, True),
+                     tiled(aq0, False), tiled(aqd0, False))
+    torch.cuda.synchronize()
+
+    def copies_equal(big, small, has_lead, what, factor=1.0):
+        a = big.reshape(big.shape[0], R, -1) if has_lead else big.reshape(R, -1)
+        b = (small.reshape(small.shape[0], 1, -1) if has_lead else small.reshape(1, -1)) * factor
+        same = (a == b) | (torch.isnan(a) & torch.isnan(b))
+        assert bool(same.all()), (what, int((~same).sum()))
+
+    copies_equal(pos, pos_s, True, "wp_pos")
+    copies_equal(tl["table"], tl_s["table"], False, "loss table")
+    copies_equal(tl["seed_pos"], tl_s["seed_pos"], True, "seed_pos")
+    copies_equal(tl["seed_gt"], tl_s["seed_gt"], False, "seed_gt")
+    copies_equal(tl["fk_body_q"], tl_s["fk_body_q"], False, "fk body_q")
+    copies_equal(tl["fk_body_qd"], tl_s["fk_body_qd"], False, "fk body_qd")
+    red = tl["reduced"].cpu().numpy()
+    assert red[1] == red_s[1] and red[3] == R * red_s[3] and red[2] == R * red_s[2]      # env 0's threshold; counts scale with the copies
+    assert abs(red[0] - red_s[0]) <= 1e-5 * abs(red_s[0])
+    copies_equal(tl["scale"], tl_s["scale"], False, "scale", 1.0 / R)
+    for k in GRAD_LEAD:
+        copies_equal(g[k], g_s[k], bool(GRAD_LEAD[k]), "grad " + k, 1.0 / R)
+    # (the FK adjoint's seeds do not go through the mean: the same values in every copy)
+    copies_equal(g["fk_joint_q"], g_s["fk_joint_q"], True, "fk grad q")
+    copies_equal(g["fk_joint_qd"], g_s["fk_joint_qd"], True, "fk grad qd")
