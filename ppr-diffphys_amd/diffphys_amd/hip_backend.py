@@ -526,11 +526,18 @@ def pose_op(op, a, b):
     return out
 
 
+_COLSUM_ONES = {}
+
+
 def colsum(x):
     """x [n, k] -> [k], the column sums as ONE GEMM (ones[1, n] @ x) instead of torch's reduction kernel: torch's multi-block reductions
     of this shape (many rows, few columns) replay STALE inside a captured HIP graph on this stack (scripts/micro/torch_graph_replay2.py),
     and everything on phys_model's iteration path must survive ``phys_model.capture_iteration``."""
-    return (torch.ones(1, x.shape[0], dtype=x.dtype, device=x.device) @ x).reshape(-1)
+    key = (x.shape[0], x.device, x.dtype)
+    ones = _COLSUM_ONES.get(key)
+    if ones is None:  # (never evicted: a captured iteration reads it by address; one entry per distinct row count, a handful)
+        ones = _COLSUM_ONES[key] = torch.ones(1, x.shape[0], dtype=x.dtype, device=x.device)
+    return (ones @ x).reshape(-1)
 
 
 def pose_op_vjp(op, a, b, g_out, need_a=True, need_b=True):
