@@ -37,5 +37,5 @@ for name, bs, segw in cfgs:
             fs.append(dm.last_kernel_ms(0)); bs_.append(dm.last_kernel_ms(1))
     f, b = np.median(fs), np.median(bs_)
     nb, nqd = int(tpl["nb"]), int(tpl["nqd"]); C = 2 * nqd + 6 * nb; B = 4 * (26 * nb + 3 * C)
-    print("TIMING v%d g%s f%s %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (
-        variant, os.environ.get("PD_GROUPS", "a"), os.environ.get("PD_FAMILY", "a"), name, bs, segw, f, b, bs * T / ((f + b) * 1e-3), 100 * bs * T / ((f + b) * 1e-3) * B / 8e12, B), flush=True)
+    print("TIMING g%s f%s %-8s bs=%-6d segw=%-2d fwd %.3f ms bwd %.3f ms -> %.3e env-steps/s  (%.2f%% of 8 TB/s at %d B/env-step)" % (
+        os.environ.get("PD_GROUPS", "a"), os.environ.get("PD_FAMILY", "a"), name, bs, segw, f, b, bs * T / ((f + b) * 1e-3), 100 * bs * T / ((f + b) * 1e-3) * B / 8e12, B), flush=True)
