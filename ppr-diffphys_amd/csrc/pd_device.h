@@ -454,9 +454,9 @@ PD_DEV void quat_decompose_adj(qt q, v3 c0, v3 c1, v3 c2, const float *g, qt &ad
   float gphi = -g[0], gth = -g[1], gpsi = -g[2];
   // matrix adjoint of rotm(q): only five of its entries are touched (c0.x, c1.x, c2.xyz)
   float A[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  { float y = c2.y, x = c2.z, d = x * x + y * y; A[5] = gphi * x / d; A[8] = -gphi * y / d; }
+  { float y = c2.y, x = c2.z, d = x * x + y * y; const float id = rcp_hw(d); A[5] = gphi * x * id; A[8] = -gphi * y * id; }
   { float s = -c2.x; A[2] = -gth * inv_sqrt_1mx2(s); }
-  { float y = c1.x, x = c0.x, d = x * x + y * y; A[1] = gpsi * x / d; A[0] = -gpsi * y / d; }
+  { float y = c1.x, x = c0.x, d = x * x + y * y; const float id = rcp_hw(d); A[1] = gpsi * x * id; A[0] = -gpsi * y * id; }
   rotm_adj(q, A, adj_q);
 }
 

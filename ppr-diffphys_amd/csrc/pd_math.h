@@ -31,8 +31,14 @@ PD_DEV v3 &operator+=(v3 &a, v3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return 
 PD_DEV v3 &operator-=(v3 &a, v3 b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
 PD_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PD_DEV v3 cross(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-PD_DEV float length(v3 a) { return sqrtf(dot(a, a)); }
-PD_DEV v3 normalize(v3 a) { float l = length(a); return l > 0.0f ? a * (1.0f / l) : V3(0.f, 0.f, 0.f); }
+// v_sqrt_f32 / v_rcp_f32 AS THEY ARE.  clang wraps the 1-ulp sqrtf and 1 / x in a rescue for denormal inputs / results (sqrt: compare, two
+// selects, two v_ldexp around the instruction; 1 / x: frexp mantissa + exponent, negate, v_ldexp) -- five / four extra instructions per use,
+// ~65 per kernel.  The bare instructions give the same bits for every argument in [2^-96, 2^96]; outside it a denormal argument reads as
+// zero and a denormal result is flushed -- lengths, squared norms and 1 - x^2 terms never live there (1 / denormal overflows to inf either way).
+PD_DEV float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }
+PD_DEV float rcp_hw(float x) { return __builtin_amdgcn_rcpf(x); }
+PD_DEV float length(v3 a) { return sqrt_hw(dot(a, a)); }
+PD_DEV v3 normalize(v3 a) { float l = length(a); return l > 0.0f ? a * rcp_hw(l) : V3(0.f, 0.f, 0.f); }
 
 PD_DEV v3 qvec(qt q) { return V3(q.x, q.y, q.z); }
 PD_DEV qt operator+(qt a, qt b) { return Q4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -44,7 +50,7 @@ PD_DEV qt qmul(qt a, qt b) {
   return Q4(a.w * b.x + b.w * a.x + a.y * b.z - a.z * b.y, a.w * b.y + b.w * a.y + a.z * b.x - a.x * b.z,
             a.w * b.z + b.w * a.z + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
 }
-PD_DEV qt qnormalize(qt q) { return q * (1.0f / sqrtf(qdot(q, q))); }
+PD_DEV qt qnormalize(qt q) { return q * rcp_hw(sqrt_hw(qdot(q, q))); }
 PD_DEV v3 qrot(qt q, v3 v) {
   v3 u = qvec(q);
   return v * (2.0f * q.w * q.w - 1.0f) + cross(u, v) * (2.0f * q.w) + u * (2.0f * dot(u, v));
@@ -76,7 +82,7 @@ PD_DEV qt q_axis_angle_sc(v3 axis, float ang, float2 &sc) {  // also returns (si
 }
 // 1/sqrt(1-x^2) for the acos/asin adjoints; 0 (contribution dropped, not inf) where sqrt(1-x^2) is not > 0,
 // as Warp's builtin adjoints do.  POLICY, see DESIGN.md section 6.
-PD_DEV float inv_sqrt_1mx2(float x) { float d = sqrtf(1.0f - x * x); return d > 0.0f ? 1.0f / d : 0.0f; }
+PD_DEV float inv_sqrt_1mx2(float x) { float d = sqrt_hw(1.0f - x * x); return d > 0.0f ? rcp_hw(d) : 0.0f; }
 PD_DEV float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // Warp's acos/asin builtins clamp their argument to [-1, 1] (recall): a unit-quaternion w that rounds to
 // 1.0000001f must not turn into NaN.  POLICY, see DESIGN.md section 6.
@@ -94,9 +100,9 @@ PD_DEV float asin_c(float x) { return asinf(clampf(x, -1.0f, 1.0f)); }
 // where libdevice's atan2f -- signed zeros, infinities, denormals -- is about 60).  atan2(0, 0) = 0; NaN in, NaN out.
 PD_DEV float atan2_pos(float y, float x) {
   const float ax = fabsf(x), hi = fmaxf(ax, y), lo = fminf(ax, y);
-  float t = hi > 0.0f ? lo * (1.0f / hi) : 0.0f;                      // in [0, 1]
+  float t = hi > 0.0f ? lo * rcp_hw(hi) : 0.0f;                      // in [0, 1]
   const bool red = t > 0.41421356f;                                    // tan(pi/8)
-  const float tr = (t - 1.0f) * (1.0f / (t + 1.0f));                   // atan(t) = pi/4 + atan((t - 1) / (t + 1))
+  const float tr = (t - 1.0f) * rcp_hw(t + 1.0f);                   // atan(t) = pi/4 + atan((t - 1) / (t + 1))
   t = red ? tr : t;
   const float z = t * t;
   float r = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * t + t;
@@ -114,7 +120,7 @@ PD_DEV float atan2_any(float y, float x) {
 PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq_dw) {
 #if PD_POLICY == 1  // the reference's text: twist = normalize((axis da, w)), q = 2 acos(twist.w) sign(axis . twist.xyz); adjoint through
   {                              // acos' (guarded: 0 at |twist.w| = 1) and the normalisation
-    const float y0 = da * alen, n2 = w * w + y0 * y0, il = 1.0f / sqrtf(n2), tw = w * il, sg = da < 0.0f ? -1.0f : 1.0f;
+    const float y0 = da * alen, n2 = w * w + y0 * y0, il = rcp_hw(sqrt_hw(n2)), tw = w * il, sg = da < 0.0f ? -1.0f : 1.0f;
     const float q0 = acos_c(tw) * 2.0f * sg;
     const float dq = -2.0f * sg * inv_sqrt_1mx2(tw);
     dq_dw = dq * (il - w * w * il * il * il);
@@ -123,7 +129,7 @@ PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq
   }
 #endif
   const float y = fabsf(da) * alen, sgn = da < 0.0f ? -1.0f : 1.0f;
-  const float d = w * w + y * y, id = d > 0.0f ? 1.0f / d : 0.0f;
+  const float d = w * w + y * y, id = d > 0.0f ? rcp_hw(d) : 0.0f;
   dq_dda = 2.0f * alen * w * id;
   dq_dw = -2.0f * sgn * y * id;
   return 2.0f * sgn * atan2_pos(y, w);
@@ -136,7 +142,7 @@ PD_DEV float twist_angle(float da, float w, float alen, float &dq_dda, float &dq
 PD_DEV float fixed_ang_h(float s2, float w, float &hs_over_s, float &h_w) {
 #if PD_POLICY == 1  // the reference's text: normalize(v) * acos(w) * 2 (normalize(0) = 0), adjoint through acos' (guarded) and normalize
   {
-    const float sl = sqrtf(s2), isl = sl > 0.0f ? 1.0f / sl : 0.0f, h0 = 2.0f * acos_c(w) * isl;
+    const float sl = sqrt_hw(s2), isl = sl > 0.0f ? rcp_hw(sl) : 0.0f, h0 = 2.0f * acos_c(w) * isl;
     hs_over_s = -h0 * isl * isl; h_w = -2.0f * inv_sqrt_1mx2(w) * isl;
     return h0;
   }
@@ -144,20 +150,20 @@ PD_DEV float fixed_ang_h(float s2, float w, float &hs_over_s, float &h_w) {
   const float den = s2 + w * w;
   float h = 0.0f, hss = 0.0f;
   if (w > 0.0f && s2 < 1e-4f * w * w) {
-    const float iw = 1.0f / w, x2 = s2 * iw * iw;
+    const float iw = rcp_hw(w), x2 = s2 * iw * iw;
     const float u = 1.0f - x2 * (1.0f / 3.0f - x2 * (1.0f / 5.0f - x2 * (1.0f / 7.0f)));
     const float upx = -2.0f / 3.0f + x2 * (4.0f / 5.0f - x2 * (6.0f / 7.0f));
     h = 2.0f * u * iw; hss = 2.0f * upx * iw * iw * iw;
   } else if (s2 > 0.0f) {
-    const float sl = sqrtf(s2), phi = atan2_pos(sl, w);
-    h = 2.0f * phi / sl; hss = 2.0f * (w / den - phi / sl) / s2;
+    const float sl = sqrt_hw(s2), phi = atan2_pos(sl, w);
+    h = 2.0f * phi * rcp_hw(sl); hss = 2.0f * (w * rcp_hw(den) - phi * rcp_hw(sl)) * rcp_hw(s2);
   }
-  hs_over_s = hss; h_w = den > 0.0f ? -2.0f / den : 0.0f;
+  hs_over_s = hss; h_w = den > 0.0f ? -2.0f * rcp_hw(den) : 0.0f;
   return h;
 }
 PD_DEV float twist_angle(float da, float w, float alen) {
 #if PD_POLICY == 1
-  { const float y0 = da * alen; return acos_c(w * (1.0f / sqrtf(w * w + y0 * y0))) * 2.0f * (da < 0.0f ? -1.0f : 1.0f); }
+  { const float y0 = da * alen; return acos_c(w * rcp_hw(sqrt_hw(w * w + y0 * y0))) * 2.0f * (da < 0.0f ? -1.0f : 1.0f); }
 #endif
   const float y = fabsf(da) * alen;
   return 2.0f * (da < 0.0f ? -1.0f : 1.0f) * atan2_pos(y, w);
@@ -204,7 +210,7 @@ PD_DEV void adj_qrot_inv_q(qt q, v3 v, qt &adj_q, v3 g) {
 }
 PD_DEV void adj_qrot_inv(qt q, v3 v, qt &adj_q, v3 &adj_v, v3 g) { adj_v += qrot(q, g); adj_qrot_inv_q(q, v, adj_q, g); }
 PD_DEV void adj_qnormalize(qt q, qt &adj_q, qt g) {
-  float il = 1.0f / sqrtf(qdot(q, q));
+  float il = rcp_hw(sqrt_hw(qdot(q, q)));
   qt n = q * il;
   float ng = qdot(n, g);
   adj_q += (g + n * (-ng)) * il;
@@ -212,7 +218,7 @@ PD_DEV void adj_qnormalize(qt q, qt &adj_q, qt g) {
 PD_DEV void adj_normalize(v3 a, v3 &adj_a, v3 g) {
   float l = length(a);
   if (l > 0.0f) {
-    float il = 1.0f / l;
+    float il = rcp_hw(l);
     v3 n = a * il;
     adj_a += (g - n * dot(n, g)) * il;
   }

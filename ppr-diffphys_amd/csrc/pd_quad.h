@@ -125,7 +125,7 @@ PD_DEV QState q_integrate(const QLane &k, const QBody &B, QState s, QM3 Rr, QM3 
   // :72  quat(w1, 0) * r: xyz = r.w w1 + w1 x r_v, w = -(w1 . r_v)
   const float qm = Q_BC3(s.r) * w1 + q_cross(w1, s.r) - k.m3 * q_sum3(w1 * s.r);
   const float rq = s.r + qm * (0.5f * dt);
-  const float r1 = rq * (1.0f / sqrtf(q_sum4(rq * rq)));
+  const float r1 = rq * rcp_hw(sqrt_hw(q_sum4(rq * rq)));
   sink = Q_BC1(fabsf(v1)) + q_sum3(fabsf(w1)) * B.reach;
   w1 = w1 * (1.0f - 0.1f * dt);                                // :75
   QState o;
@@ -215,7 +215,7 @@ PD_DEV void q_integrate_adj_wrench(const QLane &k, const QBody &B, const QState 
   T.w1 = q_mv(Rr, T.u);
   const float qm = Q_BC3(s.r) * T.w1 + q_cross(T.w1, s.r) - k.m3 * q_sum3(T.w1 * s.r);   // quat(w1, 0) * r
   const float rq = s.r + qm * (0.5f * dt);
-  const float il = 1.0f / sqrtf(q_sum4(rq * rq));
+  const float il = rcp_hw(sqrt_hw(q_sum4(rq * rq)));
   const float r1 = rq * il;
   // ---- reverse
   const float adj_r1 = gn.r + q_adj_qrot_q(k, r1, B.com, -gn.p);                        // p1 = x1 - rot(r1, com)

@@ -433,6 +433,9 @@ def test_against_frozen_bits(name, dev):
         pytest.skip("no bit fixtures recorded")
     # r05 (human / quad only): the compound joint's angle decomposition moved from libdevice's atan2f / sincosf to the library's own
     # bounded-range forms (pd_math.h atan2_any, sincos_half_pi): the same functions to 2e-7, other bits
+    # ... and, later in round 5, every sqrtf / reciprocal of the rollout kernels became the bare v_sqrt_f32 / v_rcp_f32 (pd_math.h sqrt_hw, rcp_hw:
+    # clang's denormal rescue around them gone).  Laikago's kernels kept every bit (its r03b pin still holds); the compound robots' differ by an
+    # ulp where a quotient x / d became x * rcp(d) (quat_decompose_adj) -- r05 was re-recorded on that build
     newest = ([t for t in ("r05", "r03b", "r03") if t in refs] or [None])[0]
     tpl = robots.load_template(name)
     dm = hip_backend.DeviceModel(tpl)
