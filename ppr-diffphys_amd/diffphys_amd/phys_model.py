@@ -261,10 +261,11 @@ class phys_model(nn.Module):
             for (name, _), m, has in zip(named, plan["med"].unbind(), plan["has_med"]):
                 if has:
                     grad_dict["grad_med/" + name] = m
-        if get_local_rank() == 0:
-            for (name, _), f in zip(named, flags):
+        if get_local_rank() == 0 and any(flags):
+            host_norms = plan["norms"].tolist()   # (one transfer for all the flagged parameters' messages)
+            for (name, _), f, nrm in zip(named, flags, host_norms):
                 if f:
-                    print("large grad: %.2f, clear %s" % (float(grad_dict["grad/" + name]), name))
+                    print("large grad: %.2f, clear %s" % (nrm, name))
         return grad_dict
 
     def clear_grad(self):

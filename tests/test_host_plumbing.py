@@ -123,10 +123,12 @@ def test_device_side_mocap_query_matches_the_numpy_pipeline():
         assert np.abs(got[k].numpy() - ref[k].astype(np.float32)).max() <= 1e-6 * max(1.0, np.abs(ref[k]).max()), k
 
 
-def test_batched_gradient_history_matches_the_reference_loop():
+@pytest.mark.parametrize("steady", [False, True], ids=["parameters-come-and-go", "every-parameter-every-iteration"])
+def test_batched_gradient_history_matches_the_reference_loop(steady):
     """grad_guard.GradHistory (one device tensor, one host transfer per iteration) against the reference's per-parameter
     lists (dp_model.py:965-1000 restated as a loop): same histories, same outlier decisions, same clipped gradients --
-    with outliers injected, with a parameter that has no gradient in some iterations, and with one that appears late."""
+    with outliers injected; with a parameter that has no gradient in some iterations and one that appears late (the general, per-row
+    path), and with every parameter present in every iteration (a real run: outliers then take the one-select path over the table)."""
     from diffphys_amd.grad_guard import GradHistory
 
     torch.manual_seed(0)
@@ -135,10 +137,12 @@ def test_batched_gradient_history_matches_the_reference_loop():
     hist, queues = GradHistory(queue_length=10, scale_threshold=5.0), {}
     n_out = 0
     for it in range(60):
-        active = [i for i in range(len(shapes)) if not (i == 2 and it % 7 == 3) and not (i == 5 and it < 9)]
+        active = [i for i in range(len(shapes)) if steady or (not (i == 2 and it % 7 == 3) and not (i == 5 and it < 9))]
         grads = [torch.randn(shapes[i]) * (0.5 + 0.1 * i) for i in active]
         if it in (25, 31, 32, 50):
             grads[it % len(grads)] *= 40.0  # an outlier
+        if steady and it in (31, 44):
+            grads[(it + 2) % len(grads)] *= 60.0  # two parameters flagged in one iteration
         ref = [g.clone() for g in grads]
         # reference loop
         ref_flags = []
