@@ -39,6 +39,33 @@ class _LinearGemmBias(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _LinearReluGemmBias(torch.autograd.Function):
+    """relu(x W^T + b) with the ReLU in the GEMM's epilogue (torch._addmm_activation: hipBLASLt's RELU_BIAS epilogue on the GPU -- the same
+    bits as addmm followed by relu, one launch less per layer: scripts/micro/relu_epilogue_probe.py) and _LinearGemmBias's backward behind
+    the ReLU's mask (threshold_backward on the saved output, the kernel nn.ReLU's backward runs)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        out = torch._addmm_activation(bias, x, weight.t())
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, out = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(g, out, 0)
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            gwb = _gemm_long_k(g.t(), torch.cat([x, _ones_row(x.shape[0], x).t()], 1))
+            gw, gb = gwb[:, :-1], gwb[:, -1]
+        elif ctx.needs_input_grad[1]:
+            gw = _gemm_long_k(g.t(), x)
+        elif ctx.needs_input_grad[2]:
+            gb = (_ones_row(g.shape[0], g) @ g).reshape(-1)
+        return gx, gw, gb
+
+
 _ONES = {}
 
 
@@ -67,6 +94,13 @@ def _gemm_long_k(a, b):
 
 def _linear(layer, x):
     return _LinearGemmBias.apply(x, layer.weight, layer.bias)
+
+
+def _linear_act(seq, x):
+    """seq = Sequential(Linear, activation): the ReLU (the default, as in the reference) rides in the GEMM; any other activation follows it"""
+    if type(seq[1]) is nn.ReLU and x.dim() == 2:
+        return _LinearReluGemmBias.apply(x, seq[0].weight, seq[0].bias)
+    return seq[1](_linear(seq[0], x))
 
 
 class ScaleLayer(nn.Module):
@@ -208,9 +242,8 @@ class TimeMLPWrapper(nn.Module):
         for i in range(self.D):
             if i in self.skips:
                 out = torch.cat([x, out], -1)
-            seq = getattr(self, "linear_%d" % (i + 1))
-            out = seq[1](_linear(seq[0], out))
-        out = self.linear_final[1](_linear(self.linear_final[0], out))
+            out = _linear_act(getattr(self, "linear_%d" % (i + 1)), out)
+        out = _linear_act(self.linear_final, out)
         return self.head[1](_linear(self.head[0], out))
 
 
