@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 7   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches); 7: pd_reduce_loss (reduce_loss on any table, threshold from env 0 as the reference takes it), pd_model_set_numeric_policy (the reference's literal acos forms as a run-time mode) */
+#define PD_ABI_VERSION 8   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches); 7: pd_reduce_loss (reduce_loss on any table, threshold from env 0 as the reference takes it), pd_model_set_numeric_policy (the reference's literal acos forms as a run-time mode); 8: pd_colsum */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -287,6 +287,14 @@ int pd_foot_height(int n, int nb, int nc, const float *body_q_dev, const int *c_
                    const float *c_dist_dev, float *height_dev, int *arg_dev, void *stream);
 int pd_foot_height_vjp(int n, int nb, const float *body_q_dev, const int *c_body_dev, const float *c_point_dev,
                        const int *arg_dev, const float *g_height_dev, float *g_body_q_dev, void *stream);
+
+/* out[c] = sum over the n rows of x[n][k] (row-major), rows added in a fixed order: the bias gradient of the time-MLPs' linear layers
+ * (reference: torch's autograd of nn.Linear in diffphys/lab4d_utils.py BaseMLP) and the gradient of an operand that was broadcast over
+ * n poses (global_q in rotate_frame, diffphys/dp_utils.py:113-138) -- as one launch that gives the same bits eagerly and in a replayed
+ * HIP graph.  n = 0 writes zeros.  ws_dev: PD_COLSUM_SLICES * k floats of caller-owned scratch (row slices are summed there first, then the
+ * slices in order); NULL, or n <= 1024: one slice, one launch -- the result of a given (n, k, ws given or not) never depends on anything else. */
+#define PD_COLSUM_SLICES 32
+int pd_colsum(int n, int k, const float *x_dev, float *out_dev, float *ws_dev, void *stream);
 
 /* Device time (ms) of this model's last `kind` launch, measured with hipEvents recorded on the launch stream around
  * the kernel: kind 0 = rollout forward, 1 = rollout backward.  Enabled per model by pd_model_set_timing(m, 1); used by

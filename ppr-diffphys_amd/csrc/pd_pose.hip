@@ -262,7 +262,64 @@ int pose_dispatch(int op, int n, const float *a, int a_bcast, const float *b, fl
   }
 }
 
+// Column sums of a row-major [n][k] matrix -- the bias gradient of a linear layer (n samples) and the gradient of a broadcast operand.
+// Two fixed-order stages, no atomics: workgroup (column slab of 32, row slice s of PD_COLSUM_SLICES) -- thread (phase p = tid / 32, column
+// c = tid % 32) adds the rows p, p + 8, ... of its slice (a 128-byte coalesced read per row and phase, four independent partial sums per
+// thread to keep loads in flight), the 8 phases are added in LDS in the order 0 .. 7 -> ws[s][col]; the second launch adds the slices in the
+// order 0 .. S-1.  The same bits every time, eagerly and inside a captured HIP graph (torch's multi-block sum(0) re-arms a semaphore with a
+// memset that a graph replay does not re-execute on this stack).  Small n: one slice, straight to out, one launch.
+__global__ __launch_bounds__(256) void k_colsum(int n, int k, int rows_per_slice, const float *__restrict__ x, float *__restrict__ dst) {
+  __shared__ float part[8][33];
+  const int c = threadIdx.x & 31, p = threadIdx.x >> 5, col = blockIdx.x * 32 + c;
+  const int r0 = blockIdx.y * rows_per_slice, r1 = min(n, r0 + rows_per_slice);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < k) {
+    const float *xc = x + col;
+    int r = r0 + p;
+    for (; r + 24 < r1; r += 32) {
+      s0 += xc[(size_t)r * k]; s1 += xc[(size_t)(r + 8) * k]; s2 += xc[(size_t)(r + 16) * k]; s3 += xc[(size_t)(r + 24) * k];
+    }
+    for (; r < r1; r += 8) s0 += xc[(size_t)r * k];
+  }
+  part[p][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (p == 0 && col < k) {
+    float t = part[0][c];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += part[q][c];
+    dst[(size_t)blockIdx.y * k + col] = t;
+  }
+}
+__global__ __launch_bounds__(64) void k_colsum_final(int k, int slices, const float *__restrict__ ws, float *__restrict__ out) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= k) return;
+  float v[PD_COLSUM_SLICES];   // all the slices' loads in flight at once (32 dependent round trips otherwise: 7 us for 32 KB), then the fixed order
+#pragma unroll
+  for (int s = 0; s < PD_COLSUM_SLICES; ++s) v[s] = s < slices ? ws[(size_t)s * k + col] : 0.0f;
+  float t = v[0];
+#pragma unroll
+  for (int s = 1; s < PD_COLSUM_SLICES; ++s) t = s < slices ? t + v[s] : t;
+  out[col] = t;
+}
+
 }  // namespace
+
+extern "C" int pd_colsum(int n, int k, const float *x_dev, float *out_dev, float *ws_dev, void *stream) {
+  if (n < 0 || k < 0) return 1;
+  if (k == 0) return 0;
+  if (!out_dev || (n > 0 && !x_dev)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned slabs = (unsigned)((k + 31) / 32);
+  if (n <= 1024 || !ws_dev) {  // one slice: straight to out
+    hipLaunchKernelGGL(k_colsum, dim3(slabs, 1), dim3(256), 0, st, n, k, n > 0 ? n : 1, x_dev, out_dev);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+  }
+  const int rows = (((n + PD_COLSUM_SLICES - 1) / PD_COLSUM_SLICES) + 7) & ~7;   // a multiple of the 8 row phases
+  const int slices = (n + rows - 1) / rows;
+  hipLaunchKernelGGL(k_colsum, dim3(slabs, (unsigned)slices), dim3(256), 0, st, n, k, rows, x_dev, ws_dev);
+  hipLaunchKernelGGL(k_colsum_final, dim3((unsigned)((k + 63) / 64)), dim3(64), 0, st, k, slices, ws_dev, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 extern "C" int pd_pose_op(int op, int n, const float *a_dev, int a_broadcast, const float *b_dev, float *out_dev, void *stream) {
   if (n > 0 && !out_dev) return 1;

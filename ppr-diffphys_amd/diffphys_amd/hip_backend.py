@@ -15,7 +15,7 @@ _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(o
 _lib = None
 
 NUM_STABLE, NUM_LITERAL = 0, 1  # PD_NUM_* of include/ppr_diffphys.h (DeviceModel.set_numeric_policy)
-ABI_VERSION = 7  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+ABI_VERSION = 8  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -88,6 +88,7 @@ def lib():
         L.pd_pose_op_vjp.argtypes = [ci, ci, vp, ci, vp, vp, vp, vp, vp]
         L.pd_foot_height.argtypes = [ci, ci, ci] + [vp] * 6 + [vp]
         L.pd_foot_height_vjp.argtypes = [ci, ci] + [vp] * 6 + [vp]
+        L.pd_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
         if L.pd_abi_version() != ABI_VERSION and not (os.environ.get("PPR_DIFFPHYS_LIB") and os.environ.get("PPR_DIFFPHYS_ANY_ABI")):  # scripts/ab_time.sh times older builds
             raise RuntimeError("libpprdiffphys_hip.so ABI mismatch: library %d, binding %d" % (L.pd_abi_version(), ABI_VERSION))
         _lib = L
@@ -526,18 +527,22 @@ def pose_op(op, a, b):
     return out
 
 
-_COLSUM_ONES = {}
+COLSUM_SLICES = 32   # PD_COLSUM_SLICES of the header
 
 
 def colsum(x):
-    """x [n, k] -> [k], the column sums as ONE GEMM (ones[1, n] @ x) instead of torch's reduction kernel: torch's multi-block reductions
-    of this shape (many rows, few columns) replay STALE inside a captured HIP graph on this stack (scripts/micro/torch_graph_replay2.py),
-    and everything on phys_model's iteration path must survive ``phys_model.capture_iteration``."""
-    key = (x.shape[0], x.device, x.dtype)
-    ones = _COLSUM_ONES.get(key)
-    if ones is None:  # (never evicted: a captured iteration reads it by address; one entry per distinct row count, a handful)
-        ones = _COLSUM_ONES[key] = torch.ones(1, x.shape[0], dtype=x.dtype, device=x.device)
-    return (ones @ x).reshape(-1)
+    """x [n, k] -> [k], the column sums as ONE launch of the library's own kernel (``pd_colsum``: fixed summation order, no atomics, no
+    second stage) instead of torch's reduction: torch's multi-block reductions of this shape (many rows, few columns) replay STALE inside a
+    captured HIP graph on this stack (scripts/micro/torch_graph_replay2.py), and everything on phys_model's iteration path must survive
+    ``phys_model.capture_iteration``.  Bias gradients of the time-MLPs, the gradient of a broadcast pose operand."""
+    n, k = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty(k, dtype=torch.float32, device=x.device)
+    ws = torch.empty(COLSUM_SLICES * k, dtype=torch.float32, device=x.device) if n > 1024 else None   # row slices first, then the slices in order
+    rc = lib().pd_colsum(n, k, _dev(x, "x", n * k) if n * k else None, _dev(out, "out") if k else None, _dev(ws, "ws") if ws is not None else None,
+                         _stream())
+    if rc != 0:
+        raise RuntimeError("pd_colsum failed (rc %d)" % rc)
+    return out
 
 
 def pose_op_vjp(op, a, b, g_out, need_a=True, need_b=True):

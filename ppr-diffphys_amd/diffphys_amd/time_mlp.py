@@ -9,8 +9,31 @@ import torch
 from torch import nn
 
 
+def _weight_bias_grads(g, x, need_w, need_b):
+    """(g^T x, column sums of g) for a linear layer's backward.  GPU: the weight gradient as its own GEMM -- a contiguous [out, in] result
+    that AccumulateGrad takes over without a copy -- and the bias gradient by the library's column-sum launch (hip_backend.colsum,
+    ``pd_colsum``: ~5 us, fixed order).  Round 5 first folded the bias into the GEMM (g^T [x | 1]): a concatenation in front and two strided
+    copies behind it per layer, 13 us x 30 layers of an iteration.  CPU (tests, fixtures): the GEMM forms."""
+    gw = gb = None
+    if g.is_cuda:
+        if need_w:
+            gw = _gemm_long_k(g.t(), x)
+        if need_b:
+            from . import hip_backend
+            gb = hip_backend.colsum(g)
+        return gw, gb
+    if need_w and need_b:
+        gwb = g.t() @ torch.cat([x, _ones_row(x.shape[0], x).t()], 1)
+        return gwb[:, :-1], gwb[:, -1]
+    if need_w:
+        gw = g.t() @ x
+    if need_b:
+        gb = (_ones_row(g.shape[0], g) @ g).reshape(-1)
+    return gw, gb
+
+
 class _LinearGemmBias(torch.autograd.Function):
-    """y = x W^T + b with the bias gradient taken by a GEMM (ones[1, N] @ g) instead of torch's column reduction.  Same forward as
+    """y = x W^T + b with the bias gradient taken by the library's column-sum launch (a GEMM on the CPU) instead of torch's column reduction.  Same forward as
     F.linear.  Why: on this stack (ROCm 7.x / torch 2.10) torch's multi-block reductions -- e.g. ``g.sum(0)`` over [1024, 128] -- come
     out STALE from the second replay of a captured HIP graph on (their semaphore memset is not re-executed; pure-torch reproducer
     scripts/micro/torch_graph_replay2.py), and the bias gradients of these MLPs are exactly that shape.  A GEMM has no such state, so
@@ -26,16 +49,7 @@ class _LinearGemmBias(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = gb = None
-        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            # weight AND bias gradient as ONE GEMM over the samples: g^T @ [x | 1] -- the last column is the bias gradient (a 5 us copy for
-            # the ones column instead of a second, 25 us, GEMM; scripts/micro/gemm_shapes.py)
-            gwb = _gemm_long_k(g.t(), torch.cat([x, _ones_row(x.shape[0], x).t()], 1))
-            gw, gb = gwb[:, :-1], gwb[:, -1]
-        elif ctx.needs_input_grad[1]:
-            gw = _gemm_long_k(g.t(), x)
-        elif ctx.needs_input_grad[2]:
-            gb = (_ones_row(g.shape[0], g) @ g).reshape(-1)
+        gw, gb = _weight_bias_grads(g, x, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return gx, gw, gb
 
 
@@ -55,14 +69,7 @@ class _LinearReluGemmBias(torch.autograd.Function):
         x, weight, out = ctx.saved_tensors
         g = torch.ops.aten.threshold_backward(g, out, 0)
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = gb = None
-        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
-            gwb = _gemm_long_k(g.t(), torch.cat([x, _ones_row(x.shape[0], x).t()], 1))
-            gw, gb = gwb[:, :-1], gwb[:, -1]
-        elif ctx.needs_input_grad[1]:
-            gw = _gemm_long_k(g.t(), x)
-        elif ctx.needs_input_grad[2]:
-            gb = (_ones_row(g.shape[0], g) @ g).reshape(-1)
+        gw, gb = _weight_bias_grads(g, x, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return gx, gw, gb
 
 
@@ -126,8 +133,10 @@ class _InstCode(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        gw = (_ones_row(g.shape[0], g) @ g)
-        return gw, None
+        if g.is_cuda:
+            from . import hip_backend
+            return hip_backend.colsum(g)[None], None
+        return _ones_row(g.shape[0], g) @ g, None
 
 
 class PosEmbedding(nn.Module):

@@ -146,3 +146,40 @@ def test_foot_height_matches_the_torch_gather(dev):
     bad[3, 1, 5, 4] = float("nan")
     hb, _ = hip_backend.foot_height(bad, c_body.int(), c_point, c_dist)
     assert torch.isnan(hb[3, 1]) and not torch.isnan(hb).sum().item() > 1
+
+
+@pytest.mark.parametrize("n,k", [(0, 5), (1, 1), (7, 33), (760, 18), (7600, 256), (7600, 512), (25600, 257), (100003, 3)])
+def test_colsum_against_float64_and_inside_a_replayed_graph(n, k, dev):
+    """pd_colsum (bias gradients of the time-MLPs, gradient of a broadcast pose operand): column sums in a fixed order.  Against a float64
+    sum (the error of n fp32 additions in 8 + 4 interleaved partial sums); bit-identical run to run; and -- the reason it exists -- the
+    SECOND and third replay of a captured HIP graph return the sums of the data that is in the buffer THEN (torch's own sum(0) of such
+    shapes returns the first replay's on this stack)."""
+    from diffphys_amd import hip_backend
+
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + k)
+    x = (torch.randn(n, k, generator=g) * 3.0 + 0.5).to(dev)
+    got = hip_backend.colsum(x)
+    ref = x.double().sum(0)
+    assert got.shape == (k,) and got.dtype == torch.float32
+    scale = float(x.abs().double().sum(0).max()) if n else 1.0
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * max(scale, 1.0), float((got.double() - ref).abs().max())
+    assert torch.equal(hip_backend.colsum(x), got)
+    if n == 0:
+        assert float(got.abs().max()) == 0.0
+        return
+    buf = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip_backend.colsum(buf)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = hip_backend.colsum(buf)
+    torch.cuda.current_stream().wait_stream(side)
+    for trial in range(3):
+        fresh = (torch.randn(n, k, generator=g) * (trial + 1.0)).to(dev)
+        buf.copy_(fresh)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, hip_backend.colsum(fresh)), trial
