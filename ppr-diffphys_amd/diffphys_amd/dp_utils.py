@@ -93,6 +93,35 @@ def reduce_loss(loss_seq, clip=False, th=0):
     return torch.where(loss_seq.sum() > 0, mean_pos, loss_seq.mean())
 
 
+class _ReduceLossHip(torch.autograd.Function):
+    """reduce_loss WITHOUT clipping on a float32 GPU table (bs, F), as the library's one-workgroup launch (``pd_reduce_loss``, the code the
+    trajectory-loss entries run; held to the reference's own outputs in tests/test_ref_fixtures.py) and one multiply for the gradient
+    (scale = d value / d entry, written by the same launch) -- the torch composition above is ~15 launches forward and ~8 backward."""
+
+    @staticmethod
+    def forward(ctx, table):
+        from . import hip_backend
+
+        reduced, scale = hip_backend.reduce_loss(table.detach().contiguous(), clip=False, want_scale=table.requires_grad)
+        if table.requires_grad:
+            ctx.save_for_backward(scale)
+        return reduced[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return g * scale
+
+
+def reduce_loss_masked(loss_seq, mask):
+    """reduce_loss(loss_seq with the entries under `mask` set to 0) -- the two state losses of phys_model.forward (dp_model.py:783-805 of the
+    reference: `loss[outseq_idx] = 0` then reduce_loss).  float32 GPU tables take the HIP launch, anything else the torch composition."""
+    x = loss_seq.masked_fill(mask, 0.0)
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+        return _ReduceLossHip.apply(x)
+    return reduce_loss(x)
+
+
 class _Se3LossHip(torch.autograd.Function):
     """se3_loss and both gradients in one HIP launch (C ABI ``pd_se3_loss``)."""
 

@@ -25,7 +25,7 @@ import torch.nn as nn
 from . import robots, sim
 from .dataloader import mocap_tensors, bullet2gl, parse_amp
 from .dp_model import ForwardKinematics, ForwardWarp, ForwardWarpTrajLossFK, convert_ppr_warp
-from .dp_utils import compose_delta, reduce_loss, rotate_frame, rotate_frame_vel, se3_loss
+from .dp_utils import compose_delta, reduce_loss, reduce_loss_masked, rotate_frame, rotate_frame_vel, se3_loss
 from .geom_utils import fid_reindex
 from .grad_guard import GradHistory
 from .time_mlp import TimeMLPWrapper, interp_wt, match_param_name
@@ -465,9 +465,9 @@ class phys_model(nn.Module):
             loss_traj = torch.where(outseq_idx, torch.zeros_like(loss_traj), loss_traj)
             loss_dict["traj"] = reduce_loss(loss_traj, clip=True)
         loss_pos = se3_loss(queried_position, sim_position.detach()).mean(-1)
-        loss_dict["pos_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_pos), loss_pos))
+        loss_dict["pos_state"] = reduce_loss_masked(loss_pos, outseq_idx)
         loss_vel = se3_loss(queried_velocity, sim_velocity.detach()).mean(-1)
-        loss_dict["vel_state"] = reduce_loss(torch.where(outseq_idx, torch.zeros_like(loss_vel), loss_vel))
+        loss_dict["vel_state"] = reduce_loss_masked(loss_vel, outseq_idx)
         loss_dict["reg_torque"] = _mean_sq(torques)
         loss_dict["reg_res_f"] = _mean_sq(res_f)
         loss_dict["reg_foot"] = foot_height.pow(2).mean()
