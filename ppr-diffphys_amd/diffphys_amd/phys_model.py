@@ -322,13 +322,15 @@ class phys_model(nn.Module):
             torques = torch.zeros(bs, nstep, 6 + self.n_dof, dtype=torch.float32, device=steps_fr.device)
             res_f = torch.zeros(bs, nstep, 6 * self.n_links, dtype=torch.float32, device=steps_fr.device)
         else:
-            torques = self.torque_mlp(t)
+            shared = {}
+            torques = self.torque_mlp(t, shared)
             torques = torch.cat([torch.zeros_like(torques[:, :1].repeat(1, 6)), torques], 1).view(bs, nstep, -1) * 0
-            res_f = self.residual_f_mlp(t).view(bs, nstep, -1, 6)
+            res_f = self.residual_f_mlp(t, shared).view(bs, nstep, -1, 6)
             res_f = torch.cat([res_f[..., :3] * 10, res_f[..., 3:]], -1).view(bs, nstep, -1) * 0
-        delta_root = self.root_pose_mlp(t).view(bs, nstep, -1)
-        delta_ja_ref = self.joint_angle_mlp(t).view(bs, nstep, -1)
-        state_qd = self.vel_mlp(t).view(bs, nstep, -1)
+        shared = {}   # frame -> time mapping and Fourier features, computed once for the MLPs that agree on them (time_mlp.TimeEmbedding)
+        delta_root = self.root_pose_mlp(t, shared).view(bs, nstep, -1)
+        delta_ja_ref = self.joint_angle_mlp(t, shared).view(bs, nstep, -1)
+        state_qd = self.vel_mlp(t, shared).view(bs, nstep, -1)
         return torques, delta_root, delta_ja_ref, state_qd, res_f
 
     def _attach_zero_grads(self):

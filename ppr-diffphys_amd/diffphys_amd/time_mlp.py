@@ -194,16 +194,31 @@ class TimeEmbedding(nn.Module):
         self.mapping1 = nn.Linear(self.fourier_embedding.out_channels, out_channels)
         self.mapping2 = nn.Linear(2 * out_channels, out_channels)
 
-    def frame_to_tid(self, frame_id):
-        k = frame_id.long()
-        tid_sub = frame_id - self.raw_fid_to_vstart[k]
-        return (tid_sub - self.raw_fid_to_vidlen[k] / 2) / self.max_ts * 2 * self.time_scale
+    def frame_to_tid(self, frame_id, shared=None):
+        # ((f - start) - length / 2) / max_ts * 2 is the same for every MLP over the same clip: `shared` (a dict that lives for one
+        # phys_model.get_net_pred call) lets the five MLPs compute it once -- the same operations in the same order, then x time_scale
+        key = ("tid", self.max_ts, tuple(int(x) for x in self.frame_offset_raw))
+        base = shared.get(key) if shared is not None else None
+        if base is None:
+            k = frame_id.long()
+            tid_sub = frame_id - self.raw_fid_to_vstart[k]
+            base = (tid_sub - self.raw_fid_to_vidlen[k] / 2) / self.max_ts * 2
+            if shared is not None:
+                shared[key] = base
+        return base * self.time_scale
 
-    def forward(self, frame_id):
+    def forward(self, frame_id, shared=None):
         frame_id = frame_id.reshape(-1)
-        inst_id = self.raw_fid_to_vid[frame_id.long()]
-        coeff = _linear(self.mapping1, self.fourier_embedding(self.frame_to_tid(frame_id)[:, None].float()))
-        return _linear(self.mapping2, torch.cat([coeff, self.inst_embedding(inst_id)], -1))
+        fkey = ("fourier", self.max_ts, tuple(int(x) for x in self.frame_offset_raw), self.time_scale, self.fourier_embedding.N_freqs)
+        feat = shared.get(fkey) if shared is not None else None
+        if feat is None:   # (no gradient flows into the features: MLPs with the same time scale and frequency count share them)
+            feat = self.fourier_embedding(self.frame_to_tid(frame_id, shared)[:, None].float())
+            if shared is not None:
+                shared[fkey] = feat
+        coeff = _linear(self.mapping1, feat)
+        # one video: every sample reads row 0 of the instance table (_InstCode needs the count only, no lookup)
+        inst = self.inst_embedding(frame_id if self.num_vids == 1 else self.raw_fid_to_vid[frame_id.long()])
+        return _linear(self.mapping2, torch.cat([coeff, inst], -1))
 
 
 class TimeMLPWrapper(nn.Module):
@@ -243,10 +258,12 @@ class TimeMLPWrapper(nn.Module):
         if torch.cuda.is_available():
             torch.cuda.manual_seed(1)
 
-    def forward(self, frame_id=None):
+    def forward(self, frame_id=None, shared=None):
+        """``shared``: a dict several MLPs evaluated at the SAME frame ids pass to each other (phys_model.get_net_pred): the frame -> time
+        mapping and the Fourier features are computed once per distinct (clip, time scale, frequency count)."""
         if frame_id is None:
             frame_id = torch.arange(self.num_frames, device=self.head[0].weight.device)
-        x = self.time_embedding(frame_id)
+        x = self.time_embedding(frame_id, shared)
         out = x
         for i in range(self.D):
             if i in self.skips:
