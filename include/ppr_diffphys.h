@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PD_ABI_VERSION 8   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches); 7: pd_reduce_loss (reduce_loss on any table, threshold from env 0 as the reference takes it), pd_model_set_numeric_policy (the reference's literal acos forms as a run-time mode); 8: pd_colsum */
+#define PD_ABI_VERSION 9   /* 2: host frame2step (validated), per-model timing, per-env joint_X_p binding; 3: pose algebra + foot height; 4: gradient post-processing (remove_nan / FK clamp) inside the kernels, pd_build_id; 5: pd_model_contact_order (decoding the hit log), pd_rollout_forward_traj_loss / pd_rollout_backward_traj_loss (row f4), pd_model_set_kernel_family (quad-lane small-batch kernels); 6: pd_rollout_forward_traj_loss_fk / pd_rollout_backward_traj_loss_fk (the FK of the control reference rides on the trajectory-loss launches); 7: pd_reduce_loss (reduce_loss on any table, threshold from env 0 as the reference takes it), pd_model_set_numeric_policy (the reference's literal acos forms as a run-time mode); 8: pd_colsum; 9: pd_linear_wgrad (the time-MLPs' weight + bias gradients on the fp32 matrix cores) */
 
 /* Articulation template: HOST pointers, copied by pd_model_create.  One template for all envs. */
 typedef struct pd_model_desc {
@@ -295,6 +295,15 @@ int pd_foot_height_vjp(int n, int nb, const float *body_q_dev, const int *c_body
  * slices in order); NULL, or n <= 1024: one slice, one launch -- the result of a given (n, k, ws given or not) never depends on anything else. */
 #define PD_COLSUM_SLICES 32
 int pd_colsum(int n, int k, const float *x_dev, float *out_dev, float *ws_dev, void *stream);
+
+/* Weight and bias gradient of a linear layer y = x W^T + b over n samples, on the fp32 matrix cores (csrc/pd_mlp.hip):
+ *   gw[m][kin] = sum_s g[s][m] x[s][kin],   gb[m] = sum_s g[s][m]   (gb_dev may be NULL)
+ * g_dev [n][m] = dL/dy, x_dev [n][kin], row-major, contiguous.  Fixed summation order: the same bits on every call, eagerly and in a replayed
+ * HIP graph.  Reference: torch autograd of nn.Linear in the time-MLPs (diffphys/lab4d_utils.py BaseMLP / TimeMLP; torch_utils.py:116-180) at
+ * the training window of main.py:86 (n = 7 600).  Shapes: m and kin multiples of 128; pd_linear_wgrad_workspace_floats returns 0 for any other
+ * shape (the caller keeps its BLAS path) and otherwise the floats of caller-owned scratch ws_dev needs. */
+size_t pd_linear_wgrad_workspace_floats(int n, int m, int kin);
+int pd_linear_wgrad(int n, int m, int kin, const float *g_dev, const float *x_dev, float *gw_dev, float *gb_dev, float *ws_dev, void *stream);
 
 /* Device time (ms) of this model's last `kind` launch, measured with hipEvents recorded on the launch stream around
  * the kernel: kind 0 = rollout forward, 1 = rollout backward.  Enabled per model by pd_model_set_timing(m, 1); used by

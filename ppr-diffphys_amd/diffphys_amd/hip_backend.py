@@ -15,7 +15,7 @@ _LIB_PATH = os.environ.get("PPR_DIFFPHYS_LIB") or os.path.join(os.path.dirname(o
 _lib = None
 
 NUM_STABLE, NUM_LITERAL = 0, 1  # PD_NUM_* of include/ppr_diffphys.h (DeviceModel.set_numeric_policy)
-ABI_VERSION = 8  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
+ABI_VERSION = 9  # PD_ABI_VERSION of include/ppr_diffphys.h this binding was written against
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -89,6 +89,9 @@ def lib():
         L.pd_foot_height.argtypes = [ci, ci, ci] + [vp] * 6 + [vp]
         L.pd_foot_height_vjp.argtypes = [ci, ci] + [vp] * 6 + [vp]
         L.pd_colsum.argtypes = [ci, ci, vp, vp, vp, vp]
+        L.pd_linear_wgrad_workspace_floats.restype = ctypes.c_size_t
+        L.pd_linear_wgrad_workspace_floats.argtypes = [ci, ci, ci]
+        L.pd_linear_wgrad.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp]
         if L.pd_abi_version() != ABI_VERSION and not (os.environ.get("PPR_DIFFPHYS_LIB") and os.environ.get("PPR_DIFFPHYS_ANY_ABI")):  # scripts/ab_time.sh times older builds
             raise RuntimeError("libpprdiffphys_hip.so ABI mismatch: library %d, binding %d" % (L.pd_abi_version(), ABI_VERSION))
         _lib = L
@@ -142,7 +145,7 @@ def source_hash():
     import hashlib
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "pd_trajloss.h", "../../include/ppr_diffphys.h", "Makefile"]
+    srcs = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_mlp.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "pd_trajloss.h", "../../include/ppr_diffphys.h", "Makefile"]
     h = hashlib.sha256()
     try:
         for f in srcs:
@@ -543,6 +546,24 @@ def colsum(x):
     if rc != 0:
         raise RuntimeError("pd_colsum failed (rc %d)" % rc)
     return out
+
+
+def linear_wgrad(g, x, want_bias=True):
+    """``pd_linear_wgrad``: (g^T x [m, kin], column sums of g [m] or None) for g [n, m] = dL/dy and x [n, kin] -- the weight and bias
+    gradient of a linear layer on the fp32 matrix cores, fixed summation order.  Returns None when the shape is not served (m or kin not a
+    multiple of 128): the caller keeps its BLAS path."""
+    n, m = int(g.shape[0]), int(g.shape[1])
+    kin = int(x.shape[1])
+    ws_floats = lib().pd_linear_wgrad_workspace_floats(n, m, kin)
+    if ws_floats == 0 or int(x.shape[0]) != n:
+        return None
+    gw = torch.empty(m, kin, dtype=torch.float32, device=g.device)
+    gb = torch.empty(m, dtype=torch.float32, device=g.device) if want_bias else None
+    ws = torch.empty(ws_floats, dtype=torch.float32, device=g.device)
+    rc = lib().pd_linear_wgrad(n, m, kin, _dev(g, "g", n * m), _dev(x, "x", n * kin), _dev(gw, "gw"), _dev(gb, "gb") if want_bias else None, _dev(ws, "ws"), _stream())
+    if rc != 0:
+        raise RuntimeError("pd_linear_wgrad failed (rc %d)" % rc)
+    return gw, gb
 
 
 def pose_op_vjp(op, a, b, g_out, need_a=True, need_b=True):

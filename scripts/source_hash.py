@@ -6,7 +6,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ppr-diffphys_amd", "csrc")
-SRCS = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "pd_trajloss.h", "../../include/ppr_diffphys.h", "Makefile"]
+SRCS = ["pd_kernels.hip", "pd_host.hip", "pd_loss.hip", "pd_pose.hip", "pd_mlp.hip", "pd_math.h", "pd_device.h", "pd_args.h", "pd_se3.h", "pd_quad.h", "pd_trajloss.h", "../../include/ppr_diffphys.h", "Makefile"]
 
 
 def source_hash(csrc=CSRC):

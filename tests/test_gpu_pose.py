@@ -183,3 +183,48 @@ def test_colsum_against_float64_and_inside_a_replayed_graph(n, k, dev):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, hip_backend.colsum(fresh)), trial
+
+
+@pytest.mark.parametrize("n,m,kin", [(1, 128, 128), (2, 128, 128), (17, 128, 256), (119, 256, 128), (760, 256, 256), (7600, 256, 256), (7600, 256, 512), (1255, 128, 384),
+                                     (30001, 256, 256)])
+def test_linear_wgrad_on_the_matrix_cores_against_float64(n, m, kin, dev):
+    """pd_linear_wgrad: gw = g^T x and gb = column sums of g for a linear layer's backward, v_mfma_f32_32x32x2_f32 tiles over sample slices
+    then the slices in order.  Against float64 products (bar: 1e-6 of sum |g||x| per entry -- fp32 chains of n terms reach ~3e-7 of it);
+    bit-identical run to run; the second and third replay of a captured graph give the products of the data in the buffers THEN; shapes the
+    kernel does not serve return None (the caller keeps its BLAS path)."""
+    from diffphys_amd import hip_backend
+
+    gen = torch.Generator(device="cpu").manual_seed(n + 7 * m + 13 * kin)
+    g = (torch.randn(n, m, generator=gen) * 0.7).to(dev)
+    x = (torch.randn(n, kin, generator=gen) * 1.3 + 0.2).to(dev)
+    gw, gb = hip_backend.linear_wgrad(g, x)
+    assert gw.shape == (m, kin) and gb.shape == (m,)
+    ref_w = g.double().t() @ x.double()
+    ref_b = g.double().sum(0)
+    bound_w = g.abs().double().t() @ x.abs().double()
+    bound_b = g.abs().double().sum(0)
+    assert float(((gw.double() - ref_w).abs() / (bound_w + 1e-30)).max()) < 1e-6
+    assert float(((gb.double() - ref_b).abs() / (bound_b + 1e-30)).max()) < 1e-6
+    gw2, gb2 = hip_backend.linear_wgrad(g, x)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    gw3, none_b = hip_backend.linear_wgrad(g, x, want_bias=False)
+    assert none_b is None and torch.equal(gw3, gw)
+    assert hip_backend.linear_wgrad(g[:, :100].contiguous(), x) is None and hip_backend.linear_wgrad(g, x[:, :21].contiguous()) is None
+    gbuf, xbuf = g.clone(), x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip_backend.linear_wgrad(gbuf, xbuf)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ow, ob = hip_backend.linear_wgrad(gbuf, xbuf)
+    torch.cuda.current_stream().wait_stream(side)
+    for trial in range(3):
+        g2 = (torch.randn(n, m, generator=gen) * (trial + 0.5)).to(dev)
+        x2 = torch.randn(n, kin, generator=gen).to(dev)
+        gbuf.copy_(g2); xbuf.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        ew, eb = hip_backend.linear_wgrad(g2, x2)
+        assert torch.equal(ow, ew) and torch.equal(ob, eb), trial

@@ -126,7 +126,7 @@ def test_c_abi_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = sorted(set(re.findall(r"\b(pd_[A-Za-z0-9_]+)\s*\(", hdr)))
-    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and "pd_build_id" in names and "pd_model_contact_order" in names and "pd_rollout_backward_traj_loss" in names and "pd_model_set_kernel_family" in names and "pd_rollout_backward_traj_loss_fk" in names and "pd_reduce_loss" in names and "pd_model_set_numeric_policy" in names and "pd_colsum" in names and len(names) == 32
+    assert "pd_rollout_forward" in names and "pd_fk_backward" in names and "pd_model_bind_joint_X_p" in names and "pd_pose_op_vjp" in names and "pd_build_id" in names and "pd_model_contact_order" in names and "pd_rollout_backward_traj_loss" in names and "pd_model_set_kernel_family" in names and "pd_rollout_backward_traj_loss_fk" in names and "pd_reduce_loss" in names and "pd_model_set_numeric_policy" in names and "pd_colsum" in names and "pd_linear_wgrad" in names and len(names) == 34
     lib = hip_backend.lib()
     for n in names:
         assert hasattr(lib, n), "missing symbol " + n
@@ -136,8 +136,8 @@ def test_c_abi_exports_every_declared_symbol():
     assert exported == set(names), sorted(exported ^ set(names))
     # the binary was built from the sources beside it (pd_build_id = "<git HEAD>+<source hash>")
     assert hip_backend.check_build_matches_sources().endswith("+" + hip_backend.source_hash())
-    assert lib.pd_abi_version() == 8 == hip_backend.ABI_VERSION
-    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == hip_backend.ABI_VERSION == 8
+    assert lib.pd_abi_version() == 9 == hip_backend.ABI_VERSION
+    assert int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1)) == hip_backend.ABI_VERSION == 9
     lib.pd_rollout_workspace_floats.restype = ctypes.c_size_t
     assert lib.pd_rollout_workspace_floats(None, 4, 10) == 0
 
@@ -164,6 +164,9 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert lib.pd_pose_op_vjp(1, 4, None, 1, None, None, None, None, None) != 0 and lib.pd_pose_op_vjp(1, 0, None, 1, None, None, None, None, None) == 0
     assert lib.pd_foot_height(4, 13, 0, *([None] * 7)) != 0 and lib.pd_foot_height(4, 13, 8, *([None] * 7)) != 0 and lib.pd_foot_height(0, 13, 8, *([None] * 7)) == 0
     assert lib.pd_foot_height_vjp(4, 13, *([None] * 7)) != 0 and lib.pd_foot_height_vjp(0, 13, *([None] * 7)) == 0
+    lib.pd_linear_wgrad_workspace_floats.restype = ctypes.c_size_t
+    assert lib.pd_linear_wgrad_workspace_floats(7600, 256, 512) == 32 * (256 * 512 + 256) and lib.pd_linear_wgrad_workspace_floats(7600, 256, 21) == 0
+    assert lib.pd_linear_wgrad(7600, 256, 21, *([None] * 6)) != 0 and lib.pd_linear_wgrad(7600, 256, 256, *([None] * 6)) != 0
     assert lib.pd_colsum(4, 8, None, None, None, None) != 0 and lib.pd_colsum(-1, 8, None, None, None, None) != 0 and lib.pd_colsum(4, 0, None, None, None, None) == 0
     assert lib.pd_model_bind_joint_X_p(None, None, 0) != 0
     assert lib.pd_model_contact_order(None, None, 0) != 0
