@@ -28,7 +28,7 @@ dur = lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 
 
 def group(n):
-    if "k_rollout" in n or "k_reduce_fk" in n or "k_seeds_fk" in n or "k_fk" in n or "k_pose" in n or "k_foot" in n or "k_se3" in n or "k_traj" in n:
+    if any(k in n for k in ("k_rollout", "k_reduce_fk", "k_seeds_fk", "k_fk", "k_pose", "k_foot", "k_se3", "k_traj", "k_linear_wgrad", "k_colsum")):
         import re
         return "library: " + re.search(r"k_[a-z0-9_]+(<[^>]*>)?", n).group(0)[:60]
     if n.startswith("Cijk_"):
