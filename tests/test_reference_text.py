@@ -39,8 +39,9 @@ def test_oracle_follows_the_reference_text():
 
 def test_phys_model_forward_fixture_is_reproducible(tmp_path):
     """tests/golden/ref_text_phys_model_forward.npz IS what the reference's phys_model.forward / backward text gives over the stand-ins today"""
+    # (4 threads: with the default -- one per core for torch AND for the C oracle's OpenMP -- the two pools fight and the run takes 2-10 x longer)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_phys_model_vs_reference_text.py"), "--out", str(tmp_path / "f.npz")],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert out.returncode == 0, out.stderr[-2000:]
     with np.load(os.path.join(ROOT, "tests", "golden", "ref_text_phys_model_forward.npz")) as a, np.load(str(tmp_path / "f.npz")) as b:
         assert sorted(a.files) == sorted(b.files)
