@@ -408,8 +408,19 @@ class phys_model(nn.Module):
         """``q_init_noise``: the tensor make_q_init_noise() would draw (a captured iteration passes its static buffer)."""
         frame_start = self.compute_frame_start() if frame_start is None else frame_start[: self.num_envs]
         steps_fr = frame_start[:, None] + self.steps_idx_fr[None]
-        vidid, _ = fid_reindex(self._frames_of(steps_fr, 1), len(self.frame_offset_raw) - 1, self.frame_offset_raw)
-        outseq_idx = (vidid[:, :1] - vidid) != 0
+        if len(self.frame_offset_raw) - 1 == 1:
+            # one video: no frame of a window lies in another video than its first -- the mask the reference computes (fid_reindex, then
+            # vidid[:, :1] != vidid; dp_model.py:673-676) is all False; a cached constant instead of ~15 launches per forward()
+            key = (int(steps_fr.shape[0]), self.frames_per_wdw, str(steps_fr.device))
+            cache = self.__dict__.setdefault("_no_outseq", {})
+            outseq_idx = cache.get(key)
+            if outseq_idx is None:
+                if len(cache) > 8:
+                    cache.clear()
+                outseq_idx = cache[key] = torch.zeros(self._frames_of(steps_fr, 1).shape, dtype=torch.bool, device=steps_fr.device)
+        else:
+            vidid, _ = fid_reindex(self._frames_of(steps_fr, 1), len(self.frame_offset_raw) - 1, self.frame_offset_raw)
+            outseq_idx = (vidid[:, :1] - vidid) != 0
         target_position, ref_ja, queried_q, queried_qd, torques, res_f = self.get_batch_input(steps_fr)
 
         res_fin = res_f.clone()
