@@ -177,3 +177,31 @@ def test_batched_gradient_history_matches_the_reference_loop(steady):
     before = hist.Q.clone(), list(hist.fill)
     hist.plan(names, [torch.randn(s) for s in shapes])
     assert torch.equal(hist.Q, before[0]) and hist.fill == before[1]
+
+
+def test_time_mlp_linear_functions_match_torch_autograd():
+    """time_mlp's custom autograd Functions (bias gradient by a sum the graph replay survives, ReLU in the GEMM, the shared time embedding)
+    against plain torch on the CPU: outputs and all three gradients of relu(x W^T + b) and of x W^T + b, and a TimeMLPWrapper evaluated
+    with and without the shared-embedding dict."""
+    from diffphys_amd import time_mlp
+
+    torch.manual_seed(3)
+    x = torch.randn(37, 24, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(16, 24, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(16, dtype=torch.float64, requires_grad=True)
+    up = torch.randn(37, 16, dtype=torch.float64)
+    for fn, ref in ((time_mlp._LinearReluGemmBias.apply, lambda: torch.relu(torch.nn.functional.linear(x, w, b))),
+                    (time_mlp._LinearGemmBias.apply, lambda: torch.nn.functional.linear(x, w, b))):
+        got = fn(x, w, b)
+        g = torch.autograd.grad(got, (x, w, b), up)
+        want = ref()
+        gr = torch.autograd.grad(want, (x, w, b), up)
+        assert torch.allclose(got, want, rtol=1e-12, atol=1e-12)
+        assert all(torch.allclose(a, c, rtol=1e-11, atol=1e-12) for a, c in zip(g, gr))
+    torch.manual_seed(5)
+    mlp = time_mlp.TimeMLPWrapper(90, out_channels=7)
+    t = torch.linspace(0, 89, 41)
+    a = mlp(t)
+    shared = {}
+    b1, b2 = mlp(t, shared), mlp(t, shared)   # the second call reads the cached mapping and Fourier features
+    assert torch.equal(a, b1) and torch.equal(a, b2) and len(shared) == 2
