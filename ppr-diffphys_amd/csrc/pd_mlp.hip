@@ -103,12 +103,12 @@ __global__ __launch_bounds__(256) void k_linear_wgrad_reduce(int slices, int cou
   if (i >= count_w) { i -= count_w; src = ws_b; dst = gb; count = count_b; }
   if (i >= count) return;
   float t = src[i];
-  for (int s0 = 1; s0 < slices; s0 += 8) {
-    float v[8];
+  for (int s0 = 1; s0 < slices; s0 += 32) {   // 32 loads in flight per thread (8: the kernel was eight dependent round trips long, 5.7 us)
+    float v[32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = s0 + u < slices ? src[(size_t)(s0 + u) * count + i] : 0.f;
+    for (int u = 0; u < 32; ++u) v[u] = s0 + u < slices ? src[(size_t)(s0 + u) * count + i] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t = s0 + u < slices ? t + v[u] : t;
+    for (int u = 0; u < 32; ++u) t = s0 + u < slices ? t + v[u] : t;
   }
   dst[i] = t;
 }
