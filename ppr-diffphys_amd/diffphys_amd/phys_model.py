@@ -248,6 +248,7 @@ class phys_model(nn.Module):
             raise FloatingPointError("total_loss is NaN")  # deferred from forward(), see there
         if not (host[1] <= thresh):  # too large OR not finite (NaN > thresh is False: a NaN norm must not reach the optimiser)
             self.optimizer.zero_grad()
+            self._rezero_grad_bufs()   # clip_grad_norm_ with a NaN norm has just written 0 * NaN into the cached zero gradients
             if get_local_rank() == 0:
                 print("large grad: %.2f, clear gradients" % host[1])
             if self.model_cache[0] is not None:
@@ -345,6 +346,14 @@ class phys_model(nn.Module):
                     if b is None or b.shape != p.shape or b.device != p.device:
                         b = z[p] = torch.zeros_like(p)
                     p.grad = b   # (update()'s zero_grad(set_to_none=True) detaches it again; the guards scale it in place: still zero)
+
+    def _rezero_grad_bufs(self):
+        """The cached zero gradients are SHARED across iterations, and the guards scale gradients in place: a finite factor leaves zeros
+        zero, a NaN clip coefficient (some other gradient was NaN) does not -- and zero_grad() only detaches the buffer.  Called on the
+        guard's clear / roll-back path, so that the NaN iteration cannot poison every later global norm."""
+        bufs = list(self.__dict__.get("_zero_grad_bufs", {}).values())
+        if bufs:
+            torch._foreach_zero_(bufs)
 
     @staticmethod
     def rearrange_pred(queried_q, queried_ja, queried_qd, torques, res_f):
@@ -519,8 +528,18 @@ class phys_model(nn.Module):
         return t
 
     def _inv_norm_inertia(self):
-        if getattr(self, "_inv_norm_cache", None) is None:
-            self._inv_norm_cache = self.norm_body_inertia.inverse().contiguous()
+        """inverse(norm_body_inertia), made once per VALUE of that buffer: keyed on its storage, version counter and device, so that
+        load_state_dict / load_checkpoint (an in-place copy: the version moves) and .to(device) (another storage) invalidate it."""
+        nbi = self.norm_body_inertia
+        key = (nbi.data_ptr(), nbi._version, str(nbi.device))
+        cache = getattr(self, "_inv_norm_cache", None)
+        if cache is None or getattr(self, "_inv_norm_key", None) != key:
+            inv = nbi.inverse().contiguous()
+            if cache is not None and cache.device == inv.device and cache.shape == inv.shape:
+                cache.copy_(inv)   # in place: a captured iteration reads this tensor BY ADDRESS (iteration() re-checks the key before a replay)
+            else:
+                self._inv_norm_cache = inv
+            self._inv_norm_key = key
         return self._inv_norm_cache
 
     def backward(self, loss):
@@ -567,6 +586,7 @@ class phys_model(nn.Module):
         quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if quiet is not None:  # the parameters' AccumulateGrad nodes were made on the default stream (eager iterations, the constructor's FK):
             quiet(False)       # intended here -- the warm-up below runs them on the capturing stream before anything is captured
+        ok, st, failure = True, None, None
         try:
             with torch.cuda.stream(side):
                 for _ in range(3):   # warm-up on the capturing stream: allocator, frame tables of the rollout, rocBLAS handles
@@ -582,37 +602,45 @@ class phys_model(nn.Module):
                     out = self.forward(frame_start=g_fs, q_init_noise=g_noise)
                     out["total_loss"].backward()
             torch.cuda.current_stream().wait_stream(side)
+            st = dict(graph=graph, fs=g_fs, noise=g_noise, out=out, nan=self._pending_nan, grads=[(p, p.grad) for p in params if p.grad is not None],
+                      side=dict(grfs=self.grfs, jafs=self.jafs, sim=self.sim_trajs._dev, tgt=self.target_trajs._dev, pid=self.pid_ref._dev,
+                                info=self.traj_loss_info), shape=(n, self.frames_per_wdw), weights=weights, env=self.env, replays=0)
+            if validate:
+                for trial in range(2):
+                    draw()
+                    graph.replay()
+                    got = {k: v.detach().clone() for k, v in out.items()}
+                    got_g = [g.clone() for _, g in st["grads"]]
+                    for p in params:
+                        p.grad = None
+                    self._pending_nan = None
+                    ref = self.forward(frame_start=g_fs.clone(), q_init_noise=g_noise.clone())
+                    ref["total_loss"].backward()
+                    bad = [k for k in got if not torch.equal(got[k], ref[k].detach())]
+                    names = {id(p): nme for nme, p in self.named_parameters()}
+                    bad += [names[id(p)] for (p, _), g in zip(st["grads"], got_g) if p.grad is None or not torch.equal(g, p.grad)]
+                    if verbose or bad:
+                        print("capture_iteration: replay %d vs eager: %s" % (trial, "bit-identical (%d loss terms, %d gradients)" % (len(got), len(got_g)) if not bad
+                                                                             else "DIFFERENT in %s" % bad[:12]))
+                    ok = ok and not bad
+        except Exception as e:   # an op that cannot be captured, the graph pool out of memory, an allocator error: stay eager, do not abort training
+            ok, st, failure = False, None, "%s: %s" % (type(e).__name__, e)
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
         finally:
             torch.autograd.set_multithreading_enabled(mt)
-        st = dict(graph=graph, fs=g_fs, noise=g_noise, out=out, nan=self._pending_nan, grads=[(p, p.grad) for p in params if p.grad is not None],
-                  side=dict(grfs=self.grfs, jafs=self.jafs, sim=self.sim_trajs._dev, tgt=self.target_trajs._dev, pid=self.pid_ref._dev,
-                            info=self.traj_loss_info), shape=(n, self.frames_per_wdw), weights=weights, env=self.env, replays=0)
-        ok = True
-        if validate:
-            for trial in range(2):
-                draw()
-                graph.replay()
-                got = {k: v.detach().clone() for k, v in out.items()}
-                got_g = [g.clone() for _, g in st["grads"]]
-                for p in params:
-                    p.grad = None
-                self._pending_nan = None
-                ref = self.forward(frame_start=g_fs.clone(), q_init_noise=g_noise.clone())
-                ref["total_loss"].backward()
-                bad = [k for k in got if not torch.equal(got[k], ref[k].detach())]
-                names = {id(p): nme for nme, p in self.named_parameters()}
-                bad += [names[id(p)] for (p, _), g in zip(st["grads"], got_g) if p.grad is None or not torch.equal(g, p.grad)]
-                if verbose or bad:
-                    print("capture_iteration: replay %d vs eager: %s" % (trial, "bit-identical (%d loss terms, %d gradients)" % (len(got), len(got_g)) if not bad
-                                                                         else "DIFFERENT in %s" % bad[:12]))
-                ok = ok and not bad
+            if quiet is not None:
+                quiet(True)   # (torch's default)
         for p in params:
             p.grad = None
         self._pending_nan = keep_pending
         if ok:
             self._graph = st
         elif get_local_rank() == 0:
-            print("capture_iteration: the captured iteration does not replay bit for bit on this stack -- staying eager")
+            print("capture_iteration: %s -- staying eager" % ("capture failed (%s)" % failure if failure is not None else
+                                                             "the captured iteration does not replay bit for bit on this stack"))
         return ok
 
     def _graph_usable(self):
@@ -631,6 +659,7 @@ class phys_model(nn.Module):
             self.backward(out["total_loss"])
             return out
         self._attach_zero_grads()
+        self._inv_norm_inertia()   # (a host-side key check; refreshes the tensor the graph reads when norm_body_inertia was reloaded)
         st = self._graph
         st["fs"].copy_(self.compute_frame_start(), non_blocking=True)
         noise = self.make_q_init_noise()

@@ -73,7 +73,7 @@ class _LinearReluGemmBias(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, out = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(g, out, 0)
+        g = torch.ops.aten.threshold_backward(g, out, 0).contiguous()   # (dense already on the current path; a permuted upstream gradient must not raise in hip_backend)
         gx = g @ weight if ctx.needs_input_grad[0] else None
         gw, gb = _weight_bias_grads(g, x, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return gx, gw, gb
@@ -92,16 +92,11 @@ def _ones_row(n, like):
 
 
 def _gemm_long_k(a, b):
-    """a [m, K] @ b [K, n] with K >> m, n (the weight gradient: K = samples): on MI355X / ROCm 7 rocBLAS has a 24 us kernel for
-    256 x 7600 x 256 where hipBLASLt, torch's default, picks a 55 us one (scripts/micro/gemm_shapes.py) -- routed there when K is long.
-    The choice depends on shapes only, so the eager and the captured iteration take the same kernel."""
-    if a.is_cuda and a.shape[1] >= 2048 and torch.version.hip is not None:
-        prev = torch.backends.cuda.preferred_blas_library()
-        try:
-            torch.backends.cuda.preferred_blas_library("hipblas")
-            return a @ b
-        finally:
-            torch.backends.cuda.preferred_blas_library(prev)
+    """a [m, K] @ b [K, n] with K >> m, n (the weight gradient of a layer that is NOT 128-aligned: 3 of the 30 per iteration; the aligned ones
+    are the library's `pd_linear_wgrad`).  torch's default BLAS.  Round 5 flipped the PROCESS-GLOBAL `preferred_blas_library` to rocBLAS
+    around this product (24 us against hipBLASLt's 55 at 256 x 7600 x 256) -- from autograd's backward thread, a data race with any other
+    thread issuing GEMMs: dropped; the shapes left here are small-output heads where the two libraries are within
+    a few us of each other."""
     return a @ b
 
 

