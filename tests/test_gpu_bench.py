@@ -55,7 +55,11 @@ def test_bench_self_launches_two_ranks():
     """`python bench.py --gpus 2` as the driver types it for N = 1 (no launcher): the parent starts two rank processes itself.  On this
     1-GPU box the ranks share the device (PPR_BENCH_SHARE_GPU test hook; RCCL refuses two ranks on one device, so the barrier falls back
     to gloo AND the line says so): the multi-rank code path -- sharding, barrier, MAX over ranks, both scaling modes -- runs for real."""
-    env = dict(os.environ, PPR_BENCH_SHARE_GPU="1")
+    # (the child ranks are pinned to ONE device -- the first this process may see -- so that the test means the same on a multi-GPU host: ADVICE r5)
+    first = (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or "0").split(",")[0]
+    one_gpu = dict(os.environ, HIP_VISIBLE_DEVICES=first)
+    one_gpu.pop("CUDA_VISIBLE_DEVICES", None)
+    env = dict(one_gpu, PPR_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "3"],
                          cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -71,7 +75,7 @@ def test_bench_self_launches_two_ranks():
     assert o["scaling"] == "weak" and o["global_batch"] == 8192 and o["envs_per_gpu"] == 4096
     assert "cpu_baseline" not in d and "boundary" not in d   # N = 1 only
     # two ranks that would share a GPU WITHOUT the test hook: refused, and quickly (a dead rank no longer leaves the other in the rendezvous)
-    env2 = {k: v for k, v in os.environ.items() if k != "PPR_BENCH_SHARE_GPU"}
+    env2 = {k: v for k, v in one_gpu.items() if k != "PPR_BENCH_SHARE_GPU"}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "2"],
                          cwd=ROOT, capture_output=True, text=True, timeout=300, env=env2)
     assert out.returncode != 0 and "no GPU of its own" in out.stderr

@@ -217,6 +217,15 @@ def test_nan_guards_of_the_update(dev):
     after = model.state_dict()
     assert all(torch.equal(before[k], after[k]) or torch.equal(after[k], model.model_cache[0][k].to(after[k].device)) for k in before)
     assert all(torch.isfinite(v).all() for v in after.values() if v.is_floating_point())
+    # clip_grad_norm_ with that NaN norm wrote 0 * NaN into the CACHED zero gradients of torque_mlp / residual_f_mlp, which
+    # zero_grad() only detaches -- every later global norm was NaN and the guard could never recover.  The clear path re-zeroes them:
+    bufs = list(model._zero_grad_bufs.values())
+    assert bufs and all(bool((b == 0).all()) for b in bufs)
+    out = model.forward(frame_start=fs)
+    model.backward(out["total_loss"])
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.torque_mlp.parameters())
+    gd = model.update()                                  # the NEXT iteration is clean: a finite norm, the optimiser steps
+    assert gd != {} and all(np.isfinite(float(v)) for v in gd.values())
     with torch.no_grad():
         model.forward(frame_start=fs)
     assert getattr(model, "_pending_nan", None) is None
