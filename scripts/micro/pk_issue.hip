@@ -52,6 +52,6 @@ void run(float *d, unsigned long long *c, int wps) {
 int main() {
   float *d; unsigned long long *c;
   (void)hipMalloc(&d, 1 << 22); (void)hipMalloc(&c, 256 * 8);
-  for (int wps : {1, 2, 3, 4})  // (4 waves per SIMD = 1024 threads, the largest workgroup) { run<0>(d, c, wps); run<1>(d, c, wps); run<2>(d, c, wps); run<3>(d, c, wps); }
+  for (int wps : {1, 2, 3, 4}) /* 4 waves per SIMD = 1024 threads, the largest workgroup */ { run<0>(d, c, wps); run<1>(d, c, wps); run<2>(d, c, wps); run<3>(d, c, wps); }
   return 0;
 }
