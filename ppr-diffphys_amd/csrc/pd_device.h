@@ -117,6 +117,27 @@ PD_DEV void wrench_add_from_n(v3 &t, v3 &f, const float *const (&s)[N]) {
   t = V3(acc[0].x, acc[0].y, acc[1].x); f = V3(acc[1].y, acc[2].x, acc[2].y);
 }
 
+// ... and with the own joint's wrench SUBTRACTED first: ((((c0 - w) + c1) + c2) + ...) = ((((-w) + c0) + c1) + ...) bit for bit, without the six
+// sign flips that forming -w costs (the packed add takes the negation as an operand modifier)
+template <int N>
+PD_DEV void wrench_sub_add_from_n(v3 &t, v3 &f, v3 wt, v3 wf, const float *const (&s)[N]) {
+  pd_f2 c[N][3], acc[3], w[3];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { c[k][j].x = s[k][2 * j]; c[k][j].y = s[k][2 * j + 1]; }
+  }
+  w[0].x = wt.x; w[0].y = wt.y; w[1].x = wt.z; w[1].y = wf.x; w[2].x = wf.y; w[2].y = wf.z;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) acc[j] = c[0][j] - w[j];
+#pragma unroll
+  for (int k = 1; k < N; ++k) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] += c[k][j];
+  }
+  t = V3(acc[0].x, acc[0].y, acc[1].x); f = V3(acc[1].y, acc[2].x, acc[2].y);
+}
+
 PD_DEV v3 ld3(const float *p) { return V3(p[0], p[1], p[2]); }
 PD_DEV qt ld4(const float *p) { return Q4(p[0], p[1], p[2], p[3]); }
 
@@ -496,7 +517,9 @@ PD_DEV void joint_ctx(const BodyConst &c, const BodyState &s, v3 rc_c, const flo
 // Rm = rotm(s.r) of this body (the integration made it for the staging).  HP: plain model (joint_ctx) -- the call may then run
 // for EVERY lane, unguarded: a lane without a joint (the FREE root, idle lanes) computes on the record of body c.pidx = 0 and
 // the caller drops its result.
-template <int JT, bool PLAINC = false, bool HP = PLAINC>
+// ALL (round 6, with HP): the model has ONE joint type besides the FREE root (JT is a single bit) and the call runs for every lane without
+// a type test -- no divergent region, no exec-mask code, no moves merging its results; the caller drops the result of a lane without a joint.
+template <int JT, bool PLAINC = false, bool HP = PLAINC, bool ALL = false>
 PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *Rm, const float *rec, const float *tgt,
                       const float *act, const float *ke, const float *kd, v3 &wp_t, v3 &wp_f, v3 &wc_t, v3 &wc_f) {
   JointCtx j;
@@ -510,6 +533,7 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     f_total += j.x_err * ake + j.v_err * akd;
     t_total += qrot(j.q_p, ang_err) * ake + j.w_err * (akd * ads);
   }
+  static_assert(!ALL || (HP && (JT == PD_JT_REVOLUTE || JT == PD_JT_COMPOUND)), "ALL: a plain model with one joint type");
   if ((JT & PD_JT_REVOLUTE) && (HP || c.type == PD_JOINT_REVOLUTE)) {  // :392-409
     v3 axis_p = qrot(j.q_p, c.axis), axis_c = mat_vec(Rm, c.axis);
     float q = twist_angle(dot(qvec(j.r_err), c.axis), j.r_err.w, c.alen);  // :394-400, see pd_math.h
@@ -521,7 +545,7 @@ PD_DEV void joint_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &
     f_total += j.x_err * ake + j.v_err * akd;
     t_total += swing * ake + (j.w_err - axis_p * qd) * (akd * ads);
   }
-  if (PLAINC && (JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {  // :411-445, restructured
+  if (PLAINC && (JT & PD_JT_COMPOUND) && (ALL || c.type == PD_JOINT_COMPOUND)) {  // :411-445, restructured
     const qt q_pc = qmul(qconj(j.q_p), s.r);
     float ang[3];
     v3 b0, b1, b2;
@@ -886,7 +910,7 @@ PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState
   v3 pp = V3(0, 0, 0), w_p = pp, v_p = pp, rc_par = pp;
   qt qp = Q4(0, 0, 0, 1);
   if (HP || c.parent >= 0) {
-    const float *r = rec + c.parent * PD_REC;
+    const float *r = rec + (HP ? c.pidx : c.parent) * PD_REC;  // (pidx: the call may run for a lane without a joint, see the CLONE kernels)
     pp = ld3(r); qp = ld4(r + 3); w_p = ld3(r + 7); v_p = ld3(r + 10); rc_par = ld3(r + 13);
   }
   rev_adjoint_core<HP>(m, c, s, rc_c, pp, qp, w_p, v_p, rc_par, R, tgt, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, aR, a_tgt, a_act, a_ke, a_kd);
@@ -901,6 +925,7 @@ PD_DEV void rev_adjoint(const PdDevModel &m, const BodyConst &c, const BodyState
 // the adjoint takes the clamp's pass / block decision from it -- recomputing w1 there through rotm(q) instead of qrot can land
 // on the other side of +-10 by an ulp, and a rollout that sits on the clamps (a robot dropped into the ground) then differentiates
 // a different function (found by the randomised sweep: one env of 3 200 off by 6 % in every gradient).
+template <bool LEAN = false>  // LEAN (round 6): qmul_pure for the quaternion update (the wave-specialised forward kernels of plain models)
 PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const BodyState &s, const float *Rm, v3 rc, v3 t0, v3 f0, float inv_m,
                                const float *I, const float *invI, float dt, float *R1, v3 &rc_out, float &sink_rate, unsigned &clamp_mask) {
   // Rm = rotm(s.r) (pd_math.h): the four rotations by the body's quaternion are matrix products, exactly as the adjoint
@@ -913,14 +938,30 @@ PD_DEV BodyState integrate_fwd(const PdDevModel &m, const BodyConst &c, const Bo
   v3 wb = matT_vec(Rm, s.w);                                    // :68
   v3 tb = matT_vec(Rm, t0) - cross(wb, mat_vec(I, wb));         // :69
   v3 w1 = mat_vec(Rm, wb + mat_vec(invI, tb) * dt);             // :71
-  qt r1 = qnormalize(s.r + qmul(Q4(w1.x, w1.y, w1.z, 0.f), s.r) * (0.5f * dt));  // :72
+  qt r1 = qnormalize(s.r + (LEAN ? qmul_pure(w1, s.r) : qmul(Q4(w1.x, w1.y, w1.z, 0.f), s.r)) * (0.5f * dt));  // :72
   sink_rate = fabsf(v1.y) + (fabsf(w1.x) + fabsf(w1.y) + fabsf(w1.z)) * c.reach;
   w1 = w1 * (1.0f - 0.1f * dt);                                 // :75
   BodyState o;
+  if constexpr (LEAN) {
+    // the same clamp and the same mask from ONE compare per component: x < -10 || x > 10 is |x| > 10 (false for NaN either way: it passes
+    // unclamped), the clamped value copysign(10, x) -- 4 instructions per component instead of 6.5, one condition register live at a time
+    // instead of twelve (the scalar registers the compare pairs took were spilled around the loop)
+    const float xs[6] = {w1.x, w1.y, w1.z, v1.x, v1.y, v1.z};
+    float ys[6];
+    clamp_mask = 0u;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const bool hit = fabsf(xs[k]) > 10.0f;
+      ys[k] = hit ? copysignf(10.0f, xs[k]) : xs[k];
+      clamp_mask |= hit ? (1u << k) : 0u;
+    }
+    o.w = V3(ys[0], ys[1], ys[2]); o.v = V3(ys[3], ys[4], ys[5]);
+  } else {
   o.w = clamp3(w1, 10.0f); o.v = clamp3(v1, 10.0f);             // :78-88
   clamp_mask = (clamp_pass(w1.x, -10.0f, 10.0f) == 0.0f ? 1u : 0u) | (clamp_pass(w1.y, -10.0f, 10.0f) == 0.0f ? 2u : 0u) |
                (clamp_pass(w1.z, -10.0f, 10.0f) == 0.0f ? 4u : 0u) | (clamp_pass(v1.x, -10.0f, 10.0f) == 0.0f ? 8u : 0u) |
                (clamp_pass(v1.y, -10.0f, 10.0f) == 0.0f ? 16u : 0u) | (clamp_pass(v1.z, -10.0f, 10.0f) == 0.0f ? 32u : 0u);
+  }
   rotm(r1, R1);
   rc_out = mat_vec(R1, c.com);
   o.r = r1; o.p = x1 - rc_out;                                  // :90

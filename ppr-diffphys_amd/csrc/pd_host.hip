@@ -321,11 +321,14 @@ static void build_quad(pd_model *m) {
 static int g_groups = 0;   // -DPD_STAMPS diagnostic builds only (pd_debug_set_groups): env groups per workgroup, 0 = automatic
 
 // Launch geometry of one call: kernel variant, env groups per workgroup (small batches spread over all CUs), LDS bytes.
-static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs) {
+static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs, bool loss = false) {
   const PdDevModel &d = m->dev;
   const int epw = 64 / m->segw, n_groups = (n_envs + epw - 1) / epw;
   PdLaunchCfg c{};
   c.kernel = pd_kernel_variant(kind, m->jt, n_groups, d.cu_count);
+  // the loss-evaluating forward exists wave-specialised only (round 6): its unsplit instantiation does not survive the register allocator in
+  // the branch-free form the other forward kernels of plain models have, and an env must give the same bits whichever kernel runs it
+  if (loss && c.kernel == PD_KV_FWD_UNSPLIT) c.kernel = PD_KV_FWD_SPLIT;
   c.roles = pd_variant_roles(c.kernel);
   c.groups = kind <= PD_K_ROLLOUT_BWD ? (g_groups ? g_groups : pd_groups_per_wg(n_groups, d.cu_count)) : PD_BWAVES;
   c.nblocks = (n_groups + c.groups - 1) / c.groups;
@@ -365,7 +368,7 @@ static hipError_t launch(const pd_model *m, int kind, const void *args, int n_en
     ll[0] = c.nblocks; ll[1] = c.threads; ll[2] = (int)c.lds; ll[3] = c.groups;
     return (m->policy == PD_NUM_LITERAL ? pd_launch_seg64_literal : pd_launch_seg64)(kind, m->quad->jt, d, args, c, st);
   }
-  const PdLaunchCfg c = launch_cfg(m, kind, n_envs);
+  const PdLaunchCfg c = launch_cfg(m, kind, n_envs, kind == PD_K_ROLLOUT_FWD && ((const RolloutArgs *)args)->loss_target != nullptr);
   if (c.nblocks == 0) return hipSuccess;
   if (kind < 2) {
     int *ll = const_cast<pd_model *>(m)->last_launch[kind];

@@ -58,6 +58,12 @@ __device__ __forceinline__ unsigned long long pd_memtime() {
 // per-lane 32-bit BYTE offset computed once, i.e. the saddr + voffset addressing mode -- no per-lane 64-bit multiplies
 // in the loops.  Offsets stay below 4 GB for any batch that fits the workspace.
 typedef const __attribute__((address_space(4))) int *pd_const_int_p;  // constant address space => scalar (s_load) access
+// The saddr + voffset mode only comes out of instruction selection when it SEES  (scalar base) + zext(32-bit lane offset)  in the block of the
+// access.  Both halves are loop-invariant in the rollout loops, so the optimiser hoists  base + zext(offset)  as a per-lane 64-bit address
+// and the loop pays a 64-bit vector add per access plus the scalar chain that feeds it.  PD_OPAQUE_V / _S make a value opaque where they
+// stand (no instruction: an empty asm that "updates" the register), which keeps the two halves apart until selection (round 6).
+#define PD_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#define PD_OPAQUE_S(x) do { if constexpr (CLONE && SPLIT && SEGW < 64) asm volatile("" : "+s"(x)); } while (0)  // (the unsplit instantiations keep these bases in vector registers, and the 64-lane segment's instantiation with all of them forced does not compile -- "illegal VGPR to SGPR copy": not forced there)
 PD_DEV int ld_uniform(const int *p, int i) { return ((pd_const_int_p)(unsigned long long)p)[i]; }  // read-only input, wave-uniform index
 PD_DEV float ldg(const float *ubase, unsigned boff) { return *(const float *)((const char *)ubase + boff); }
 PD_DEV void stg(float *ubase, unsigned boff, float v) { *(float *)((char *)ubase + boff) = v; }
@@ -576,6 +582,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     bool two = false;        // wave-uniform: some env has more candidates than lanes (<= 2 SEGW): lane j also keeps candidate SEGW + j
     int c_e = 0, c_e2 = 0;
     float4 c_P = make_float4(0.f, 0.f, 0.f, 0.f), c_M = c_P, c_P2 = c_P, c_M2 = c_P;
+    // (The cull in TWO pieces -- tile levels behind B(s), point level behind B(s + 1), candidates serving steps s + 2 .. s + K + 1 -- was
+    // built again in round 6 on the branch-free body wave: 0.214-0.216 ms against 0.202 at 4096 envs.  At normal priority beside the
+    // body wave's busy phases the point level takes 4 000 cycles instead of 2 200 and still runs into the next hand-over A, the margins
+    // for K + 1 steps make 8.0 candidates per env-step instead of 7.0: EXPERIMENTS.md, profiles/r06_fwd_stamps.txt.)
     for (int step = 0; step < a.nsteps; ++step) {
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
       // A: records + cull vectors of this step are staged, wrench accumulators are zero; bit 30: a body of one of my envs
@@ -931,6 +941,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     }
     return;
   }
+  // CLONE (round 6; wave-specialised kernels of PLAIN models, pd_parented(JT)): the body wave's step is BRANCH-FREE.  An idle lane
+  // (l >= nb) is a full clone of its env's last body -- same constants, same state, same loads -- and writes what that body's lane
+  // writes to the same LDS / global addresses (same values, same instruction); a lane without a joint (the FREE root) runs the joint
+  // pass on the record of body 0 and drops the result in a select.  A lone wave pays ~9 cycles per branch instruction taken or not,
+  // ~2.6 per exec-mask instruction and ~4.5 per v_mov that merges a divergent region's results (scripts/micro/issue_mix.hip,
+  // profiles/r06_issue_mix.txt): the guarded form of this loop carried 22 branches, 13 exec-mask regions and 67 moves per step.
+  // Only GLOBAL stores stay guarded, by env_ok alone (an env slot past the batch clones env 0 without its contacts).
+  // The unsplit instantiations of plain models keep their guards -- two busy waves per SIMD: in the branch-free form human 4096 ran 0.408
+  // ms against 0.349, quad 8192 0.807 against 0.731 -- but take the same ARITHMETIC (LEANA: the quaternion update without its zero
+  // products, the own joint's wrench subtracted inside the packed sums): a compound robot's env must give the same bits on either side of
+  // the batch size that switches kernels (test_unsplit_forward_speculates_and_redoes_its_cull).
+  static_assert(SPLIT || !LOSS, "the loss-evaluating forward is wave-specialised only");
+  constexpr bool CLONE = SPLIT && pd_parented(JT);
+  constexpr bool LEANA = pd_parented(JT);
+  const bool wr = CLONE || is_body;            // LDS writes / per-body work
+  const bool gw = CLONE ? env_ok : is_body;    // global stores
   const size_t idx = (size_t)ec * nb + b;  // flat body index (env-major)
   const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
 
@@ -943,7 +969,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     ke[k] = on ? a.target_ke[(size_t)ec * m.nqd + c.qdstart + k] : 0.f;
     kd[k] = on ? a.target_kd[(size_t)ec * m.nqd + c.qdstart + k] : 0.f;
   }
-  if (is_body) {
+  if (wr) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) facc[b * PD_W6 + k] = 0.f;
   }
@@ -953,7 +979,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   }
   int cz[4];  // first four children, the zero record for a missing one
 #pragma unroll
-  for (int k = 0; k < 4; ++k) cz[k] = is_body && c.child[k] >= 0 ? c.child[k] : nb;
+  for (int k = 0; k < 4; ++k) cz[k] = wr && c.child[k] >= 0 ? c.child[k] : nb;
 
   // ---- eval_fk (dp_model.py:1204): level-synchronous walk of the chain through LDS
   BodyState s;
@@ -961,13 +987,15 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   float Rm[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};  // rotm(s.r) of the current state: integration, staging and the joint's axis share it
   v3 rc = V3(0, 0, 0);  // Rm com of the current state, shared by staging, joints and integration
   float margin = 0.f, sunk = 0.f;  // speculative contact cull: allowed / integrated loss of height since the epoch's state
+  float margin98 = __builtin_inff();
   for (int d = 0; d <= m.max_depth; ++d) {
-    if (is_body && c.depth == d) {
+    if (wr && c.depth == d) {
       s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
       rotm(s.r, Rm);
       rc = mat_vec(Rm, c.com);
       float4 cv = stage_record(rec, cull, b, s, rc, Rm);
       margin = sink_margin(c, s, a.dt);
+      margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
       cv.x -= margin;
       if (SPLIT) spec[b] = cv;  // epoch 0
     }
@@ -977,23 +1005,30 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
 
   // Controls are software-prefetched one step ahead: with one wavefront per SIMD there is no other
   // wave to hide the HBM latency of a load issued at its point of use.
-  const unsigned boff = (unsigned)idx * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;  // per-lane byte offsets
+  unsigned boff = (unsigned)idx * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;  // per-lane byte offsets
+  unsigned boff16 = boff * 4u, boff24 = boff * 6u;  // ... of this body's float4 (trajectory planes) and of its six floats (res_f)
   float n_tgt[ND], n_act[ND], n_rf[6];
   int n_fr = -1;  // frame that state `step` is gathered into (or -1), fetched with the controls
+  size_t ow_prev = (size_t)12 * N;  // CLONE: offset of planes 3-4 of the previous step (of step 0 at step 0)
+
   auto load_controls = [&](int step) {
     const int sc = __builtin_amdgcn_readfirstlane(step < a.nsteps ? step : a.nsteps - 1);  // keeps the address arithmetic scalar
     n_fr = ld_uniform(a.frame_of_step, sc);  // scalar load: no vector-memory instruction for a wave-uniform value
+    // (the LOADS keep the compiler's addressing -- hoisted per-lane 64-bit addresses plus one scalar step offset shared by refs and
+    // torques: the saddr form costs more scalar instructions per array than the vector adds it saves, and running offsets instead of the
+    // step x stride products overflow the scalar register file into v_readlane / v_writelane inside the loop: both built and counted)
     const size_t o = (size_t)sc * a.bs * m.nqd;
+    const float *rb = a.refs + o, *tb = a.torques + o, *rf = a.res_f + (size_t)sc * N * 6;
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
-      bool on = k < ndof;
-      n_tgt[k] = on ? ldg(a.refs + o + k, boff_qd) : 0.f;
-      n_act[k] = on ? ldg(a.torques + o + k, boff_qd) : 0.f;
+      // (CLONE: unconditional -- the FREE root reads the first ND of its own six dofs, valid addresses, and its joint result is dropped)
+      bool on = LEANA || k < ndof;
+      n_tgt[k] = on ? ldg(rb + k, boff_qd) : 0.f;
+      n_act[k] = on ? ldg(tb + k, boff_qd) : 0.f;
     }
-    const float *rf = a.res_f + (size_t)sc * N * 6;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const float2 v = ldg2(rf + 2 * k, boff * 6u);
+      const float2 v = ldg2(rf + 2 * k, boff24);
       n_rf[2 * k] = v.x; n_rf[2 * k + 1] = v.y;
     }
   };
@@ -1005,11 +1040,14 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   v3 o_ft = V3(0, 0, 0), o_ff = o_ft;
   unsigned o_mask = 0u, clamp_mask = 0u;  // which velocity components the step's integration clamped (stored for the adjoint)
   auto spill_state = [&](int step, const BodyState &cs, int cfr) {
-    if (!is_body) return;
-    float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
-    stg4(tj, boff * 4u, make_float4(cs.r.x, cs.r.y, cs.r.z, cs.r.w));
-    stg4(tj + (size_t)4 * N, boff * 4u, make_float4(cs.w.x, cs.w.y, cs.w.z, cs.v.x));
-    stg4(tj + (size_t)8 * N, boff * 4u, make_float4(cs.p.x, cs.p.y, cs.p.z, cs.v.y));
+    size_t oj = (size_t)step * (PD_TRAJ_G * 4) * N;
+    PD_OPAQUE_S(oj);  // (the OFFSET: a pointer that went through the asm is a generic one, its accesses flat_*; and in front of the guard:
+    //                    inside the divergent region the forced scalar does not compile)
+    float *tj = a.ws + oj;
+    if (!gw) return;
+    stg4(tj, boff16, make_float4(cs.r.x, cs.r.y, cs.r.z, cs.r.w));
+    stg4(tj + (size_t)4 * N, boff16, make_float4(cs.w.x, cs.w.y, cs.w.z, cs.v.x));
+    stg4(tj + (size_t)8 * N, boff16, make_float4(cs.p.x, cs.p.y, cs.p.z, cs.v.y));
     if (cfr >= 0) {  // frame gather (dp_model.py:1231-1248)
       float *o = a.wp_pos + ((size_t)cfr * N + idx) * 7;
       o[0] = cs.p.x; o[1] = cs.p.y; o[2] = cs.p.z; o[3] = cs.r.x; o[4] = cs.r.y; o[5] = cs.r.z; o[6] = cs.r.w;
@@ -1044,13 +1082,14 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
     }
   };
-  auto spill_wrench = [&](int step) {  // what the o_* registers hold for `step`
-    if (!is_body) return;
-    float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
-    stg4(tj + (size_t)12 * N, boff * 4u, make_float4(o_vz, o_ft.x, o_ft.y, o_ft.z));
-    stg4(tj + (size_t)16 * N, boff * 4u, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
+  auto spill_wrench_at = [&](float *tj) {  // what the o_* registers hold for a step, to planes 3-4 of that step at tj
+    if (!gw) return;
+    stg4(tj, boff16, make_float4(o_vz, o_ft.x, o_ft.y, o_ft.z));
+    stg4(tj + (size_t)4 * N, boff16, make_float4(o_ff.x, o_ff.y, o_ff.z, __uint_as_float(o_mask)));
   };
+  auto spill_wrench = [&](int step) { spill_wrench_at(a.ws + (size_t)step * (PD_TRAJ_G * 4) * N + (size_t)12 * N); };
   if (a.nsteps > 0) load_controls(0);
+
   // unsplit kernel: the speculated candidates of this wave's envs (see the sweep in the loop)
   int u_since = PD_SPEC_K, u_nh = 0, u_e = 0;
   bool u_have = false, u_owns = false;
@@ -1060,6 +1099,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     // hand-over A first: the records of this step were staged at the end of the previous iteration (or by FK), so the
     // contact wave starts sweeping while this wave still unpacks controls and spills the state
     if (SPLIT) pair_signal(sig, (step + 1) | (spec_failed ? PD_SIG_FLAG : 0));  // A: hand this step's records to the contact wave
+    PD_OPAQUE_V(boff16);  // (see PD_OPAQUE_V: the trajectory stores' lane offset stays a 32-bit operand)
     STAMP(0);
     PD_WAIT_VMEM();
     float tgt[ND], act[ND];
@@ -1139,8 +1179,15 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     STAMP(1);
     // ---- eval_body_joints (runs while the contact wave sweeps)
     v3 wp_t = V3(0, 0, 0), wp_f = wp_t, wc_t = wp_t, wc_f = wp_t;
-    if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT, JT == PD_JT_COMPOUND>(m, c, s, rc, Rm, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
-    if (is_body) {
+    if constexpr (LEANA) {  // (the unsplit kernels too: where the joint pass sits among the blocks decides which products the compiler fuses)
+      joint_fwd<JT, JT == PD_JT_COMPOUND, true, true>(m, c, s, rc, Rm, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
+      const bool jointed = c.type != PD_JOINT_FREE;
+      wp_t = jointed ? wp_t : V3(0, 0, 0); wp_f = jointed ? wp_f : V3(0, 0, 0);
+      wc_t = jointed ? wc_t : V3(0, 0, 0); wc_f = jointed ? wc_f : V3(0, 0, 0);
+    } else {
+      if (is_body && c.type != PD_JOINT_FREE) joint_fwd<JT, JT == PD_JT_COMPOUND>(m, c, s, rc, Rm, rec, tgt, act, ke, kd, wp_t, wp_f, wc_t, wc_f);
+    }
+    if (wr) {
       float *pc = pcon + b * PD_W6;
       pc[0] = wp_t.x; pc[1] = wp_t.y; pc[2] = wp_t.z; pc[3] = wp_f.x; pc[4] = wp_f.y; pc[5] = wp_f.z;
     }
@@ -1149,11 +1196,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     v3 jt = -wc_t, jf = -wc_f;  // joint wrench on this body: own joint first, then children in index order
     {  // first four children: all LDS reads are issued back to back (one exposed latency instead of one per child), packed sums
       const float *const src[4] = {pcon + cz[0] * PD_W6, pcon + cz[1] * PD_W6, pcon + cz[2] * PD_W6, pcon + cz[3] * PD_W6};
-      wrench_add_from_n(jt, jf, src);
+      if constexpr (LEANA) wrench_sub_add_from_n(jt, jf, wc_t, wc_f, src);  // (same sums, the negation as an operand modifier)
+      else wrench_add_from_n(jt, jf, src);
     }
     for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
-      if (is_body && cid != 0xff) {
+      if (wr && cid != 0xff) {
         const float *pc = pcon + cid * PD_W6;
         jt += V3(pc[0], pc[1], pc[2]); jf += V3(pc[3], pc[4], pc[5]);
       }
@@ -1163,7 +1211,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       // the previous step's trajectory record and frame outputs are issued where this wave is about to wait anyway (measured
       // against right after hand-over A, and against after the vmcnt wait: -2 % / -0.5 % forward time at 4096 envs)
       spill_state(step, s, fr);
-      if (step > 0) spill_wrench(step - 1);
+      // CLONE: no `step > 0` region of its own -- step 0 writes the zeros o_* hold into step 0's planes 3-4, which step 1 (or the store
+      // behind the loop) overwrites: same lane, same address, program order
+      if constexpr (CLONE) {
+        size_t ow = ow_prev;  // planes 3-4 of step max(step - 1, 0)
+        PD_OPAQUE_S(ow);
+        spill_wrench_at(a.ws + ow);
+        ow_prev = (size_t)step * (PD_TRAJ_G * 4) * N + (size_t)12 * N;
+      } else if (step > 0) {
+        spill_wrench(step - 1);
+      }
       STAMP(8);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
       STAMP(9);
@@ -1172,7 +1229,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       if (step > 0) spill_wrench(step - 1);
       WAVE_SYNC();
     }
-    if (is_body) {
+    if (wr) {
       float *f = facc + b * PD_W6;
       ft += V3(f[0], f[1], f[2]); ff += V3(f[3], f[4], f[5]);
 #pragma unroll
@@ -1180,7 +1237,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     }
     const v3 grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
     ft += jt; ff += jf;
-    if (fr >= 0 && is_body) {  // force snapshots of a frame step (4 of 100 steps): written here, no copies carried for them
+    if (fr >= 0) if (gw) {  // force snapshots of a frame step (the wave-uniform test first: a scalar branch around the region) (4 of 100 steps): written here, no copies carried for them
       if (a.grf) {
         float *o = a.grf + ((size_t)fr * N + idx) * 6;
         o[0] = grf_t.x; o[1] = grf_t.y; o[2] = grf_t.z; o[3] = grf_f.x; o[4] = grf_f.y; o[5] = grf_f.z;
@@ -1197,7 +1254,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     float sink_rate;
     {
       float R1[9];
-      s = integrate_fwd(m, c, s, Rm, rc, ft, ff, inv_m, I, invI, a.dt, R1, rc, sink_rate, clamp_mask);
+      s = integrate_fwd<LEANA>(m, c, s, Rm, rc, ft, ff, inv_m, I, invI, a.dt, R1, rc, sink_rate, clamp_mask);
 #pragma unroll
       for (int k = 0; k < 9; ++k) Rm[k] = R1[k];
     }
@@ -1205,14 +1262,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     STAMP(4);
     {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
       sunk += sink_rate * a.dt;
-      const bool bad = is_body && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin);
+      // CLONE: one compare -- the bound carries "has candidates at all" (+inf otherwise) and the factor, set where the margin is
+      const bool bad = CLONE ? !(sunk <= margin98) : (wr && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin));
       spec_failed = __ballot(bad) != 0ull;
     }
     WAVE_SYNC();
-    if (is_body) {
+    if (wr) {
       float4 cv = stage_record(rec, cull, b, s, rc, Rm);
       if (SPLIT && (step + 1) % PD_SPEC_K == 0) {  // state step+1 opens a speculation epoch
         margin = sink_margin(c, s, a.dt); sunk = 0.f;
+        margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
         cv.x -= margin;
         spec[(((step + 1) / PD_SPEC_K) & 1) * nb + b] = cv;
       }
@@ -2500,10 +2559,8 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
       }
       // (unsplit: compound-only robots above 4 x CUs env groups -- pd_kernel_variant; no other joint mix has that instantiation)
       if (((const RolloutArgs *)args)->loss_target) {  // trajectory loss at the frame states (pd_rollout_forward_traj_loss)
-        if (cfg.kernel == PD_KV_FWD_SPLIT || JT != PD_JT_COMPOUND)
-          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-        else
-          hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, JT != PD_JT_COMPOUND, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+        if (cfg.kernel != PD_KV_FWD_SPLIT) return hipErrorInvalidValue;  // (the host sends every loss-evaluating launch to the split kernel: pd_host.hip launch_cfg)
+        hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
       } else if (cfg.kernel == PD_KV_FWD_SPLIT || JT != PD_JT_COMPOUND)
         hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
       else
@@ -2554,7 +2611,6 @@ static hipError_t set_lds_jt(int bytes) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   }
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-  if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, JT != PD_JT_COMPOUND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_bwd<PD_SEGW, JT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {

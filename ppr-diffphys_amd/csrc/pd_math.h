@@ -50,6 +50,12 @@ PD_DEV qt qmul(qt a, qt b) {
   return Q4(a.w * b.x + b.w * a.x + a.y * b.z - a.z * b.y, a.w * b.y + b.w * a.y + a.z * b.x - a.x * b.z,
             a.w * b.z + b.w * a.z + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z);
 }
+// qmul(Q4(a.x, a.y, a.z, 0), b) without the four products with the zero: the same value for finite b (x + 0 * y is x up to the sign of a
+// zero), four instructions less on a wave whose instruction count is its run time (integrate_bodies :72, round 6)
+PD_DEV qt qmul_pure(v3 a, qt b) {
+  return Q4(b.w * a.x + a.y * b.z - a.z * b.y, b.w * a.y + a.z * b.x - a.x * b.z, b.w * a.z + a.x * b.y - a.y * b.x,
+            -(a.x * b.x) - a.y * b.y - a.z * b.z);
+}
 PD_DEV qt qnormalize(qt q) { return q * rcp_hw(sqrt_hw(qdot(q, q))); }
 PD_DEV v3 qrot(qt q, v3 v) {
   v3 u = qvec(q);

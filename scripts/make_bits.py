@@ -21,6 +21,7 @@ os.makedirs(out_dir, exist_ok=True)
 for name in names:
     tpl = robots.load_template(name)
     dm = hip_backend.DeviceModel(tpl)
+    dm.set_kernel_family(1)   # the lane-per-body kernels, as test_against_frozen_bits pins them
     rec = {}
     for t, inp in (("golden", golden_inputs(load_golden(name))),
                    ("bench8", synth.make_env_inputs(tpl, name, range(8), 100, seed=77, seqs=("mi-trot", "mi-spin"), penetration=0.002))):

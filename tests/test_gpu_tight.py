@@ -424,7 +424,7 @@ def test_against_frozen_bits(name, dev):
     from diffphys_amd import hip_backend, robots, synth
 
     refs = {}
-    for tag in ("r01", "r02", "r03", "r03b", "r05"):
+    for tag in ("r01", "r02", "r03", "r03b", "r05", "r06"):
         path = os.path.join(GOLDEN, "%s_bits_%s.npz" % (tag, name))
         if os.path.exists(path):
             with np.load(path) as z:
@@ -436,7 +436,11 @@ def test_against_frozen_bits(name, dev):
     # ... and, later in round 5, every sqrtf / reciprocal of the rollout kernels became the bare v_sqrt_f32 / v_rcp_f32 (pd_math.h sqrt_hw, rcp_hw:
     # clang's denormal rescue around them gone).  Laikago's kernels kept every bit (its r03b pin still holds); the compound robots' differ by an
     # ulp where a quotient x / d became x * rcp(d) (quat_decompose_adj) -- r05 was re-recorded on that build
-    newest = ([t for t in ("r05", "r03b", "r03") if t in refs] or [None])[0]
+    # r06 (all three robots): the wave-specialised forward kernels of plain models became branch-free (CLONE, csrc/pd_kernels.hip): the joint
+    # pass runs unguarded for every lane, the own joint's wrench is subtracted inside the packed child sums, the quaternion update drops its
+    # products with the zero w, the clamps are one compare per component -- the same terms, but the compiler contracts other multiply-add
+    # pairs in the straight-line code: poses differ from r03b / r05 by 1 ulp (1.2e-7 of the tensor's max on the golden inputs)
+    newest = ([t for t in ("r06", "r05", "r03b", "r03") if t in refs] or [None])[0]
     tpl = robots.load_template(name)
     dm = hip_backend.DeviceModel(tpl)
     dm.set_kernel_family(1)   # the fixtures pin the lane-per-body kernels (these small batches would take the quad-lane ones by default)
