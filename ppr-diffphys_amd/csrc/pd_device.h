@@ -443,9 +443,12 @@ PD_DEV void joint_force_adj(float q, float qd, float target, float ke, float kd,
                             float &adj_act) {
   adj_ke += g * (q - target); adj_q += g * ke; adj_target += -g * ke;
   adj_kd += g * qd; adj_qd += g * kd; adj_act += g;
-  float adj_limit = -g;
-  if (q > up) { adj_q += -lke * adj_limit; if (qd > 0.0f) adj_qd += -lkd * adj_limit; }
-  else if (q < lo) { adj_q += -lke * adj_limit; if (qd < 0.0f) adj_qd += -lkd * adj_limit; }
+  // the limit force's adjoint (:274-281) as selects -- the same sums (x + 0 is x), no divergent region: the nested conditionals compiled to
+  // two taken branches per dof on a wave whose instruction stream is its run time (round 6)
+  const float adj_limit = -g;
+  const bool over = q > up, under = !over && q < lo;
+  adj_q += (over || under) ? -lke * adj_limit : 0.0f;
+  adj_qd += ((over && qd > 0.0f) || (under && qd < 0.0f)) ? -lkd * adj_limit : 0.0f;
 }
 
 // (-fno-signed-zeros, csrc/Makefile: the sign of a zero is not defined in this library.  The one place a value hangs on it is
@@ -618,15 +621,15 @@ struct JointPrep {
   float2 sc0, sc1;  // (sin, cos) of ang[0] / 2 and ang[1] / 2, as q_axis_angle computed them
 };
 
-template <int JT, bool HP = false>
+template <int JT, bool HP = false, bool ALL = false>  // ALL: see joint_fwd -- one joint type, no type tests
 PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodyState &s, v3 rc_c, const float *rec, const float *tgt,
                            const float *act, const float *ke, const float *kd, JointPrep &P) {
   joint_ctx<HP>(c, s, rc_c, rec, P.j);
   const JointCtx &j = P.j;
   const float ake = m.attach_ke, akd = m.attach_kd;
   P.f_raw = j.x_err * ake + j.v_err * akd;
-  P.f_total = ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) ? clamp3(P.f_raw, 1.0e4f) : P.f_raw;
-  if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
+  P.f_total = ((JT & PD_JT_COMPOUND) && (ALL || c.type == PD_JOINT_COMPOUND)) ? clamp3(P.f_raw, 1.0e4f) : P.f_raw;
+  if ((JT & PD_JT_COMPOUND) && (ALL || c.type == PD_JOINT_COMPOUND)) {
     P.qa = HP ? qconj(j.q_p) : qmul(qconj(c.q_off), qconj(j.q_p));  // (HP: identity child frames, see joint_ctx)
     const qt qb = qmul(P.qa, s.r);
     P.q_pc = HP ? qb : qmul(qb, c.q_off);
@@ -662,7 +665,7 @@ PD_DEV void joint_adj_prep(const PdDevModel &m, const BodyConst &c, const BodySt
   }
 }
 
-template <int JT, bool HP = false>
+template <int JT, bool HP = false, bool ALL = false>
 PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyState &s, const JointPrep &P, const float *tgt,
                             const float *act, const float *ke, const float *kd, v3 gc_t, v3 gc_f, v3 gp_t, v3 gp_f, BodyAdj &own,
                             BodyAdj &par, float *a_tgt, float *a_act, float *a_ke, float *a_kd) {
@@ -715,7 +718,7 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     adj_qrot_q(j.q_p, c.axis, adj_q_p, adj_axis_p);
     adj_qrot_q(s.r, c.axis, adj_q_c, adj_axis_c);
   }
-  if ((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND) {
+  if ((JT & PD_JT_COMPOUND) && (ALL || c.type == PD_JOINT_COMPOUND)) {
     const v3 ax[3] = {V3(1, 0, 0), P.ax1, P.ax2};
     v3 adj_f_raw = clamp3_pass(f_raw, adj_f, 1.0e4f);
     adj_x_err += adj_f_raw * ake; adj_v_err += adj_f_raw * akd;
@@ -766,7 +769,7 @@ PD_DEV void joint_adj_apply(const PdDevModel &m, const BodyConst &c, const BodyS
     if (HP) adj_cqp += adj_qa; else adj_qmul_b(qconj(c.q_off), adj_cqp, adj_qa);
     adj_q_p += qconj(adj_cqp);
   }
-  if (!((JT & PD_JT_COMPOUND) && c.type == PD_JOINT_COMPOUND)) {  // r_err = conj(q_p) * q_c  (a COMPOUND joint does not use r_err:
+  if (!((JT & PD_JT_COMPOUND) && (ALL || c.type == PD_JOINT_COMPOUND))) {  // r_err = conj(q_p) * q_c  (a COMPOUND joint does not use r_err:
     qt adj_cqp = Q4(0, 0, 0, 0);                                  //  its adjoint is exactly zero there)
     adj_qmul(qconj(j.q_p), s.r, adj_cqp, adj_q_c, adj_r_err);
     adj_q_p += qconj(adj_cqp);

@@ -2105,11 +2105,16 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     const BodyConst c = load_body_const(m, b, ec);
     const unsigned boff_qd = (unsigned)((size_t)ec * m.nqd + c.qdstart) * 4u;
     const bool has_par = c.parent >= 0;
+    // CLONE3 (round 6; compound-only plain models, the any-joint-mix loop below): an idle lane clones its env's last body -- same loads,
+    // same arithmetic, the same values to the same LDS / global addresses -- so the loop has no idle-lane regions; the joint adjoint keeps
+    // ONE divergent region per half (the FREE root sits it out) without type or parent tests inside (joint_adj_prep / _apply: ALL).
+    constexpr bool CLONE3 = JT == PD_JT_COMPOUND;
+    const bool wr = CLONE3 || is_body, gw = CLONE3 ? env_ok : is_body;
     const int ndof = c.type == PD_JOINT_REVOLUTE ? 1 : (c.type == PD_JOINT_COMPOUND ? 3 : 0);
     float ke[ND], kd[ND], g_ke[ND], g_kd[ND];
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
-      const bool on = is_body && k < ndof;
+      const bool on = wr && k < ndof;
       ke[k] = on ? a.target_ke[(size_t)ec * m.nqd + c.qdstart + k] : 0.f;
       kd[k] = on ? a.target_kd[(size_t)ec * m.nqd + c.qdstart + k] : 0.f;
       g_ke[k] = 0.f; g_kd[k] = 0.f;
@@ -2121,13 +2126,22 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     const unsigned boff_zero = (unsigned)((size_t)ec * m.nqd + m.qdstart[0] + (b >= 1 && b <= 6 ? b - 1 : 0)) * 4u;
     auto store_controls = [&](int step, const float *a_tgt, const float *a_act, const float *a_ke, const float *a_kd) {
       const size_t oc = (size_t)__builtin_amdgcn_readfirstlane(step) * a.bs * m.nqd;
+      if constexpr (CLONE3) {  // every non-FREE joint has ND dofs: one region for the six stores
+        if (gw && ndof > 0) {
+#pragma unroll
+          for (int k = 0; k < ND; ++k) { stg(a.g_refs + oc + k, boff_qd, NZ(a_tgt[k])); stg(a.g_torques + oc + k, boff_qd, NZ(a_act[k])); }
+        }
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k]; }
+      } else {
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
         if (is_body && k < ndof) { stg(a.g_refs + oc + k, boff_qd, NZ(a_tgt[k])); stg(a.g_torques + oc + k, boff_qd, NZ(a_act[k])); }
         g_ke[k] += a_ke[k]; g_kd[k] += a_kd[k];
       }
+      }
       if (zero_by_lanes) {
-        if (is_body && b >= 1 && b <= 6) { stg(a.g_refs + oc, boff_zero, 0.f); stg(a.g_torques + oc, boff_zero, 0.f); }
+        if (gw && b >= 1 && b <= 6 && l < nb) { stg(a.g_refs + oc, boff_zero, 0.f); stg(a.g_torques + oc, boff_zero, 0.f); }
       } else if (is_body && c.type == PD_JOINT_FREE) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { stg(a.g_refs + oc + k, boff_qd, 0.f); stg(a.g_torques + oc + k, boff_qd, 0.f); }
@@ -2195,7 +2209,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         const size_t o = (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * a.bs * m.nqd;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-          const bool on = is_body && k < ndof;
+          const bool on = CLONE3 || (is_body && k < ndof);  // (CLONE3: unconditional; the root reads the first of its own dofs and never uses them)
           n_tgt[k] = on ? ldg(a.refs + o + k, boff_qd) : 0.f;
           n_act[k] = on ? ldg(a.torques + o + k, boff_qd) : 0.f;
         }
@@ -2215,11 +2229,11 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         BodyState s;
         s.p = V3(0, 0, 0); s.r = Q4(0, 0, 0, 1); s.w = V3(0, 0, 0); s.v = V3(0, 0, 0);
         JointPrep P;
-        const bool jointed = is_body && c.type != PD_JOINT_FREE;
+        const bool jointed = wr && c.type != PD_JOINT_FREE;
         if (jointed) {
           const float *r = rec + b * PD_REC;
           s.p = ld3(r); s.r = ld4(r + 3); s.w = ld3(r + 7); s.v = ld3(r + 10);
-          joint_adj_prep<JT, pd_parented(JT)>(m, c, s, ld3(r + 13), rec, tgt, act, ke, kd, P);
+          joint_adj_prep<JT, pd_parented(JT), CLONE3>(m, c, s, ld3(r + 13), rec, tgt, act, ke, kd, P);
         }
         STAMP(8);
         pair_wait(sig, a.nsteps - step);  // A: the wrench adjoints of this step are staged
@@ -2232,10 +2246,10 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
         if (jointed) {
           const v3 gc_t = ld3(adjf + b * PD_W6), gc_f = ld3(adjf + b * PD_W6 + 3);
           v3 gp_t = V3(0, 0, 0), gp_f = gp_t;
-          if (has_par) { gp_t = ld3(adjf + c.parent * PD_W6); gp_f = ld3(adjf + c.parent * PD_W6 + 3); }
-          joint_adj_apply<JT, pd_parented(JT)>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
+          if (CLONE3 || has_par) { gp_t = ld3(adjf + c.pidx * PD_W6); gp_f = ld3(adjf + c.pidx * PD_W6 + 3); }  // (plain model: every jointed body hangs on one)
+          joint_adj_apply<JT, pd_parented(JT), CLONE3>(m, c, s, P, tgt, act, ke, kd, gc_t, gc_f, gp_t, gp_f, own, par, a_tgt, a_act, a_ke, a_kd);
         }
-        if (is_body) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
+        if (wr) { adj_store(cslot + b * PD_ADJ, par); adj_store(oslot + b * PD_ADJ, own); }
         STAMP(10);
         pair_signal(sig + 1, a.nsteps - step);  // J: (own, parent) contributions are complete
         __builtin_amdgcn_s_setprio(0);
@@ -2281,7 +2295,11 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   // inertia and inverse inertia are read from LDS where they are used (9 + 9 registers less across the step)
   float inv_m = a.inv_mass[idx];
   float g_inv_m = 0.f;
-  float *ga_lds = gacc + (l < nb ? l : nb) * PD_GACC;  // idle lanes share a dummy slot: they must not alias body nb - 1's sums
+  // CLONE3 (see the joint wave): idle lanes clone the env's last body -- also its LDS accumulators: every lane of a read-fma-write reads
+  // before any writes, so clones add the same value to the same old one and write the same sum
+  constexpr bool CLONE3 = JT == PD_JT_COMPOUND;
+  const bool wr = CLONE3 || is_body, gw = CLONE3 ? env_ok : is_body;
+  float *ga_lds = gacc + (CLONE3 ? b : (l < nb ? l : nb)) * PD_GACC;  // (else idle lanes share a dummy slot: they must not alias body nb - 1's sums)
   float *I = ga_lds + 18, *invI = I + 9;
 #pragma unroll
   for (int k = 0; k < 18; ++k) ga_lds[k] = 0.f;
@@ -2289,7 +2307,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   for (int k = 0; k < 9; ++k) { I[k] = a.inertia[idx * 9 + k]; invI[k] = a.inv_inertia[idx * 9 + k]; }
   int cz[4];  // first four children, the zero record for a missing one
 #pragma unroll
-  for (int k = 0; k < 4; ++k) cz[k] = is_body && c.child[k] >= 0 ? c.child[k] : nb;
+  for (int k = 0; k < 4; ++k) cz[k] = wr && c.child[k] >= 0 ? c.child[k] : nb;
 
   BodyAdj gn = adj_zero();  // adjoint of state step+1
   BodyState s;
@@ -2316,7 +2334,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     float Rm[9];
     rotm(s.r, Rm);  // the body's rotation as a matrix: shared by the staging and the adjoint of integrate_bodies
     const v3 rc = mat_vec(Rm, c.com);
-    if (is_body) stage_record(rec, cull, b, s, rc, Rm);
+    if (wr) stage_record(rec, cull, b, s, rc, Rm);
     if (JT != PD_JT_REVOLUTE) pair_signal(sig + 3, a.nsteps - step);  // S
   };
   // (ROLES == 2) the forward hit list of a step is replayed inline: its length and this lane's entry are fetched a step ahead
@@ -2351,7 +2369,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     for (int k = 0; k < 9; ++k) aR[k] = 0.f;
     integrate_adj2(m, c, s, Rm, clamp_mask, t0, f0, inv_m, I, invI, a.dt, gn, ga, aR, g_inv_m, LdsAcc9{ga_lds}, LdsAcc9{ga_lds + 9}, [&](v3 t, v3 f) {
       adj_t0 = t; adj_f0 = f;
-      if (is_body) {
+      if (wr) {
         float *o = adjf + b * PD_W6;
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = f.x; o[4] = f.y; o[5] = f.z;
       }
@@ -2362,7 +2380,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
       if (pre_ok) load_log(step - 1, cnt_n, e_n);
     });
     rotm_adj(s.r, aR, ga.r);
-    if (is_body) {
+    if (gw) {
       float *o = a.g_res_f + (size_t)__builtin_amdgcn_readfirstlane(step) * N * 6;  // adjoint of wp_add
       stg2(o, boff * 6u, make_float2(NZ(adj_t0.x), NZ(adj_t0.y))); stg2(o + 2, boff * 6u, make_float2(NZ(adj_t0.z), NZ(adj_f0.x)));
       stg2(o + 4, boff * 6u, make_float2(NZ(adj_f0.y), NZ(adj_f0.z)));
@@ -2389,11 +2407,11 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     }
     for (int k = 4; k < m.max_children; ++k) {
       int cid = (int)((c.children >> (8 * k)) & 0xffull);
-      if (is_body && cid != 0xff) adj_add_from(ga, cslot + cid * PD_ADJ);
+      if (wr && cid != 0xff) adj_add_from(ga, cslot + cid * PD_ADJ);
     }
     STAMP(3);
     if (ROLES == 3) pair_wait(sig + 2, a.nsteps - step);  // C: contact adjoints are complete
-    if (is_body) {
+    if (wr) {
       float *d = cacc + b * PD_ADJ;
       const float *const src[1] = {d};
       adj_add_from_n(ga, src);
