@@ -46,6 +46,7 @@ import torch  # noqa: E402
 HBM_PEAK_BYTES = 8.0e12        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 HBM_ACHIEVABLE_BYTES = 6.3e12  # same guide: what a streaming kernel reaches in practice
 VECTOR_PEAK_FLOPS = 157.3e12   # same guide: fp32 vector peak (packed v_pk_fma_f32: 256 CUs x 4 SIMDs x 16 lanes x 2 x 2 x 2.4 GHz)
+VALU_CYCLES_PER_INST = 4.2    # self-measured issue interval of a non-packed fp32 wave64 instruction per SIMD (profiles/r06_micro_valu.txt); the guide lists 2
 GLOBAL_BS = 4096               # BASELINE.json: "batch=4096"
 
 
@@ -312,6 +313,7 @@ def main():
             torch.cuda.synchronize()
             barrier()
             blocks.append(time.perf_counter() - t0)
+        local_blocks[:] = blocks   # this rank's own clock, before the MAX over ranks (per_rank in the line)
         if world > 1:
             tt = torch.tensor(blocks, dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -346,8 +348,10 @@ def main():
 
         return step
 
+    local_blocks = []
     step, bs, gbs = setup(args.scaling)
     blocks, g = timed(step)
+    local_ms = float(np.median(local_blocks)) / args.steps * 1e3
     elapsed = float(np.median(blocks))  # the median block: ms_per_step x steps = one real K-step block
     warm_extra = extra_warm[0]
     bad = int(torch.isnan(g["q_init"]).sum().item())
@@ -367,6 +371,24 @@ def main():
         kb.append(dm.last_kernel_ms(1))
     dm.set_timing(False)
     fwd_ms, bwd_ms = float(np.mean(kf)), float(np.mean(kb))
+
+    # per rank: which kernel family ran the rank's shard and its OWN clock -- a scaling record can then tell a slow rank
+    # from the latency floor of a small shard (512 envs per GPU at N = 8 take the quad-lane kernels)
+    def family(kind):
+        i = dm.last_launch_info(kind)
+        waves, envs = i["threads_per_wg"] // 64, max(1, i["envs_per_wg"])
+        if waves >= 2 * envs:
+            return "quad-lane: one env per wave pair"
+        epw = 64 // max(1, dm.segment_width())                 # envs per wave of the lane-per-body kernels
+        roles = waves * epw // envs                            # waves per env group
+        return "lane per body: %d envs per wave, %d wave%s per env group" % (epw, roles, "" if roles == 1 else "s")
+    mine = {"rank": rank, "envs": bs, "ms_per_step": local_ms, "fwd_kernel_ms": fwd_ms, "bwd_kernel_ms": bwd_ms,
+            "fwd_family": family(0), "bwd_family": family(1), "segment_lanes": dm.segment_width()}
+    per_rank = [mine]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     # N > 1: the same measurement in the OTHER scaling mode, reported beside the main one (SURVEY section 8(d) writes C4 as
     # one 4096-env batch split over the GPUs = strong; the driver's contract quotes weak).  At N = 1 the two coincide.
@@ -406,6 +428,13 @@ def main():
                 prof = {}
         pb, pf = prof.get("k_rollout_bwd", {}), prof.get("k_rollout_fwd", {})
         same_cfg = args.robot == "laikago" and bs in (GLOBAL_BS, 512) and T == 100 and args.segw == 0  # a committed profile is of this configuration
+        # ... and of THIS library: the profile carries the source half of pd_build_id() it was taken on (scripts/profile_gpu.sh); counters of
+        # another build say nothing about the kernels timed here, so every counter-derived field goes null
+        lib_hash = hip_backend.build_id().split("+")[-1]
+        prof_hash = prof.get("source_hash")
+        stale_profile = bool(prof) and prof_hash != lib_hash
+        if stale_profile:
+            same_cfg = False
         geo_b, geo_f = dm.last_launch_info(1), dm.last_launch_info(0)
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
 
@@ -426,15 +455,19 @@ def main():
             n = p.get("valu_insts_per_launch") if same_cfg else None
             if not n:
                 return None
-            peak = cus * 4.0 * 2.4e9 / 4.2
+            peak = cus * 4.0 * 2.4e9 / VALU_CYCLES_PER_INST
             # the data-sheet number beside the self-measured ceiling: 157.3 TFLOP/s fp32 vector (MI355X_MICROARCH.md; v_pk_fma_f32
             # only: 2 FMAs per lane and issue).  Upper bound of what this kernel does against it: EVERY vector instruction counted as
             # one FMA per lane (2 flop x 64 lanes)
             return {"unit": "wave64 fp32 instructions/s", "achieved": n / (ms * 1e-3), "peak": peak, "frac": n / (ms * 1e-3) / peak,
-                    "peak_source": "self-measured: scripts/micro/valu_chain.hip, pk_issue.hip (one non-packed wave64 instruction per ~4.2 cycles and SIMD)",
+                    "peak_source": "self-measured, raw output in profiles/r06_micro_valu.txt (scripts/micro/run_valu_micro.sh: valu_chain.hip, pk_issue.hip, "
+                                   "issue_rate.hip built with the library's flags): one non-packed wave64 instruction per ~4.2 cycles and SIMD at 4 waves per "
+                                   "SIMD, 4.5 at the two waves the rollout kernels have, 4.8-4.9 for a lone wave.  /opt/skills/guides/MI355X_MICROARCH.md lists "
+                                   "v_fma_f32 wave64 at 2 cycles (SIMD-32): against THAT figure frac halves (frac_of_guide_rate)",
+                    "frac_of_guide_rate": n / (ms * 1e-3) / (cus * 4.0 * 2.4e9 / 2.0),
                     "frac_of_vector_peak": n * 128.0 / (ms * 1e-3) / VECTOR_PEAK_FLOPS, "vector_peak_tflops": VECTOR_PEAK_FLOPS / 1e12,
                     "frac_of_vector_peak_note": "instructions x 64 lanes x 2 flop (every instruction priced as an FMA: an upper bound) / 157.3 TFLOP/s",
-                    "insts_per_launch": n, "cycles_per_instruction": 4.2, "clock_ghz_assumed": 2.4}
+                    "insts_per_launch": n, "cycles_per_instruction": VALU_CYCLES_PER_INST, "clock_ghz_assumed": 2.4}
 
         line = {
             "metric": "env-steps/sec (fwd+adjoint), Laikago 12-DoF, batch=4096, 1/2/4/8 MI355X",
@@ -443,6 +476,7 @@ def main():
             "n_gpus": world,
             "collective_backend": backend,   # "nccl" (= RCCL) | "gloo" (RCCL could not come up) | null at N = 1: barrier + MAX only
             "ranks_seen": ranks_seen,        # all-reduced count of ranks behind that backend
+            "per_rank": per_rank,            # all-gathered: each rank's shard, kernel family, own ms_per_step and kernel durations
             "devices_seen": devices_seen,    # all-gathered identity (UUID / PCI address) of each rank's GPU: N distinct unless PPR_BENCH_SHARE_GPU (a test hook)
             "devices_distinct": len({json.dumps({k: v for k, v in d.items() if k not in ("index", "name")} or d, sort_keys=True) for d in devices_seen}),
             "launcher": "self" if os.environ.get("PPR_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "none"),
@@ -486,7 +520,9 @@ def main():
                 "peak_achievable": HBM_ACHIEVABLE_BYTES / 1e9,
                 "traffic": pb.get("hbm_bytes_per_launch") if same_cfg else None,
                 "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `bench.py --steps 10`), NOT measured in "
-                                   "this run" % prof.get("tag", "pmc_summary.json")) if (same_cfg and pb) else None,
+                                   "this run; taken on library source %s = the one loaded here" % (prof.get("tag", "pmc_summary.json"), prof_hash)) if (same_cfg and pb)
+                                  else ("the committed profile is of another build (library source %s, loaded %s): counter-derived fields are null"
+                                        % (prof_hash, lib_hash) if stale_profile else None),
                 "avg_launch_ms": bwd_ms,
                 # the event pass against the timed region: its forward + adjoint launch durations / the timed ms per step.  Above 1 = the
                 # event pass runs slower than the timed blocks (the event records sit between the launches), i.e. `frac` UNDERSTATES the

@@ -10,7 +10,7 @@ FLAGS="-w -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -ffp-contract=fast
 case "$1" in
 build)
   mkdir -p bin
-  for f in valu_chain pk_issue; do /opt/rocm/bin/hipcc $FLAGS $f.hip -o bin/$f; done
+  for f in valu_chain pk_issue issue_rate issue_mix; do /opt/rocm/bin/hipcc $FLAGS $f.hip -o bin/$f; done
   # what the inner loops compiled to: the count of v_fma_f32 / v_pk_fma_f32 in each binary's device code, so the run's reader can see that
   # "cycles per FMA" is per v_fma_f32 (non-packed) in valu_chain and per named instruction in pk_issue
   for f in valu_chain pk_issue; do
@@ -30,9 +30,15 @@ run)
     ./bin/valu_chain
   done
   for rep in 1 2; do
-    echo "== pk_issue (v_fma_f32 vs v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, 8 chains; 1, 2, 3, 4, 8 waves per SIMD), repeat $rep"
+    echo "== pk_issue (v_fma_f32 vs v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, 8 chains; 1, 2, 3, 4 waves per SIMD), repeat $rep"
     ./bin/pk_issue
   done
+  for rep in 1 2; do
+    echo "== issue_rate (round 6: the same 64-instruction loop by OPERAND KIND and encoding -- all-VGPR VOP2 / VOP3, an SGPR operand, an inline constant, a literal; 8 chains; 1 .. 4 waves per SIMD), repeat $rep"
+    ./bin/issue_rate
+  done
+  echo "== issue_mix (round 6: what a non-vector instruction costs a wave whose stream is a chain of v_fma_f32: 64 FMAs + 32 extras per iteration; 1 and 2 waves per SIMD)"
+  ./bin/issue_mix
   ;;
 *) echo "usage: $0 build|run"; exit 2;;
 esac

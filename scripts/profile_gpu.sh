@@ -10,6 +10,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --steps 10 --warmup 2 --repeats 2 --no-cpu-baseline --no-boundary $@"
 echo "$BENCH" > $OUT/command.txt
+# which library these counters are of: the source half of pd_build_id() -- bench.py drops counter-derived fields when it differs from the library it runs
+python3 -c "import sys; sys.path.insert(0, '$REPO/ppr-diffphys_amd'); from diffphys_amd import hip_backend; print(hip_backend.build_id().split('+')[-1])" > $OUT/source_hash.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -113,6 +113,10 @@ for k in ("k_rollout_fwd", "k_rollout_bwd"):
                   100 * mean(k, "SQ_LDS_BANK_CONFLICT") / max(1.0, mean(k, "SQ_LDS_IDX_ACTIVE"))), ""]
 open(os.path.join(dst, tag + "_summary.md"), "w").write("\n".join(lines))
 summary["tag"] = tag
+try:  # the library the counters were taken on (scripts/profile_gpu.sh): bench.py compares it with the library it runs
+    summary["source_hash"] = open(os.path.join(src, "source_hash.txt")).read().strip()
+except Exception:
+    summary["source_hash"] = None
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
 if write_json:
     json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)

@@ -217,3 +217,43 @@ def test_literal_generic_robot_with_a_fixed_joint(dev, oracle_libs, tmp_path):
     # gradients, the typical env within an order of magnitude of the fp32 oracle's own error.
     assert np.median(own["worst"]) <= 10.0 * max(np.median(own["fp32_acos"]), 1e-3), (np.median(own["worst"]), np.median(own["fp32_acos"]))
     assert ok.mean() >= 0.3
+    # ---- the CONTRACT of the mode on a FIXED-joint robot, with the outliers accounted for by cause.  An env is
+    # "at the discontinuity" when, at some step of the kernel's own trajectory, the FIXED joint's r_err.w = w of conj(q_p q_pj) q_c -- formed
+    # in fp32 from the stored fp32 quaternions, once contracted (fma) and once not -- lies within 2 ulp of 1: there the guarded derivative
+    # of acos is 0 or 5.8e3 by the last bit, and which one an evaluator sees is its contraction.  Those envs are EXCLUDED AND COUNTED; every
+    # other env must lie within 10 x the fp32 literal oracle's own error (floor 1e-2), and whatever is worse than 1e0 must be an excluded env.
+    jt, par = np.asarray(tpl["joint_type"]), np.asarray(tpl["joint_parent"])
+    fixed = [i for i in range(nb) if int(jt[i]) == 3]
+    assert fixed, "the toy robot has a FIXED joint"
+    bq = own["traj"]["states_q"].reshape(T, bs, nb, 7).astype(np.float32)
+    xp = np.asarray(tpl["joint_X_p"], np.float32)
+
+    def qmul32(a, b, fused):  # (x, y, z, w) fp32 products; fused = every multiply-add as one rounding (through float64), else each product rounded
+        f = (lambda x, y, z: (x.astype(np.float64) * y.astype(np.float64) + z.astype(np.float64)).astype(np.float32)) if fused else (lambda x, y, z: (x * y).astype(np.float32) + z)
+        ax, ay, az, aw = [a[..., k] for k in range(4)]
+        bx, by, bz, bw = [b[..., k] for k in range(4)]
+        z = np.zeros_like(ax)
+        x = f(aw, bx, f(bw, ax, f(ay, bz, -(az * by).astype(np.float32))))
+        y = f(aw, by, f(bw, ay, f(az, bx, -(ax * bz).astype(np.float32))))
+        zz = f(aw, bz, f(bw, az, f(ax, by, -(ay * bx).astype(np.float32))))
+        w = f(aw, bw, -f(ax, bx, f(ay, by, (az * bz).astype(np.float32))))
+        return np.stack([x, y, zz, w], -1).astype(np.float32)
+
+    near = np.zeros(bs, bool)
+    ulp1 = np.float32(1.0) - np.nextafter(np.float32(1.0), np.float32(0.0))
+    for i in fixed:
+        qc = bq[:, :, i, 3:]
+        qp = bq[:, :, int(par[i]), 3:] if int(par[i]) >= 0 else np.tile(np.float32([0, 0, 0, 1]), (T, bs, 1))
+        qpj = np.broadcast_to(xp[i, 3:], qp.shape)
+        for fused in (False, True):
+            q_p = qmul32(qp, qpj, fused)
+            conj = q_p * np.float32([-1, -1, -1, 1])
+            rw = qmul32(conj, qc, fused)[..., 3]
+            near |= (np.abs(np.float32(1.0) - np.abs(rw)) <= 2 * ulp1).any(0)
+    far = ~near
+    print("toy robot LITERAL contract: %d of %d envs have the FIXED joint's r.w within 2 ulp of 1 at some step (excluded); the other %d: worst %.1e "
+          "(fp32 literal oracle there: worst %.1e); worst excluded env %.1e" % (near.sum(), bs, far.sum(), own["worst"][far].max() if far.any() else 0.0,
+                                                                               own["fp32_acos"][far].max() if far.any() else 0.0, own["worst"][near].max() if near.any() else 0.0))
+    if far.any():
+        assert (own["worst"][far] <= np.maximum(1e-2, 10.0 * own["fp32_acos"][far])).all(), (own["worst"][far].max(), own["fp32_acos"][far].max())
+    assert not (far & (own["worst"] > 1.0)).any(), "an env far from the acos discontinuity is off by more than its gradient's size"
