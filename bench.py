@@ -419,7 +419,7 @@ def main():
         ach_fwd = bs * T * bf / (fwd_ms * 1e-3)
         prof = {}
         # committed PMC profiles: the headline configuration, and the 512 envs a GPU holds at N = 8 (quad-lane kernels)
-        pmc = os.path.join(ROOT, "profiles", "r04_l512_pmc_summary.json" if bs == 512 else "pmc_summary.json")
+        pmc = os.path.join(ROOT, "profiles", "r06_l512_pmc_summary.json" if bs == 512 else "pmc_summary.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:

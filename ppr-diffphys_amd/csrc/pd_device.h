@@ -39,6 +39,7 @@ struct PdDevModel {
   int list_cap;                                            // ints reserved for the tile list (>= ntiles and >= 2*nb)
   int has_limits;                                          // any joint_limit_ke / kd != 0 (else the limit force is identically 0)
   float gx, gy, gz, attach_ke, attach_kd;
+  float spec_safety, spec_slack;                          // speculative contact cull: allowed sinking per step (pd_kernels.hip sink_margin)
   int env_lds_floats;                                     // per-env LDS scratch
   int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (2-role wave-specialised adjoint only)

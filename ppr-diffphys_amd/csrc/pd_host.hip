@@ -237,6 +237,8 @@ static int build_device(pd_model *m, int segw) {
   for (int i = 0; i < m->nqd; ++i) if (m->lim_ke[i] != 0.f || m->lim_kd[i] != 0.f) d.has_limits = 1;
   d.gx = m->gravity[0]; d.gy = m->gravity[1]; d.gz = m->gravity[2];
   d.attach_ke = m->attach_ke; d.attach_kd = m->attach_kd;
+  // the speculative cull's margin (pd_kernels.hip sink_margin): tight where candidates are many (mesh robots), generous where they are few
+  d.spec_safety = nc > 512 ? 1.25f : 3.0f; d.spec_slack = nc > 512 ? 1.0e-4f : 1.0e-3f;
   d.X_p_env = m->xp_env; d.xp_envs = m->xp_envs;
   // cull vectors (float4 per body, 16-B aligned) + records + wrench slots + adjoint slots + tile list + hit list (8*segw) + per-hit result slots (13*segw)
   d.env_lds_floats = ((nb * (4 + PD_REC + PD_W6 + 2 * PD_ADJ) + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;  // + PD_ADJ: the zero record

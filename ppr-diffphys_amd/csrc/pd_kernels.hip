@@ -456,14 +456,19 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
 #ifndef PD_SPEC_K
 #define PD_SPEC_K 4  // steps served by one speculative cull
 #endif
-#ifndef PD_SPEC_SAFETY
-#define PD_SPEC_SAFETY 1.25f  // allowed sinking per step = this x what the present velocity gives ... (1.5 / 2e-4 until round 3)
-#endif
-#ifndef PD_SPEC_SLACK
-#define PD_SPEC_SLACK 1e-4f  // ... + this (metres)
-#endif
-PD_DEV float sink_margin(const BodyConst &c, const BodyState &s, float dt) {
-  return (float)PD_SPEC_K * (PD_SPEC_SAFETY * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + PD_SPEC_SLACK);
+// allowed sinking per step = m.spec_safety x what the present velocity gives + m.spec_slack metres: per MODEL since round 6 (pd_host.hip).
+// Laikago (3 838 mesh points): 1.25 x + 0.1 mm -- every candidate costs a lane of the hit pass (round 3's sweep: 1.5 / 2e-4 before).  Box
+// robots (human, quad: 8 points per body): 3 x + 1 mm -- their candidates are few whatever the margin, and the tight one made the exact
+// sweep run again in 10 % of human's wave-steps (quad 2048 forward 0.219 -> 0.186 ms, human 1024 0.179 -> 0.175; 4 x the same, 6 x worse).
+// (the revolute-only instantiations -- Laikago: mesh contacts -- keep the tight pair as IMMEDIATES: as kernel arguments the two values cost
+// the headline forward kernel two scalar registers in a loop that spills them, 0.202 -> 0.205 ms; a revolute-only box robot gets the tight
+// margin then: more exact sweeps, the same results)
+#define PD_SPEC_SAFETY_TIGHT 1.25f
+#define PD_SPEC_SLACK_TIGHT 1.0e-4f
+template <int JT>
+PD_DEV float sink_margin(const PdDevModel &m, const BodyConst &c, const BodyState &s, float dt) {
+  const float safety = JT == PD_JT_REVOLUTE ? PD_SPEC_SAFETY_TIGHT : m.spec_safety, slack = JT == PD_JT_REVOLUTE ? PD_SPEC_SLACK_TIGHT : m.spec_slack;
+  return (float)PD_SPEC_K * (safety * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + slack);
 }
 
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.  COPY = false leaves
@@ -749,7 +754,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     q_rotm(k, s.r, Rr, Rc);
     float rc = q_mvc(Rr, B.com0, B.com1, B.com2);
     auto q_margin = [&](const QState &x) {  // sink_margin (the speculative contact cull), all four lanes
-      return (float)PD_SPEC_K * (PD_SPEC_SAFETY * a.dt * (Q_BC1(fabsf(x.v)) + q_sum3(fabsf(x.w)) * B.reach) + PD_SPEC_SLACK);
+      return (float)PD_SPEC_K * (PD_SPEC_SAFETY_TIGHT * a.dt * (Q_BC1(fabsf(x.v)) + q_sum3(fabsf(x.w)) * B.reach) + PD_SPEC_SLACK_TIGHT);  // (quad-lane: revolute-only)
     };
     // staging: the record fields are contiguous vectors, lane c writes component c of each; the cull vector (p_y, row 1 of rotm) is
     // lane 1's: its own p and its row
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       rotm(s.r, Rm);
       rc = mat_vec(Rm, c.com);
       float4 cv = stage_record(rec, cull, b, s, rc, Rm);
-      margin = sink_margin(c, s, a.dt);
+      margin = sink_margin<JT>(m, c, s, a.dt);
       margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
       cv.x -= margin;
       if (SPLIT) spec[b] = cv;  // epoch 0
@@ -1119,7 +1124,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
       if (u_since >= PD_SPEC_K || spec_failed || !u_have) {  // wave-uniform
         if (is_body) {
-          margin = sink_margin(c, s, a.dt); sunk = 0.f;
+          margin = sink_margin<JT>(m, c, s, a.dt); sunk = 0.f;
           float4 cv = cull[b];
           cv.x -= margin;
           spec[b] = cv;
@@ -1270,7 +1275,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     if (wr) {
       float4 cv = stage_record(rec, cull, b, s, rc, Rm);
       if (SPLIT && (step + 1) % PD_SPEC_K == 0) {  // state step+1 opens a speculation epoch
-        margin = sink_margin(c, s, a.dt); sunk = 0.f;
+        margin = sink_margin<JT>(m, c, s, a.dt); sunk = 0.f;
         margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
         cv.x -= margin;
         spec[(((step + 1) / PD_SPEC_K) & 1) * nb + b] = cv;
