@@ -557,6 +557,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     if (lane == 0) { sig[0] = 0; sig[1] = 0; }
     __syncthreads();
   }
+  if constexpr (QUAD) {
+    if (!env_ok) return;  // one env per wave pair: a pair past the batch has nothing to do (no workgroup barrier follows)
+  }
 
   BodyConst c = load_body_const(m, b, ec);
 #pragma unroll
@@ -697,8 +700,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   }
   if constexpr (QUAD) {
     // ================= body wave, four lanes per body: lane 4 qb + qc holds component qc of body qb of this wave's ONE env
+    // Round 6, as in the lane-per-body kernels (CLONE): no divergent region in the step loop.  A wave whose env lies past the batch has
+    // left (below the hand-over words' initialisation: the contact wave too); an idle quad (qb >= nb) is a CLONE of the env's last body and
+    // writes what that body's quad writes; lane 3 of a quad -- it holds the w of quaternions and nothing of vectors -- sends its "vector"
+    // stores to the PAD float of its body's record / wrench slot instead of sitting them out, and reads component 2 where the others read
+    // their own (a select zeroes it).  The loop had 27 branches and 16 exec-mask regions per step.
     const int qb = lane >> 2, qc = lane & 3, bb = qb < nb ? qb : nb - 1, qv = qc < 3 ? qc : 2;
-    const bool qbody = env_ok && qb < nb;
+    const bool qbody = true;
     const QLane k = q_lane(qc);
     const size_t qidx = (size_t)ec * nb + bb;
     QBody B;
@@ -759,10 +767,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     // staging: the record fields are contiguous vectors, lane c writes component c of each; the cull vector (p_y, row 1 of rotm) is
     // lane 1's: its own p and its row
     auto q_stage = [&](const QState &x, float rcx, const QM3 &R, float lower, float4 *spec_dst) {
-      if (qbody) {
+      {
         float *r = rec + bb * PD_REC;
         r[3 + qc] = x.r;
-        if (k.isv) { r[qc] = x.p; r[7 + qc] = x.w; r[10 + qc] = x.v; r[13 + qc] = rcx; }
+        r[k.isv ? qc : 16] = x.p; r[k.isv ? 7 + qc : 16] = x.w; r[k.isv ? 10 + qc : 16] = x.v; r[k.isv ? 13 + qc : 16] = rcx;  // (lane 3: the record's pad float)
         if (qc == 1) {
           cull[bb] = make_float4(x.p, R.a, R.b, R.c);
           if (spec_dst) spec_dst[bb] = make_float4(x.p - lower, R.a, R.b, R.c);
@@ -782,8 +790,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       const int sc = __builtin_amdgcn_readfirstlane(step < a.nsteps ? step : a.nsteps - 1);
       n_fr = ld_uniform(a.frame_of_step, sc);
       const size_t o = (size_t)sc * a.bs * m.nqd;
-      n_tgt = B.joint ? ldg(a.refs + o, boff_qd) : 0.f;
-      n_act = B.joint ? ldg(a.torques + o, boff_qd) : 0.f;
+      n_tgt = ldg(a.refs + o, boff_qd);   // (unconditional: the root reads the first of its own six dofs, its joint result is dropped)
+      n_act = ldg(a.torques + o, boff_qd);
       const float *rf = a.res_f + (size_t)sc * N * 6;
       n_rft = ldg(rf, boff_rf); n_rff = ldg(rf + 3, boff_rf);
     };
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
             if (k.isv) a.loss_seed_gt[ot + qc] = gg_v;
           }
         }
-        lb = (qbody && qc == 0) ? lb : 0.f;   // one lane per body carries the body's loss into the mean over bodies (dp_model.py:777)
+        lb = (qb < nb && qc == 0) ? lb : 0.f;   // one lane per REAL body (not its clones) carries the body's loss into the mean over bodies (dp_model.py:777)
 #pragma unroll
         for (int w = 32; w >= 1; w >>= 1) lb += __shfl_xor(lb, w, 64);
         if (lane == 0 && env_ok) {
@@ -843,12 +851,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       float wp_t, wc_t, jf_;
       {
         const float *pr = rec + B.pidx * PD_REC;
-        const float pp = k.isv ? pr[qv] : 0.f, qp = pr[3 + qc], w_p = k.isv ? pr[7 + qv] : 0.f, v_p = k.isv ? pr[10 + qv] : 0.f,
-                    rc_par = k.isv ? pr[13 + qv] : 0.f;
+        const float l_pp = pr[qv], qp = pr[3 + qc], l_wp = pr[7 + qv], l_vp = pr[10 + qv], l_rc = pr[13 + qv];  // (unguarded reads, then selects)
+        const float pp = k.isv ? l_pp : 0.f, w_p = k.isv ? l_wp : 0.f, v_p = k.isv ? l_vp : 0.f, rc_par = k.isv ? l_rc : 0.f;
         q_joint_fwd(k, B, s, Rr, rc, pp, qp, w_p, v_p, rc_par, tgt, act, ake, akd, wp_t, wc_t, jf_);
       }
       wp_t = B.joint ? wp_t : 0.f; wc_t = B.joint ? wc_t : 0.f; jf_ = B.joint ? jf_ : 0.f;
-      if (qbody && k.isv) { pcon[bb * PD_W6 + qc] = wp_t; pcon[bb * PD_W6 + 3 + qc] = jf_; }
+      pcon[bb * PD_W6 + (k.isv ? qc : 6)] = wp_t; pcon[bb * PD_W6 + (k.isv ? 3 + qc : 6)] = jf_;  // (lane 3: the slot's pad float)
       STAMP(2);
       WAVE_SYNC();
       float jt = -wc_t, jf = -jf_;  // joint wrench on this body: own joint first, then children in index order
@@ -861,7 +869,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
       for (int j = 4; j < m.max_children; ++j) {
         const int cid = (int)((q_children >> (8 * j)) & 0xffull);
-        if (qbody && cid != 0xff) { jt += pcon[cid * PD_W6 + qv]; jf += pcon[cid * PD_W6 + 3 + qv]; }
+        if (cid != 0xff) { jt += pcon[cid * PD_W6 + qv]; jf += pcon[cid * PD_W6 + 3 + qv]; }
       }
       jt = k.isv ? jt : 0.f; jf = k.isv ? jf : 0.f;
       STAMP(6);
@@ -869,28 +877,28 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       // (every DPP read happens with the whole quad active: values are formed first, selected after, stored under the body mask last)
       const float vx_all = Q_BC0(s.v), vy_all = Q_BC1(s.v);
       const float pl1 = k.isv ? s.w : vx_all, pl2 = k.isv ? s.p : vy_all;
-      if (qbody) {
+      {
         float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
         stg(tj, boff_tj, s.r);
         stg(tj + (size_t)4 * N, boff_tj, pl1);
         stg(tj + (size_t)8 * N, boff_tj, pl2);
-        if (step > 0) {
-          float *tp = a.ws + (size_t)(step - 1) * (PD_TRAJ_G * 4) * N;
-          stg(tp + (size_t)12 * N, boff_tj, o_p3); stg(tp + (size_t)16 * N, boff_tj, o_p4);
-        }
+        // (no `step > 0` region: step 0 writes the zeros o_p3 / o_p4 hold into step 0's planes 3-4, step 1 overwrites them)
+        float *tp = a.ws + (size_t)(step > 0 ? step - 1 : 0) * (PD_TRAJ_G * 4) * N;
+        stg(tp + (size_t)12 * N, boff_tj, o_p3); stg(tp + (size_t)16 * N, boff_tj, o_p4);
       }
       if (fr >= 0) q_frame_out(fr, s);
       STAMP(8);
       pair_wait(sig + 1, step + 1);  // B: contact wrenches are complete
       STAMP(9);
-      if (qbody && k.isv) {
+      {  // (lane 3 reads floats 3 and 6 of the slot -- dropped -- and zeroes them: float 3 is zeroed by lane 0 as well, 6 is the pad)
         float *f = facc + bb * PD_W6;
-        ft += f[qc]; ff += f[3 + qc];
+        const float f_t = f[qc], f_f = f[3 + qc];
+        ft += k.isv ? f_t : 0.f; ff += k.isv ? f_f : 0.f;
         f[qc] = 0.f; f[3 + qc] = 0.f;
       }
       const float grf_t = ft, grf_f = ff;  // res_f + contacts (integrator_euler.py:510)
       ft += jt; ff += jf;
-      if (fr >= 0 && qbody && k.isv) {  // force snapshots of a frame step
+      if (fr >= 0) if (k.isv) {  // force snapshots of a frame step (the wave-uniform test first)
         if (a.grf) { float *o = a.grf + ((size_t)fr * N + qidx) * 6; o[qc] = grf_t; o[3 + qc] = grf_f; }
         if (a.jaf) { float *o = a.jaf + ((size_t)fr * N + qidx) * 6; o[qc] = ft - grf_t; o[3 + qc] = ff - grf_f; }
       }
@@ -911,7 +919,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       STAMP(4);
       {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
         sunk += sink * a.dt;
-        const bool bad = qbody && B.sphere_w >= 0.0f && !(sunk <= 0.98f * margin);
+        const bool bad = B.sphere_w >= 0.0f && !(sunk <= 0.98f * margin);
         spec_failed = __ballot(bad) != 0ull;
       }
       WAVE_SYNC();
@@ -1355,6 +1363,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (lane == 0 && !contact_wave) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
     __syncthreads();
   }
+  if constexpr (QUAD) {
+    if (!env_ok) return;  // one env per wave pair: a pair past the batch has nothing to do (no workgroup barrier follows)
+  }
 
   BodyConst c = load_body_const(m, b, ec);
 #pragma unroll
@@ -1483,7 +1494,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     static_assert(SEGW == 64 && SPLIT && !EARLY && JT == PD_JT_REVOLUTE, "quad-lane body wave: one env per wave, revolute-only plain models");
     // ================= body wave, four lanes per body (see k_rollout_fwd): the reverse sweep of dp_model.py:1251-1400
     const int qb = lane >> 2, qc = lane & 3, bb = qb < nb ? qb : nb - 1, qv = qc < 3 ? qc : 2;
-    const bool qbody = env_ok && qb < nb;
+    // round 6 (see the forward kernel's quad-lane loop): waves past the batch have left, idle quads clone the env's last body, lane 3 of a quad
+    // sends the vector fields it has no part in to a PAD float (of its body's record, or of its wrench-adjoint slot: the 13-float adjoint
+    // records have none) and reads component 2 where the others read their own
+    const bool qbody = true;
+    float *const dummy = adjf + bb * PD_W6 + 6;
     const QLane k = q_lane(qc);
     const size_t qidx = (size_t)ec * nb + bb;
     QBody B;
@@ -1517,11 +1532,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int cid = (int)((q_children >> (8 * j)) & 0xffull); qcz[j] = (qbody && cid != 0xff) ? cid : nb; }
     if (lane < PD_ADJ) cslot[nb * PD_ADJ + lane] = 0.f;   // the zero record
-    if (qbody) {
-      float *d = cacc + bb * PD_ADJ;
-      d[3 + qc] = 0.f;
-      if (k.isv) { d[qc] = 0.f; d[7 + qc] = 0.f; d[10 + qc] = 0.f; }
-    }
+    // cacc / cslot record of this lane: the quaternion float, and the three vector floats (lane 3: the pad)
+    float *const ca_r = cacc + bb * PD_ADJ + 3 + qc, *const ca_p = k.isv ? cacc + bb * PD_ADJ + qc : dummy,
+                *const ca_w = k.isv ? cacc + bb * PD_ADJ + 7 + qc : dummy, *const ca_v = k.isv ? cacc + bb * PD_ADJ + 10 + qc : dummy;
+    float *const cs_r = cslot + bb * PD_ADJ + 3 + qc, *const cs_p = k.isv ? cslot + bb * PD_ADJ + qc : dummy,
+                *const cs_w = k.isv ? cslot + bb * PD_ADJ + 7 + qc : dummy, *const cs_v = k.isv ? cslot + bb * PD_ADJ + 10 + qc : dummy;
+    *ca_r = 0.f; *ca_p = 0.f; *ca_w = 0.f; *ca_v = 0.f;
     QM3 g_I, g_invI;
     g_I.a = g_I.b = g_I.c = 0.f; g_invI = g_I;
     float g_inv_m = 0.f, g_ke = 0.f, g_kd = 0.f;
@@ -1539,7 +1555,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
 #pragma unroll
       for (int g = 0; g < PD_TRAJ_G; ++g) n_pl[g] = ldg(tj + (size_t)(4 * g) * N, boff_tj);
       const size_t o = (size_t)sc * a.bs * m.nqd;
-      n_tgt = B.joint ? ldg(a.refs + o, boff_qd) : 0.f;   // (the applied torque enters the adjoint through the contact wave's jf only)
+      n_tgt = ldg(a.refs + o, boff_qd);   // (unconditional; the applied torque enters the adjoint through the contact wave's jf only)
     };
     auto q_seeds = [&](int fr) {  // dp_model.py:1264-1271
       const float *gp = a.adj_pos + ((size_t)fr * N + qidx) * 7, *gv = a.adj_vel + ((size_t)fr * N + qidx) * 6;
@@ -1571,10 +1587,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       QM3 Rr, Rc;
       q_rotm(k, s.r, Rr, Rc);
       const float rc = q_mvc(Rr, B.com0, B.com1, B.com2);
-      if (qbody) {  // staging (stage_record): the contact wave reads records and cull vectors
+      {  // staging (stage_record): the contact wave reads records and cull vectors
         float *r = rec + bb * PD_REC;
         r[3 + qc] = s.r;
-        if (k.isv) { r[qc] = s.p; r[7 + qc] = s.w; r[10 + qc] = s.v; r[13 + qc] = rc; }
+        r[k.isv ? qc : 16] = s.p; r[k.isv ? 7 + qc : 16] = s.w; r[k.isv ? 10 + qc : 16] = s.v; r[k.isv ? 13 + qc : 16] = rc;  // (lane 3: the record's pad float)
         if (qc == 1) cull[bb] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
       }
       STAMP(0);
@@ -1584,10 +1600,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       aR.a = aR.b = aR.c = 0.f;
       float adj_t0, adj_f0;
       q_integrate_adj_wrench(k, B, s, Rr, Rc, invIt, mask, t0, a.dt, gn, T, adj_t0, adj_f0);
-      if (qbody && k.isv) { adjf[bb * PD_W6 + qc] = adj_t0; adjf[bb * PD_W6 + 3 + qc] = adj_f0; }
+      adjf[bb * PD_W6 + (k.isv ? qc : 6)] = adj_t0; adjf[bb * PD_W6 + (k.isv ? 3 + qc : 6)] = adj_f0;  // (lane 3: the slot's pad float)
       pair_signal(sig, a.nsteps - step);  // A: records + wrench adjoints are staged
       STAMP(1);
-      if (qbody && k.isv) {
+      if (k.isv) {
         float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
         stg(o, boff_rf, NZ(adj_t0)); stg(o + 3, boff_rf, NZ(adj_f0));
       }
@@ -1624,10 +1640,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       }
       STAMP(2);
       ga.r += q_rotm_adj(k, s.r, aR);
-      if (qbody) {
-        float *d = cslot + bb * PD_ADJ;
-        d[3 + qc] = par.r;
-        if (k.isv) { d[qc] = par.p; d[7 + qc] = par.w; d[10 + qc] = par.v; }
+      {
+        *cs_r = par.r; *cs_p = par.p; *cs_w = par.w; *cs_v = par.v;
         if (qc == 0) {
           if (B.type == PD_JOINT_REVOLUTE) { stg(a.g_refs + oc, boff_qd, NZ(a_tgt)); stg(a.g_torques + oc, boff_qd, NZ(a_act)); }
         }
@@ -1653,7 +1667,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       }
       for (int j = 4; j < m.max_children; ++j) {
         const int cid = (int)((q_children >> (8 * j)) & 0xffull);
-        if (qbody && cid != 0xff) {
+        if (cid != 0xff) {
           const float *src = cslot + cid * PD_ADJ;
           ga.r += src[3 + qc];
           if (k.isv) { ga.p += src[qc]; ga.w += src[7 + qc]; ga.v += src[10 + qc]; }
@@ -1662,14 +1676,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       STAMP(3);
       pair_wait(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
       STAMP(8);
-      if (qbody) {
-        float *d = cacc + bb * PD_ADJ;
-        ga.r += d[3 + qc];
-        d[3 + qc] = 0.f;
-        if (k.isv) {
-          ga.p += d[qc]; ga.w += d[7 + qc]; ga.v += d[10 + qc];
-          d[qc] = 0.f; d[7 + qc] = 0.f; d[10 + qc] = 0.f;
-        }
+      {
+        const float c_r = *ca_r, c_p = *ca_p, c_w = *ca_w, c_v = *ca_v;
+        ga.r += c_r; ga.p += k.isv ? c_p : 0.f; ga.w += k.isv ? c_w : 0.f; ga.v += k.isv ? c_v : 0.f;
+        *ca_r = 0.f; *ca_p = 0.f; *ca_w = 0.f; *ca_v = 0.f;
       }
       gn = ga;
       STAMP(4);
