@@ -44,6 +44,7 @@ struct PdDevModel {
   int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (2-role wave-specialised adjoint only)
   int env_lds_bwd3;                                       // per-env LDS scratch of the 3-role adjoint kernel (k_rollout_bwd3)
+  int env_lds_rec2;                                       // second generation of cull vectors + records (quad-lane adjoint: the step is software-pipelined)
   const float *X_p_env;                                   // [xp_envs][nb][7] per-env joint_X_p bound by the caller, or null (template X_p)
   int xp_envs;
 };

@@ -257,12 +257,13 @@ static int build_device(pd_model *m, int segw) {
   // the role-split adjoint (k_rollout_bwd3) keeps the contact tables in global memory; per env: two generations of cull vectors and records,
   // wrench adjoints, (parent, own) joint slots + the zero record, contact sums, inertia-gradient accumulators, tile list, hit list, per-hit slots, signals
   d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;
+  d.env_lds_rec2 = ((nb * (4 + PD_REC) + 31) / 32) * 32;  // (quad-lane adjoint only)
   d.env_lds_bwd3 = ((nb * (2 * (4 + PD_REC) + PD_W6 + 3 * PD_ADJ + PD_GACC) + PD_GACC + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
   d.env_lds_bwd3 += (16 - d.env_lds_bwd3 % 32 + 32) % 32;  // env stride 16 mod 32, as above
   // revolute-only: 2-role kernel (+ joint hand-over records) or the 3-role one, no tables; other joint mixes: the 2-role
   // k_rollout_bwd3 with the contact tables in LDS (or the unsplit kernel, A/B only)
   const size_t lds_rollout_bwd = jt == PD_JT_REVOLUTE
-                                     ? (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats + 2 * d.env_lds_jc) * 4
+                                     ? (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats + 2 * d.env_lds_jc + d.env_lds_rec2) * 4
                                      : lds_tables + (size_t)envs_per_block * std::max(d.env_lds_bwd3, d.env_lds_floats) * 4;
   // (the 160 KiB checks below are for PD_BWAVES env groups per workgroup, the most a launch uses)
   const size_t lds_fk = (size_t)envs_per_block * nb * (PD_REC + PD_ADJ) * 4;
@@ -364,7 +365,7 @@ static hipError_t launch(const pd_model *m, int kind, const void *args, int n_en
     c.nblocks = (n_envs + c.groups - 1) / c.groups;
     c.threads = c.roles * c.groups * 64;
     c.lds = kind == PD_K_ROLLOUT_FWD ? m->quad->lds_tables + (size_t)c.groups * d.env_lds_floats * 4   // contact tables in LDS
-                                     : (size_t)c.groups * (d.env_lds_floats + 2 * d.env_lds_jc) * 4;  // adjoint: + joint hand-over records
+                                     : (size_t)c.groups * (d.env_lds_floats + 2 * d.env_lds_jc + d.env_lds_rec2) * 4;  // adjoint: + joint hand-over records + second generation of records
     if (c.nblocks == 0) return hipSuccess;
     int *ll = const_cast<pd_model *>(m)->last_launch[kind];
     ll[0] = c.nblocks; ll[1] = c.threads; ll[2] = (int)c.lds; ll[3] = c.groups;

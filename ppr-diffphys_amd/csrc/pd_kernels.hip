@@ -151,8 +151,17 @@ PD_DEV void seg_run_sum(float *acc, int pb, int l, int nh, bool &last) {
 // publishes after a workgroup-scope release, the consumer polls.  Unlike s_barrier it does not tie the four wave pairs of
 // a workgroup together.
 PD_DEV void pair_signal(int *flag, int value) {
+#ifdef PD_SIGNAL_FENCE
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  // Everything handed over lives in LDS, and the LDS executes one wave's instructions in issue order: the records written above
+  // land before the flag does, so the producer need not wait for them (the release fence's s_waitcnt lgkmcnt(0), one LDS round
+  // trip on every hand-over).  All lanes store the same word: no exec-mask round trip either.
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+#endif
 }
 // The low 30 bits of the word are the counter; the producer may pass a flag in bit 30.  Returns the word.
 #define PD_SIG_FLAG 0x40000000
@@ -1347,7 +1356,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   // itself was measured slower at every batch size -- EXPERIMENTS.md round 3 -- and is gone from the sources since round 5)
 
   SweepTables tabs;
-  const int env_stride = m.env_lds_floats + (SPLIT ? 2 * m.env_lds_jc : 0);
+  const int env_stride = m.env_lds_floats + (SPLIT ? 2 * m.env_lds_jc : 0) + (QUAD ? m.env_lds_rec2 : 0);
   float *scratch = lds_setup<!SPLIT>(m, smem, tabs, wave * EPW + seg, env_stride);
   float4 *cull = (float4 *)scratch;
   // cslot: nb + 1 records, the last one stays zero and stands in for "no child" (the gather then needs no predicates)
@@ -1377,10 +1386,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   int cz[4];  // first four children, the zero record for a missing one
 #pragma unroll
   for (int k = 0; k < 4; ++k) cz[k] = is_body && c.child[k] >= 0 ? c.child[k] : nb;
+  // (quad-lane adjoint: records and cull vectors in two generations by step parity, see its body wave; rec_s / cull_s = this step's)
+  const float *rec_s = rec;
+  const float4 *cull_s = cull;
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {
-    const int pb = (int)(r - rec) / PD_REC;
+    const int pb = (int)(r - rec_s) / PD_REC;
     BodyAdj o = adj_zero();
-    contact_point_adj(r, cull[pb], P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    contact_point_adj(r, cull_s[pb], P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
     adj_store(out, o);
   };
   if (SPLIT && contact_wave) {
@@ -1457,12 +1469,16 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       pair_wait(sig, a.nsteps - step);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for these contact adjoints
       STAMP(9);
+      if constexpr (QUAD) {
+        rec_s = (step & 1) ? jc + 2 * m.env_lds_jc + 4 * nb : rec;
+        cull_s = (step & 1) ? (const float4 *)(jc + 2 * m.env_lds_jc) : cull;
+      }
       if (fast) {
         float out[PD_ADJ];
 #pragma unroll
         for (int i = 0; i < PD_ADJ; ++i) out[i] = 0.f;
         const int pb = l < nh ? (e_c >> 24) & 0x3f : -2;
-        if (l < nh) contact_hit(rec + pb * PD_REC, P_c, M_c, out);
+        if (l < nh) contact_hit(rec_s + pb * PD_REC, P_c, M_c, out);
         STAMP(10);
         bool last;
         seg_run_sum<PD_ADJ>(out, pb, l, nh, last);
@@ -1473,11 +1489,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         STAMP(11);
       } else {
         float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
-        if (is_body) cv = cull[b];
+        if (is_body) cv = cull_s[b];
         int *lg = a.hitlog + ((size_t)step * a.bs + ec) * PD_HITLOG;
         const bool replay = __ballot(env_ok && cnt_c < 0) == 0ull;  // -1: the list did not fit the log, cull again (whole wave)
         int log_n_unused;
-        sweep_contacts<SEGW, PD_ADJ, PD_ADJ, false>(m, tabs, c, cv, rec, cull, list, hits, slot, cacc, is_body, env_ok, seg, l,
+        sweep_contacts<SEGW, PD_ADJ, PD_ADJ, false>(m, tabs, c, cv, rec_s, cull_s, list, hits, slot, cacc, is_body, env_ok, seg, l,
                                                     replay ? lg : nullptr, replay ? (env_ok ? cnt_c : 0) : PD_NO_REPLAY, log_n_unused,
                                                     contact_hit STAMP_PASS);
       }
@@ -1557,21 +1573,31 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       const size_t o = (size_t)sc * a.bs * m.nqd;
       n_tgt = ldg(a.refs + o, boff_qd);   // (unconditional; the applied torque enters the adjoint through the contact wave's jf only)
     };
-    auto q_seeds = [&](int fr) {  // dp_model.py:1264-1271
-      const float *gp = a.adj_pos + ((size_t)fr * N + qidx) * 7, *gv = a.adj_vel + ((size_t)fr * N + qidx) * 6;
-      const float sp = gp[qv], sr = gp[3 + qc], sw = gv[qv], sv = gv[3 + qv];
-      gn.p += k.isv ? sp : 0.f; gn.r += sr; gn.w += k.isv ? sw : 0.f; gn.v += k.isv ? sv : 0.f;
-    };
     const float ake = m.attach_ke, akd = m.attach_kd;
-    if (a.nsteps > 0) load_step(a.nsteps - 1);
-    STAMP_DECL;
-    for (int step = a.nsteps - 1; step >= 0; --step) {
-      PD_WAIT_VMEM();
-      if (n_fr >= 0) q_seeds(n_fr);
+    // Round 6: the step is software-pipelined.  Everything of a step that no adjoint enters -- unpacking the stored state, rotm, the
+    // staged record and cull vector, the forward values integrate_bodies' adjoint needs again, the frame's seeds (a global load) -- is
+    // PRE(step) and runs one step AHEAD, in the window this wave used to spend waiting for the contact adjoints of the step before
+    // (hand-over B: 9 % of the step at 512 envs, and the chain  B -> top -> phase 1 -> A -> contact wave -> B  was the step).  The
+    // records and cull vectors therefore live in two generations by step parity (the contact wave still reads step k's while PRE
+    // stages step k - 1's), like the joint hand-over records.
+    float *const rec2 = jc + 2 * m.env_lds_jc + 4 * nb;
+    float4 *const cull2 = (float4 *)(jc + 2 * m.env_lds_jc);
+    QState s;
+    float t0 = 0.f, f0 = 0.f, tgt = 0.f, rc = 0.f, sd_p = 0.f, sd_r = 0.f, sd_w = 0.f, sd_v = 0.f;
+    unsigned mask = 0u;
+    QM3 Rr, Rc;
+    QIntTmp T;
+    s.p = s.r = s.w = s.v = 0.f;
+    Rr.a = Rr.b = Rr.c = 0.f; Rc = Rr;
+    auto q_pre = [&](int step) {
+      // ---- seeds of this state (dp_model.py:1264-1271): requested here, added when the running adjoint reaches the step
+      const int fr = n_fr;
+      sd_p = 0.f; sd_r = 0.f; sd_w = 0.f; sd_v = 0.f;
+      if (fr >= 0) {
+        const float *gp = a.adj_pos + ((size_t)fr * N + qidx) * 7, *gv = a.adj_vel + ((size_t)fr * N + qidx) * 6;
+        sd_p = gp[qv]; sd_r = gp[3 + qc]; sd_w = gv[qv]; sd_v = gv[3 + qv];
+      }
       // ---- unpack the stored step: planes q | (w, v.x) | (p, v.y) | (v.z, t) | (f, clamp mask)
-      QState s;
-      float t0, f0;
-      unsigned mask;
       {
         const float vx = Q_BC3(n_pl[1]), vy = Q_BC3(n_pl[2]), vz = Q_BC0(n_pl[3]);
         const float tsh = q_dpp<PD_QP(1, 2, 3, 3)>(n_pl[3]);
@@ -1581,27 +1607,32 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         s.v = qc == 0 ? vx : (qc == 1 ? vy : (qc == 2 ? vz : 0.f));
         t0 = k.isv ? tsh : 0.f; f0 = k.isv ? n_pl[4] : 0.f;
       }
-      const float tgt = n_tgt;
-      const size_t oc = (size_t)step * a.bs * m.nqd;
+      tgt = n_tgt;
       load_step(step - 1);
-      QM3 Rr, Rc;
       q_rotm(k, s.r, Rr, Rc);
-      const float rc = q_mvc(Rr, B.com0, B.com1, B.com2);
+      rc = q_mvc(Rr, B.com0, B.com1, B.com2);
       {  // staging (stage_record): the contact wave reads records and cull vectors
-        float *r = rec + bb * PD_REC;
+        float *r = ((step & 1) ? rec2 : rec) + bb * PD_REC;
         r[3 + qc] = s.r;
         r[k.isv ? qc : 16] = s.p; r[k.isv ? 7 + qc : 16] = s.w; r[k.isv ? 10 + qc : 16] = s.v; r[k.isv ? 13 + qc : 16] = rc;  // (lane 3: the record's pad float)
-        if (qc == 1) cull[bb] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
+        if (qc == 1) ((step & 1) ? cull2 : cull)[bb] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
       }
+      q_integrate_adj_pre(k, B, s, Rr, Rc, t0, a.dt, T);
+    };
+    if (a.nsteps > 0) { load_step(a.nsteps - 1); q_pre(a.nsteps - 1); }
+    STAMP_DECL;
+    for (int step = a.nsteps - 1; step >= 0; --step) {
+      gn.p += k.isv ? sd_p : 0.f; gn.r += sd_r; gn.w += k.isv ? sd_w : 0.f; gn.v += k.isv ? sd_v : 0.f;   // (zeros off a frame step)
+      const size_t oc = (size_t)step * a.bs * m.nqd;
+      const float *const rec_g = (step & 1) ? rec2 : rec;
       STAMP(0);
       // ---- adjoint of integrate_bodies, phase 1: the wrench adjoint
-      QIntTmp T;
       QM3 aR;
       aR.a = aR.b = aR.c = 0.f;
       float adj_t0, adj_f0;
-      q_integrate_adj_wrench(k, B, s, Rr, Rc, invIt, mask, t0, a.dt, gn, T, adj_t0, adj_f0);
+      q_integrate_adj_wrench(k, B, s, Rr, Rc, invIt, mask, a.dt, gn, T, adj_t0, adj_f0);
       adjf[bb * PD_W6 + (k.isv ? qc : 6)] = adj_t0; adjf[bb * PD_W6 + (k.isv ? 3 + qc : 6)] = adj_f0;  // (lane 3: the slot's pad float)
-      pair_signal(sig, a.nsteps - step);  // A: records + wrench adjoints are staged
+      pair_signal(sig, a.nsteps - step);  // A: records (staged one step ago) + wrench adjoints
       STAMP(1);
       if (k.isv) {
         float *o = a.g_res_f + (size_t)step * N * 6;  // adjoint of wp_add
@@ -1618,7 +1649,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       par.p = par.r = par.w = par.v = 0.f;
       float a_tgt = 0.f, a_act = 0.f, a_ke = 0.f, a_kd = 0.f;
       {
-        const float *pr = rec + B.pidx * PD_REC, *pa = adjf + B.pidx * PD_W6;
+        const float *pr = rec_g + B.pidx * PD_REC, *pa = adjf + B.pidx * PD_W6;
         const float l_pp = pr[qv], qp = pr[3 + qc], l_wp = pr[7 + qv], l_vp = pr[10 + qv], l_rcp = pr[13 + qv], l_gt = pa[qv], l_gf = pa[3 + qv];
         const float pp = k.isv ? l_pp : 0.f, w_p = k.isv ? l_wp : 0.f, v_p = k.isv ? l_vp : 0.f, rc_par = k.isv ? l_rcp : 0.f;
         const float gp_t = k.isv ? l_gt : 0.f, gp_f = k.isv ? l_gf : 0.f;
@@ -1674,6 +1705,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         }
       }
       STAMP(3);
+      // ---- the state-only half of the NEXT iteration (step - 1; at step 0 it restages state 0 into the other generation, unused)
+      q_pre(step - 1);
+      STAMP(9);
       pair_wait(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
       STAMP(8);
       {
@@ -1685,6 +1719,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       STAMP(4);
     }
     STAMP_FLUSH(a);
+    auto q_seeds = [&](int fr) {  // dp_model.py:1264-1271
+      const float *gp = a.adj_pos + ((size_t)fr * N + qidx) * 7, *gv = a.adj_vel + ((size_t)fr * N + qidx) * 6;
+      const float sp = gp[qv], sr = gp[3 + qc], sw = gv[qv], sv = gv[3 + qv];
+      gn.p += k.isv ? sp : 0.f; gn.r += sr; gn.w += k.isv ? sw : 0.f; gn.v += k.isv ? sv : 0.f;
+    };
     if (a.frame_of_step[0] >= 0) q_seeds(a.frame_of_step[0]);  // seeds of state 0
     // ---- adjoint of eval_fk, in the lane-per-body layout: the running adjoint is transposed through LDS
     WAVE_SYNC();

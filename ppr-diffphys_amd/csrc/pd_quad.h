@@ -54,7 +54,25 @@ PD_DEV float q_dot3(float a, float b) { return q_sum3(a * b); }
 PD_DEV float q_cross(float a, float b) { const float t = a * Q_ROT1(b) - Q_ROT1(a) * b; return Q_ROT1(t); }
 
 struct QM3 { float a, b, c; };  // what lane r holds of a 3 x 3 matrix: its row r (or its column r); lane 3: zeros
+// Multiply-adds whose one factor is a quad broadcast: the compiler fuses a DPP read into v_mul / v_add but not into a contracted
+// fma (v_fma_f32 is VOP3, no DPP operand on gfx9) and leaves  v_mov_b32_dpp + v_fma  per term -- 133 DPP moves in the adjoint's step
+// loop.  v_fmac_f32 is VOP2 and takes the DPP read itself; written as asm, with the s_nop 1 the DPP read-after-VALU-write hazard
+// wants in front (the hazard recognizer does not look into asm).  Term order = the order the contracted expression had.
+#define Q_QP_(a, b, c, d) " quad_perm:[" #a "," #b "," #c "," #d "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define Q_S_BC0 Q_QP_(0, 0, 0, 0)
+#define Q_S_BC1 Q_QP_(1, 1, 1, 1)
+#define Q_S_BC2 Q_QP_(2, 2, 2, 2)
+#define Q_S_BC3 Q_QP_(3, 3, 3, 3)
+#ifndef PD_QUAD_NO_ASM
+PD_DEV float q_mv(QM3 m, float v) {   // lane r: sum_j m[r][j] v_j
+  float r;
+  asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %3" Q_S_BC1 "v_fmac_f32_dpp %0, %1, %2" Q_S_BC0 "v_fmac_f32_dpp %0, %1, %4" Q_S_BC2
+      : "=&v"(r) : "v"(v), "v"(m.a), "v"(m.b), "v"(m.c));
+  return r;
+}
+#else
 PD_DEV float q_mv(QM3 m, float v) { return m.a * Q_BC0(v) + m.b * Q_BC1(v) + m.c * Q_BC2(v); }           // lane r: sum_j m[r][j] v_j
+#endif
 PD_DEV float q_mvc(QM3 m, float v0, float v1, float v2) { return m.a * v0 + m.b * v1 + m.c * v2; }      // v: a per-body constant
 
 // The three permuted, signed copies of b that a Hamilton product a * b needs (reusable when b meets several a):
@@ -65,10 +83,28 @@ PD_DEV QPerm q_perm(const QLane &k, float b) {
   P.p1 = q_dpp<PD_QP(3, 2, 1, 0)>(b) * k.s1; P.p2 = q_dpp<PD_QP(2, 3, 0, 1)>(b) * k.s2; P.p3 = q_dpp<PD_QP(1, 0, 3, 2)>(b) * k.s3;
   return P;
 }
+#ifndef PD_QUAD_NO_ASM
+PD_DEV float q_qmul(float a, float b, const QPerm &P) {
+  float r;
+  asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, %3" Q_S_BC0 "v_fmac_f32_dpp %0, %1, %2" Q_S_BC3 "v_fmac_f32_dpp %0, %1, %4" Q_S_BC1 "v_fmac_f32_dpp %0, %1, %5" Q_S_BC2
+      : "=&v"(r) : "v"(a), "v"(b), "v"(P.p1), "v"(P.p2), "v"(P.p3));
+  return r;
+}
+#else
 PD_DEV float q_qmul(float a, float b, const QPerm &P) { return Q_BC3(a) * b + Q_BC0(a) * P.p1 + Q_BC1(a) * P.p2 + Q_BC2(a) * P.p3; }
+#endif
 PD_DEV float q_qmul(const QLane &k, float a, float b) { return q_qmul(a, b, q_perm(k, b)); }
 // conj(a) * b = a.w b - (a.x P1 + a.y P2 + a.z P3)
+#ifndef PD_QUAD_NO_ASM
+PD_DEV float q_qmul_conj(float a, float b, const QPerm &P) {
+  float r;
+  asm("s_nop 1\n\tv_mul_f32_dpp %0, %1, -%3" Q_S_BC1 "v_fmac_f32_dpp %0, %1, -%2" Q_S_BC0 "v_fmac_f32_dpp %0, %1, -%4" Q_S_BC2 "v_fmac_f32_dpp %0, %1, %5" Q_S_BC3
+      : "=&v"(r) : "v"(a), "v"(P.p1), "v"(P.p2), "v"(P.p3), "v"(b));
+  return r;
+}
+#else
 PD_DEV float q_qmul_conj(float a, float b, const QPerm &P) { return Q_BC3(a) * b - (Q_BC0(a) * P.p1 + Q_BC1(a) * P.p2 + Q_BC2(a) * P.p3); }
+#endif
 
 // quat_rotate (pd_math.h qrot): v (2 w^2 - 1) + 2 w (u x v) + 2 u (u . v); v in lanes (lane 3: 0), result lane 3: 0
 PD_DEV float q_qrot(const QLane &k, float q, float v) {
@@ -199,15 +235,24 @@ PD_DEV float q_rotm_adj(const QLane &k, float q, QM3 A) {
   return k.isv ? au : aw;
 }
 
+#ifndef PD_QUAD_NO_ASM
+PD_DEV void q_add_outer(QM3 &M, float a, float b) {   // M[r][j] += a_r b_j
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %3, %4" Q_S_BC0 "v_fmac_f32_dpp %1, %3, %4" Q_S_BC1 "v_fmac_f32_dpp %2, %3, %4" Q_S_BC2
+      : "+v"(M.a), "+v"(M.b), "+v"(M.c) : "v"(b), "v"(a));
+}
+#else
 PD_DEV void q_add_outer(QM3 &M, float a, float b) { M.a += a * Q_BC0(b); M.b += a * Q_BC1(b); M.c += a * Q_BC2(b); }   // M[r][j] += a_r b_j
+#endif
 PD_DEV void q_add_outer_c(QM3 &M, float a, float b0, float b1, float b2) { M.a += a * b0; M.b += a * b1; M.c += a * b2; }  // b: per-body constant
 
 // Adjoint of integrate_bodies (pd_device.h integrate_adj2), quad-lane.  Rr / Rc rows / columns of rotm(s.r); It / invIt: the
 // transposed inertia / inverse inertia (row c of the transpose); mask: the forward pass's clamp mask; gn: adjoint of the next state.
-// Phase 1 ends with the wrench adjoint (adj_t0, adj_f0); phase 2 (q_integrate_adj_rest) needs nothing from other waves.
-struct QIntTmp { float wb, Iwb, tb, u, w1, adj_w1, adj_v1, adj_rq, gW, adj_tb, adj_a, adj_wb; };
-PD_DEV void q_integrate_adj_wrench(const QLane &k, const QBody &B, const QState &s, QM3 Rr, QM3 Rc, QM3 invIt, unsigned mask, float t0, float dt,
-                                   const QAdj &gn, QIntTmp &T, float &adj_t0, float &adj_f0) {
+// q_integrate_adj_pre recomputes the forward values, phase 1 (q_integrate_adj_wrench) ends with the wrench adjoint (adj_t0, adj_f0),
+// phase 2 (q_integrate_adj_rest) needs nothing from other waves.
+struct QIntTmp { float wb, Iwb, tb, u, w1, adj_w1, adj_v1, adj_rq, gW, adj_tb, adj_a, adj_wb, il, r1; };
+// The forward values the adjoint needs again (no adjoint enters): the kernel runs this one step AHEAD of the reverse part, while it
+// would otherwise wait for the contact adjoints.
+PD_DEV void q_integrate_adj_pre(const QLane &k, const QBody &B, const QState &s, QM3 Rr, QM3 Rc, float t0, float dt, QIntTmp &T) {
   T.wb = q_mv(Rc, s.w);
   T.Iwb = q_mv(B.I, T.wb);
   T.tb = q_mv(Rc, t0) - q_cross(T.wb, T.Iwb);
@@ -215,8 +260,12 @@ PD_DEV void q_integrate_adj_wrench(const QLane &k, const QBody &B, const QState 
   T.w1 = q_mv(Rr, T.u);
   const float qm = Q_BC3(s.r) * T.w1 + q_cross(T.w1, s.r) - k.m3 * q_sum3(T.w1 * s.r);   // quat(w1, 0) * r
   const float rq = s.r + qm * (0.5f * dt);
-  const float il = rcp_hw(sqrt_hw(q_sum4(rq * rq)));
-  const float r1 = rq * il;
+  T.il = rcp_hw(sqrt_hw(q_sum4(rq * rq)));
+  T.r1 = rq * T.il;
+}
+PD_DEV void q_integrate_adj_wrench(const QLane &k, const QBody &B, const QState &s, QM3 Rr, QM3 Rc, QM3 invIt, unsigned mask, float dt,
+                                   const QAdj &gn, QIntTmp &T, float &adj_t0, float &adj_f0) {
+  const float il = T.il, r1 = T.r1;
   // ---- reverse
   const float adj_r1 = gn.r + q_adj_qrot_q(k, r1, B.com, -gn.p);                        // p1 = x1 - rot(r1, com)
   T.adj_v1 = (mask & (8u << k.c)) ? 0.0f * gn.v : gn.v;                                 // clamp adjoints: the forward pass's decisions
