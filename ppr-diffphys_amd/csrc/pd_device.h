@@ -44,7 +44,7 @@ struct PdDevModel {
   int cu_count;                                           // compute units of the device (launch heuristics)
   int env_lds_jc;                                         // + joint hand-over records (2-role wave-specialised adjoint only)
   int env_lds_bwd3;                                       // per-env LDS scratch of the 3-role adjoint kernel (k_rollout_bwd3)
-  int env_lds_rec2;                                       // second generation of cull vectors + records (quad-lane adjoint: the step is software-pipelined)
+  int env_lds_rec2;                                       // quad-lane adjoint (64-lane copy of an eligible model, else 0): PD_QGEN generations of cull vectors + records and of the state-only hand-over
   const float *X_p_env;                                   // [xp_envs][nb][7] per-env joint_X_p bound by the caller, or null (template X_p)
   int xp_envs;
 };
@@ -808,6 +808,9 @@ PD_DEV void joint_adj(const PdDevModel &m, const BodyConst &c, const BodyState &
 // LDS -- and rev_adjoint, on the body wave, is the part that needs the wrench adjoints.  Together they equal the
 // revolute branch of joint_adj.
 #define PD_JC 23  // floats of the hand-over record (odd stride)
+#define PD_QPRE 22  // floats per LANE of the quad-lane adjoint's state-only hand-over (contact wave -> body wave, [field][64 lanes]): s (4), t0, f0,
+                    // clamp mask, rc, rotm rows (3) and columns (3), the forward values of integrate_bodies' adjoint (QIntTmp: wb, Iwb, tb, u, w1, il, r1), pad
+#define PD_QGEN 3   // generations of it (and of the records / cull vectors the same wave stages): step k - 1 is written while k and k + 1 are read
 struct RevCache {
   qt q_p, r_err;
   v3 x_p, axis_p, axis_c;

@@ -257,7 +257,9 @@ static int build_device(pd_model *m, int segw) {
   // the role-split adjoint (k_rollout_bwd3) keeps the contact tables in global memory; per env: two generations of cull vectors and records,
   // wrench adjoints, (parent, own) joint slots + the zero record, contact sums, inertia-gradient accumulators, tile list, hit list, per-hit slots, signals
   d.env_lds_jc = ((nb * PD_JC + 31) / 32) * 32;
-  d.env_lds_rec2 = ((nb * (4 + PD_REC) + 31) / 32) * 32;  // (quad-lane adjoint only)
+  // quad-lane adjoint (the 64-lane copy of an eligible model, build_quad): PD_QGEN generations of what its state wave stages ahead of the
+  // other two -- cull vectors + records, the state-only values of the body wave's step (PD_QPRE floats per lane), joint hand-over records
+  d.env_lds_rec2 = (segw == 64 && jt == PD_JT_REVOLUTE && nb <= 16) ? PD_QGEN * (((nb * (4 + PD_REC) + 31) / 32) * 32 + PD_QPRE * 64 + d.env_lds_jc) : 0;
   d.env_lds_bwd3 = ((nb * (2 * (4 + PD_REC) + PD_W6 + 3 * PD_ADJ + PD_GACC) + PD_GACC + PD_ADJ + std::max(ntiles, 2 * nb) + 8 * segw + PD_ADJ * segw + 3) / 4) * 4 + 4;
   d.env_lds_bwd3 += (16 - d.env_lds_bwd3 % 32 + 32) % 32;  // env stride 16 mod 32, as above
   // revolute-only: 2-role kernel (+ joint hand-over records) or the 3-role one, no tables; other joint mixes: the 2-role
@@ -360,8 +362,10 @@ static hipError_t launch(const pd_model *m, int kind, const void *args, int n_en
   if (use_quad(m, kind, n_envs, args)) {
     const PdDevModel &d = m->quad->dev;
     PdLaunchCfg c{};
-    c.kernel = kind == PD_K_ROLLOUT_FWD ? PD_KV_FWD_QUAD : PD_KV_BWD_QUAD; c.roles = 2;
+    c.kernel = kind == PD_K_ROLLOUT_FWD ? PD_KV_FWD_QUAD : PD_KV_BWD_QUAD;
+    c.roles = kind == PD_K_ROLLOUT_FWD ? 2 : 3;   // adjoint: body, contact and state wave per env
     c.groups = g_groups ? g_groups : pd_groups_per_wg(n_envs, d.cu_count);
+    if (c.roles == 3 && c.groups > 2) c.groups = 2;   // (three roles: at most 384 threads, two waves per SIMD -- the body wave needs its 256 VGPRs)
     c.nblocks = (n_envs + c.groups - 1) / c.groups;
     c.threads = c.roles * c.groups * 64;
     c.lds = kind == PD_K_ROLLOUT_FWD ? m->quad->lds_tables + (size_t)c.groups * d.env_lds_floats * 4   // contact tables in LDS

@@ -1336,14 +1336,24 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
 // =============================================================================================
 // EARLY (SPLIT only): hand-over A is signalled from inside the adjoint of integrate_bodies, as soon as the wrench adjoint
 // exists (integrate_adj2), instead of after it.
+#ifdef PD_KNOCK
+// Timing experiment only (results are wrong): the ADJOINT kernels' waves run through their waits -- PD_KNOCK & 1 the first role's
+// (body / integrate waves), & 2 the second role's (contact / joint waves) -- which gives each role's own instruction stream time.
+PD_DEV int pair_wait_knock(int *flag, int value) {
+  if (PD_KNOCK & (((int)(threadIdx.x >> 6) >= (int)blockDim.x / 128) ? 2 : 1)) return value;
+  return pair_wait(flag, value);
+}
+#define pair_wait pair_wait_knock
+#endif
 // QUAD: the body wave in the four-lanes-per-body form (pd_quad.h), one env per wave, 64-lane mapping -- see k_rollout_fwd.
 template <int SEGW, int JT, bool SPLIT, bool EARLY = false, bool QUAD = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(PdDevModel m, RolloutArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
-  const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);  // env groups per workgroup (host's choice per launch)
-  const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
+  const int bw = (int)blockDim.x / (QUAD ? 192 : (SPLIT ? 128 : 64));  // env groups per workgroup (host's choice per launch)
+  const int role = SPLIT ? (int)(threadIdx.x >> 6) / bw : 0;  // wave-uniform: 0 body wave, 1 contact wave, 2 (QUAD) state wave
+  const bool contact_wave = role != 0;
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   // pair signals: the spare words at the end of the first env's area
   int *sig = (int *)(scratch - (size_t)seg * env_stride + m.env_lds_floats - 4);
   if (SPLIT) {
-    if (lane == 0 && !contact_wave) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
+    if (lane == 0 && !contact_wave) { sig[0] = 0; sig[1] = 0; sig[2] = 0; sig[3] = 0; }
     __syncthreads();
   }
   if constexpr (QUAD) {
@@ -1437,15 +1447,91 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     float4 pose[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) pose[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- QUAD (round 6): a THIRD role, the state wave.  Everything of a step that no adjoint enters runs there, up to PD_QGEN - 1 steps
+    // ahead of the other two: the state-only half of the revolute joints' adjoint (rev_forward, lane-per-body layout: it was this wave's)
+    // and PRE(step) of the body wave's stream -- unpack the stored state, rotm, the staged record and cull vector, the forward values
+    // integrate_bodies' adjoint needs again -- in the body wave's four-lanes-per-body layout, handed over through LDS (PD_QPRE floats
+    // per lane).  Measured at 512 envs with one role's waves alone in the kernel: body wave 0.174 ms, contact wave 0.181 ms, the pair
+    // 0.198 ms -- each wave's own instruction stream is the step.  PRE inside the contact wave: body 0.153, contact 0.224, pair 0.233.
+    // Generations by step modulo PD_QGEN: the state wave writes step k's when the body wave has signalled A of step k + PD_QGEN - 1.
+    const int qb = lane >> 2, qc = lane & 3, bbq = qb < nb ? qb : nb - 1;
+    const QLane kq = q_lane(qc);
+    const int qgen_floats = m.env_lds_rec2 / PD_QGEN - PD_QPRE * 64 - m.env_lds_jc;   // cull vectors + records of one generation
+    float *const qgen = jc + 2 * m.env_lds_jc, *const qpre = qgen + PD_QGEN * qgen_floats;
+    QBody Bq;
+    float npl_c[PD_TRAJ_G];
+    const unsigned boff_tjq = (unsigned)(((size_t)ec * nb + bbq) * 4 + qc) * 4u;
+    auto load_planes = [&](int step, float *pl) {
+      const float *tj = a.ws + (size_t)__builtin_amdgcn_readfirstlane(step > 0 ? step : 0) * (PD_TRAJ_G * 4) * N;
+#pragma unroll
+      for (int g = 0; g < PD_TRAJ_G; ++g) pl[g] = ldg(tj + (size_t)(4 * g) * N, boff_tjq);
+    };
+    auto q_pre = [&](const float *pl, int g) {   // PRE of the step whose planes are pl, into generation g
+      // ---- unpack the stored step: planes q | (w, v.x) | (p, v.y) | (v.z, t) | (f, clamp mask)
+      QState s;
+      const float vx = Q_BC3(pl[1]), vy = Q_BC3(pl[2]), vz = Q_BC0(pl[3]);
+      const float tsh = q_dpp<PD_QP(1, 2, 3, 3)>(pl[3]);
+      const float maskf = Q_BC3(pl[4]);
+      s.r = pl[0];
+      s.w = kq.isv ? pl[1] : 0.f; s.p = kq.isv ? pl[2] : 0.f;
+      s.v = qc == 0 ? vx : (qc == 1 ? vy : (qc == 2 ? vz : 0.f));
+      const float t0 = kq.isv ? tsh : 0.f, f0 = kq.isv ? pl[4] : 0.f;
+      QM3 Rr, Rc;
+      q_rotm(kq, s.r, Rr, Rc);
+      const float rc = q_mvc(Rr, Bq.com0, Bq.com1, Bq.com2);
+      {  // staging (stage_record): this wave's contact adjoint and the body wave's joint adjoint read records and cull vectors
+        float *G = qgen + g * qgen_floats, *r = G + 4 * nb + bbq * PD_REC;
+        r[3 + qc] = s.r;
+        r[kq.isv ? qc : 16] = s.p; r[kq.isv ? 7 + qc : 16] = s.w; r[kq.isv ? 10 + qc : 16] = s.v; r[kq.isv ? 13 + qc : 16] = rc;  // (lane 3: the record's pad float)
+        if (qc == 1) ((float4 *)G)[bbq] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
+      }
+      QIntTmp T;
+      q_integrate_adj_pre(kq, Bq, s, Rr, Rc, t0, a.dt, T);
+      float *P = qpre + g * (PD_QPRE * 64) + lane;
+      P[0 * 64] = s.p; P[1 * 64] = s.r; P[2 * 64] = s.w; P[3 * 64] = s.v; P[4 * 64] = t0; P[5 * 64] = f0; P[6 * 64] = maskf; P[7 * 64] = rc;
+      P[8 * 64] = Rr.a; P[9 * 64] = Rr.b; P[10 * 64] = Rr.c; P[11 * 64] = Rc.a; P[12 * 64] = Rc.b; P[13 * 64] = Rc.c;
+      P[14 * 64] = T.wb; P[15 * 64] = T.Iwb; P[16 * 64] = T.tb; P[17 * 64] = T.u; P[18 * 64] = T.w1; P[19 * 64] = T.il; P[20 * 64] = T.r1;
+    };
+    int g3 = a.nsteps > 0 ? (a.nsteps - 1) % PD_QGEN : 0;   // generation of the step at hand (step % PD_QGEN)
+    if constexpr (QUAD) {
+      if (role == 2) {
+        // ================= state wave
+        const BodyConst cb = load_body_const(m, bbq, ec);
+        const size_t qidx = (size_t)ec * nb + bbq;
+        const int qv = qc < 3 ? qc : 2;
+        Bq.com0 = cb.com.x; Bq.com1 = cb.com.y; Bq.com2 = cb.com.z;
+        const float *Ib = a.inertia + qidx * 9, *Jb = a.inv_inertia + qidx * 9;
+        Bq.I.a = kq.isv ? Ib[qv * 3] : 0.f; Bq.I.b = kq.isv ? Ib[qv * 3 + 1] : 0.f; Bq.I.c = kq.isv ? Ib[qv * 3 + 2] : 0.f;
+        Bq.invI.a = kq.isv ? Jb[qv * 3] : 0.f; Bq.invI.b = kq.isv ? Jb[qv * 3 + 1] : 0.f; Bq.invI.c = kq.isv ? Jb[qv * 3 + 2] : 0.f;
+        float *const jcq = qpre + PD_QGEN * (PD_QPRE * 64);   // the joint hand-over records, PD_QGEN generations
+        if (a.nsteps > 0) { load_ctrl(a.nsteps - 1, tgt_c, act_c); load_pose(a.nsteps - 1, pose); load_planes(a.nsteps - 1, npl_c); }
+        for (int step = a.nsteps - 1; step >= 0; --step) {
+          PD_WAIT_VMEM();
+          // generation g3 is free once the body wave has left step + PD_QGEN behind: its hand-over A of step + PD_QGEN - 1 (<= 0: at once)
+          pair_wait(sig, a.nsteps - step - (PD_QGEN - 1));
+          if (rev) {
+            const qt q_c = Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), qp = Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w);
+            const v3 w_c = V3(pose[1].x, pose[1].y, pose[1].z), pp = V3(pose[4].x, pose[4].y, pose[4].z), w_p = V3(pose[3].x, pose[3].y, pose[3].z);
+            rev_cache_store(jcq + g3 * m.env_lds_jc + b * PD_JC, rev_forward<pd_parented(JT)>(m, c, q_c, w_c, pp, qp, w_p, tgt_c, act_c, ke1, kd1));
+          }
+          q_pre(npl_c, g3);
+          load_ctrl(step - 1, tgt_c, act_c); load_pose(step - 1, pose); load_planes(step - 1, npl_c);
+          pair_signal(sig + 1, a.nsteps - step);   // S: this step's joint hand-over records, records, cull vectors and PRE are staged
+          g3 = g3 == 0 ? PD_QGEN - 1 : g3 - 1;
+        }
+        return;
+      }
+    }
     if (a.nsteps > 0) {
-      load_log(a.nsteps - 1, cnt_c, e_c); load_ctrl(a.nsteps - 1, tgt_c, act_c); load_pose(a.nsteps - 1, pose);
+      load_log(a.nsteps - 1, cnt_c, e_c);
+      if constexpr (!QUAD) { load_ctrl(a.nsteps - 1, tgt_c, act_c); load_pose(a.nsteps - 1, pose); }
       load_log(a.nsteps - 2, cnt_n, e_n);
       fetch_point(cnt_c, e_c, P_c, M_c);
     }
     for (int step = a.nsteps - 1; step >= 0; --step) {
       PD_WAIT_VMEM();
       // (the hand-over records are double-buffered by step parity: the body wave may still be reading the previous ones)
-      if (rev)
+      if (!QUAD && rev)
       {
         const qt q_c = Q4(pose[0].x, pose[0].y, pose[0].z, pose[0].w), qp = Q4(pose[2].x, pose[2].y, pose[2].z, pose[2].w);
         const v3 w_c = V3(pose[1].x, pose[1].y, pose[1].z), pp = V3(pose[4].x, pose[4].y, pose[4].z), w_p = V3(pose[3].x, pose[3].y, pose[3].z);
@@ -1458,20 +1544,24 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       float4 P_n, M_n;
       int cnt_n2, e_n2;
       fetch_point(cnt_n, e_n, P_n, M_n);
-      load_ctrl(step - 1, tgt_n, act_n);
-      load_pose(step - 1, pose);
+      if constexpr (!QUAD) {
+        load_ctrl(step - 1, tgt_n, act_n);
+        load_pose(step - 1, pose);
+      } else {
+        tgt_n = 0.f; act_n = 0.f;
+      }
       load_log(step - 2, cnt_n2, e_n2);
       const bool fast = __ballot(env_ok && (cnt_c < 0 || cnt_c > SEGW)) == 0ull;  // wave-uniform
       const int nh = fast && env_ok ? cnt_c : 0;
       STAMP(7);
       // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
-      pair_signal(sig + 1, a.nsteps - step);
+      if constexpr (!QUAD) pair_signal(sig + 1, a.nsteps - step);
       pair_wait(sig, a.nsteps - step);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for these contact adjoints
       STAMP(9);
       if constexpr (QUAD) {
-        rec_s = (step & 1) ? jc + 2 * m.env_lds_jc + 4 * nb : rec;
-        cull_s = (step & 1) ? (const float4 *)(jc + 2 * m.env_lds_jc) : cull;
+        rec_s = qgen + g3 * qgen_floats + 4 * nb;
+        cull_s = (const float4 *)(qgen + g3 * qgen_floats);
       }
       if (fast) {
         float out[PD_ADJ];
@@ -1502,6 +1592,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       __builtin_amdgcn_s_setprio(0);
       cnt_c = cnt_n; e_c = e_n; P_c = P_n; M_c = M_n; tgt_c = tgt_n; act_c = act_n;
       cnt_n = cnt_n2; e_n = e_n2;
+      if constexpr (QUAD) g3 = g3 == 0 ? PD_QGEN - 1 : g3 - 1;
     }
     STAMP_FLUSH(a);
     return;
@@ -1562,34 +1653,28 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     // stored state / wrench / controls of the NEXT iteration are prefetched: lane c owns float c of each trajectory plane
     const unsigned boff_tj = (unsigned)(qidx * 4 + qc) * 4u, boff_qd = (unsigned)((size_t)ec * m.nqd + B.qdstart) * 4u;
     const unsigned boff_rf = (unsigned)(qidx * 6 + qv) * 4u;
-    float n_pl[PD_TRAJ_G], n_tgt = 0.f;
+    float n_tgt = 0.f;
     int n_fr = -1;
     auto load_step = [&](int step) {
       const int sc = __builtin_amdgcn_readfirstlane(step >= 0 ? step : 0);
       n_fr = a.frame_of_step[sc + 1];
-      const float *tj = a.ws + (size_t)sc * (PD_TRAJ_G * 4) * N;
-#pragma unroll
-      for (int g = 0; g < PD_TRAJ_G; ++g) n_pl[g] = ldg(tj + (size_t)(4 * g) * N, boff_tj);
       const size_t o = (size_t)sc * a.bs * m.nqd;
       n_tgt = ldg(a.refs + o, boff_qd);   // (unconditional; the applied torque enters the adjoint through the contact wave's jf only)
     };
     const float ake = m.attach_ke, akd = m.attach_kd;
-    // Round 6: the step is software-pipelined.  Everything of a step that no adjoint enters -- unpacking the stored state, rotm, the
-    // staged record and cull vector, the forward values integrate_bodies' adjoint needs again, the frame's seeds (a global load) -- is
-    // PRE(step) and runs one step AHEAD, in the window this wave used to spend waiting for the contact adjoints of the step before
-    // (hand-over B: 9 % of the step at 512 envs, and the chain  B -> top -> phase 1 -> A -> contact wave -> B  was the step).  The
-    // records and cull vectors therefore live in two generations by step parity (the contact wave still reads step k's while PRE
-    // stages step k - 1's), like the joint hand-over records.
-    float *const rec2 = jc + 2 * m.env_lds_jc + 4 * nb;
-    float4 *const cull2 = (float4 *)(jc + 2 * m.env_lds_jc);
+    // Round 6: everything of a step that no adjoint enters -- unpacking the stored state, rotm, the staged record and cull vector, the
+    // forward values integrate_bodies' adjoint needs again -- is PRE(step).  It first moved one step ahead inside this wave, into the wait
+    // for the contact adjoints (0.208 -> 0.199 ms at 512 envs); then to the CONTACT wave, whose stream was less than half of this one's
+    // (see there): this wave takes PD_QPRE floats per lane from LDS.  What stays here of the look-ahead: the target angle and the
+    // frame's seeds (global loads, requested one step early).
+    const int qgen_floats = m.env_lds_rec2 / PD_QGEN - PD_QPRE * 64 - m.env_lds_jc;
+    float *const qgen = jc + 2 * m.env_lds_jc, *const qpre = qgen + PD_QGEN * qgen_floats;
     QState s;
     float t0 = 0.f, f0 = 0.f, tgt = 0.f, rc = 0.f, sd_p = 0.f, sd_r = 0.f, sd_w = 0.f, sd_v = 0.f;
     unsigned mask = 0u;
     QM3 Rr, Rc;
     QIntTmp T;
-    s.p = s.r = s.w = s.v = 0.f;
-    Rr.a = Rr.b = Rr.c = 0.f; Rc = Rr;
-    auto q_pre = [&](int step) {
+    auto q_ahead = [&](int step) {
       // ---- seeds of this state (dp_model.py:1264-1271): requested here, added when the running adjoint reaches the step
       const int fr = n_fr;
       sd_p = 0.f; sd_r = 0.f; sd_w = 0.f; sd_v = 0.f;
@@ -1597,34 +1682,28 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         const float *gp = a.adj_pos + ((size_t)fr * N + qidx) * 7, *gv = a.adj_vel + ((size_t)fr * N + qidx) * 6;
         sd_p = gp[qv]; sd_r = gp[3 + qc]; sd_w = gv[qv]; sd_v = gv[3 + qv];
       }
-      // ---- unpack the stored step: planes q | (w, v.x) | (p, v.y) | (v.z, t) | (f, clamp mask)
-      {
-        const float vx = Q_BC3(n_pl[1]), vy = Q_BC3(n_pl[2]), vz = Q_BC0(n_pl[3]);
-        const float tsh = q_dpp<PD_QP(1, 2, 3, 3)>(n_pl[3]);
-        mask = __float_as_uint(Q_BC3(n_pl[4]));
-        s.r = n_pl[0];
-        s.w = k.isv ? n_pl[1] : 0.f; s.p = k.isv ? n_pl[2] : 0.f;
-        s.v = qc == 0 ? vx : (qc == 1 ? vy : (qc == 2 ? vz : 0.f));
-        t0 = k.isv ? tsh : 0.f; f0 = k.isv ? n_pl[4] : 0.f;
-      }
       tgt = n_tgt;
       load_step(step - 1);
-      q_rotm(k, s.r, Rr, Rc);
-      rc = q_mvc(Rr, B.com0, B.com1, B.com2);
-      {  // staging (stage_record): the contact wave reads records and cull vectors
-        float *r = ((step & 1) ? rec2 : rec) + bb * PD_REC;
-        r[3 + qc] = s.r;
-        r[k.isv ? qc : 16] = s.p; r[k.isv ? 7 + qc : 16] = s.w; r[k.isv ? 10 + qc : 16] = s.v; r[k.isv ? 13 + qc : 16] = rc;  // (lane 3: the record's pad float)
-        if (qc == 1) ((step & 1) ? cull2 : cull)[bb] = make_float4(s.p, Rr.a, Rr.b, Rr.c);
-      }
-      q_integrate_adj_pre(k, B, s, Rr, Rc, t0, a.dt, T);
     };
-    if (a.nsteps > 0) { load_step(a.nsteps - 1); q_pre(a.nsteps - 1); }
+    auto q_take = [&](int g) {   // the contact wave's PRE of generation g
+      const float *P = qpre + g * (PD_QPRE * 64) + lane;
+      s.p = P[0 * 64]; s.r = P[1 * 64]; s.w = P[2 * 64]; s.v = P[3 * 64]; t0 = P[4 * 64]; f0 = P[5 * 64]; mask = __float_as_uint(P[6 * 64]); rc = P[7 * 64];
+      Rr.a = P[8 * 64]; Rr.b = P[9 * 64]; Rr.c = P[10 * 64]; Rc.a = P[11 * 64]; Rc.b = P[12 * 64]; Rc.c = P[13 * 64];
+      T.wb = P[14 * 64]; T.Iwb = P[15 * 64]; T.tb = P[16 * 64]; T.u = P[17 * 64]; T.w1 = P[18 * 64]; T.il = P[19 * 64]; T.r1 = P[20 * 64];
+    };
+    int g3 = a.nsteps > 0 ? (a.nsteps - 1) % PD_QGEN : 0;   // generation of the step at hand (step % PD_QGEN)
+    if (a.nsteps > 0) {
+      load_step(a.nsteps - 1);
+      PD_WAIT_VMEM();
+      q_ahead(a.nsteps - 1);
+      pair_wait(sig + 1, 1);   // S: the state wave's step nsteps - 1
+      q_take(g3);
+    }
     STAMP_DECL;
     for (int step = a.nsteps - 1; step >= 0; --step) {
       gn.p += k.isv ? sd_p : 0.f; gn.r += sd_r; gn.w += k.isv ? sd_w : 0.f; gn.v += k.isv ? sd_v : 0.f;   // (zeros off a frame step)
       const size_t oc = (size_t)step * a.bs * m.nqd;
-      const float *const rec_g = (step & 1) ? rec2 : rec;
+      const float *const rec_g = qgen + g3 * qgen_floats + 4 * nb, *const jc_g = qpre + PD_QGEN * (PD_QPRE * 64) + g3 * m.env_lds_jc;
       STAMP(0);
       // ---- adjoint of integrate_bodies, phase 1: the wrench adjoint
       QM3 aR;
@@ -1642,8 +1721,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       QAdj ga;
       q_integrate_adj_rest(k, B, s, Rr, It, t0, f0, a.dt, gn, T, ga, aR, g_inv_m, g_I, g_invI);
       STAMP(5);
-      pair_wait(sig + 1, a.nsteps - step);  // the contact wave's joint hand-over records
-      STAMP(6);
+      STAMP(6);   // (the joint hand-over records came with hand-over S of this step, taken one iteration ago)
       // ---- adjoint of eval_body_joints
       QAdj par;
       par.p = par.r = par.w = par.v = 0.f;
@@ -1653,7 +1731,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         const float l_pp = pr[qv], qp = pr[3 + qc], l_wp = pr[7 + qv], l_vp = pr[10 + qv], l_rcp = pr[13 + qv], l_gt = pa[qv], l_gf = pa[3 + qv];
         const float pp = k.isv ? l_pp : 0.f, w_p = k.isv ? l_wp : 0.f, v_p = k.isv ? l_vp : 0.f, rc_par = k.isv ? l_rcp : 0.f;
         const float gp_t = k.isv ? l_gt : 0.f, gp_f = k.isv ? l_gf : 0.f;
-        const QRev R = q_rev_load(k, jc + (step & 1) * m.env_lds_jc + bb * PD_JC, qv);
+        const QRev R = q_rev_load(k, jc_g + bb * PD_JC, qv);
         QAdj own, pj_;
         own.p = own.r = own.w = own.v = 0.f;
         QM3 aRj;
@@ -1705,8 +1783,12 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
         }
       }
       STAMP(3);
-      // ---- the state-only half of the NEXT iteration (step - 1; at step 0 it restages state 0 into the other generation, unused)
-      q_pre(step - 1);
+      // ---- the NEXT iteration's look-ahead: seeds / target requested, the contact wave's PRE(step - 1) taken (its LDS reads fly while this
+      // wave waits for B; at step 0: PRE of state 0 again, unused)
+      q_ahead(step - 1);
+      g3 = g3 == 0 ? PD_QGEN - 1 : g3 - 1;
+      pair_wait(sig + 1, step > 0 ? a.nsteps - step + 1 : a.nsteps);  // S: the state wave's step - 1 (at step 0 there is none: what is taken is not used)
+      q_take(g3);
       STAMP(9);
       pair_wait(sig + 2, a.nsteps - step);  // B: contact adjoints are complete
       STAMP(8);
@@ -1725,7 +1807,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       gn.p += k.isv ? sp : 0.f; gn.r += sr; gn.w += k.isv ? sw : 0.f; gn.v += k.isv ? sv : 0.f;
     };
     if (a.frame_of_step[0] >= 0) q_seeds(a.frame_of_step[0]);  // seeds of state 0
-    // ---- adjoint of eval_fk, in the lane-per-body layout: the running adjoint is transposed through LDS
+    // ---- adjoint of eval_fk, in the lane-per-body layout: the running adjoint is transposed through LDS; state 0's records are the
+    // contact wave's generation 0 (taken above: hand-over P of step 0)
+    float *const rec0 = qgen + 4 * nb;
     WAVE_SYNC();
     if (qbody) {
       float *d = cacc + bb * PD_ADJ;
@@ -1739,8 +1823,8 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       if (a.nsteps == 0) {
         for (int d = 0; d <= m.max_depth; ++d) {  // nothing staged yet: rebuild state 0
           if (is_body && c.depth == d) {
-            BodyState s0 = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
-            stage_record(rec, b, s0, c.com);
+            BodyState s0 = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec0);
+            stage_record(rec0, b, s0, c.com);
           }
           WAVE_SYNC();
         }
@@ -1751,7 +1835,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
             int cid = (int)((c.children >> (8 * j)) & 0xffull);
             if (cid != 0xff) adj_add_from(gs, cslot + cid * PD_ADJ);
           }
-          BodyAdj pr_ = fk_joint_adj<JT, 1>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec,
+          BodyAdj pr_ = fk_joint_adj<JT, 1>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec0,
                                           gs, a.g_q_init + (size_t)ec * m.nq + c.qstart, a.g_qd_init + (size_t)ec * m.nqd + c.qdstart);
           adj_store(cslot + b * PD_ADJ, pr_);
         }

@@ -72,10 +72,11 @@ elif wb == 2 * G and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ c
     report("BWD", "joint wave", rows(b_all, 1), [(7, "top: prefetch controls"), (8, "wait S + joint_adj_prep"), (9, "wait A"),
                                                 (10, "joint_adj_apply + slots"), (11, "signal J + control-gradient stores")])
 elif segw == 64 and name == "laikago" and os.environ.get("PD_FAMILY", "") != "1":  # quad-lane adjoint (small batches)
-    report("BWD", "body wave (quad)", rows(b_all, 0), [(0, "top: vmcnt wait, seeds, unpack, prefetch, rotm, stage"), (1, "integrate adj phase 1 + adjf + signal A"),
+    report("BWD", "body wave (quad)", rows(b_all, 0), [(0, "seeds added"), (1, "integrate adj phase 1 (reverse part) + adjf + signal A"),
                                                       (5, "g_res_f stores + integrate adj phase 2"), (6, "wait J (joint hand-over records)"),
                                                       (2, "LDS reads + rev_adjoint"), (7, "rotm adjoint + slots + control-gradient stores"),
-                                                      (3, "child gather"), (8, "wait B"), (4, "cacc")])
+                                                      (3, "child gather"), (9, "PRE of the next iteration: unpack, prefetch, rotm, stage, forward values"),
+                                                      (8, "wait B"), (4, "cacc")])
     report("BWD", "contact wave", rows(b_all, 1), [(8, "joint state-only half -> LDS"), (7, "prefetch issue"), (9, "wait at hand-over A"),
                                                   (10, "contact adjoint per hit"), (11, "per-body sums"), (12, "tail / generic sweep")])
 else:
