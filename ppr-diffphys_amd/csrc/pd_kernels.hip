@@ -174,6 +174,20 @@ PD_DEV int pair_wait(int *flag, int value) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return v;
 }
+// Timing experiments only (-DPD_KNOCK=bits, results are WRONG): what one role's own instruction stream costs.
+//   1: role-0 waves (body / integrate) run through their waits    2: the other roles' waves run through theirs
+//   4: role-0 waves leave at once                                 8: the other roles' waves leave at once
+//  16: applies to the forward kernel (default: the adjoint kernels)
+// e.g. 9 = body waves alone, 6 = the other role(s) alone, 3 = every wave free of the others (EXPERIMENTS.md round 6).
+#ifdef PD_KNOCK
+PD_DEV int pair_wait_knock(int *flag, int value, int role) {
+  if (PD_KNOCK & (role ? 2 : 1)) return value;
+  return pair_wait(flag, value);
+}
+#define PD_KNOCK_EXIT(fwd, role) do { if ((((PD_KNOCK) & 16) != 0) == (fwd) && ((PD_KNOCK) & ((role) ? 8 : 4))) return; } while (0)
+#else
+#define PD_KNOCK_EXIT(fwd, role)
+#endif
 
 // Ground-contact sweep for one segment (= one env).  Conservative three-level cull, then the exact
 // test of the reference inside on_hit.  All tables are in LDS (copied once per workgroup):
@@ -530,6 +544,9 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 // QUAD (small batches of revolute-only robots; pd_quad.h): the body wave gives every body FOUR lanes (component-parallel arithmetic),
 // one env per wave, SEGW = 64 so that the contact wave and every LDS table are those of the 64-lane mapping.  Same records, same
 // hand-overs, same trajectory layout: the adjoint kernels run on what it saves.
+#if defined(PD_KNOCK) && (PD_KNOCK & 16)
+#define pair_wait(f, v) pair_wait_knock(f, v, knock_role)
+#endif
 template <int SEGW, int JT, bool SPLIT, bool LOSS = false, bool QUAD = false>
 __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   static_assert(!QUAD || (SEGW == 64 && SPLIT && JT == PD_JT_REVOLUTE), "quad-lane body wave: one env per wave, revolute-only plain models");
@@ -540,6 +557,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   // over all compute units instead of filling a few
   const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);
   const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
+  [[maybe_unused]] const int knock_role = contact_wave ? 1 : 0;
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     if (lane == 0) { sig[0] = 0; sig[1] = 0; }
     __syncthreads();
   }
+  PD_KNOCK_EXIT(true, knock_role);
   if constexpr (QUAD) {
     if (!env_ok) return;  // one env per wave pair: a pair past the batch has nothing to do (no workgroup barrier follows)
   }
@@ -1337,13 +1356,10 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
 // EARLY (SPLIT only): hand-over A is signalled from inside the adjoint of integrate_bodies, as soon as the wrench adjoint
 // exists (integrate_adj2), instead of after it.
 #ifdef PD_KNOCK
-// Timing experiment only (results are wrong): the ADJOINT kernels' waves run through their waits -- PD_KNOCK & 1 the first role's
-// (body / integrate waves), & 2 the second role's (contact / joint waves) -- which gives each role's own instruction stream time.
-PD_DEV int pair_wait_knock(int *flag, int value) {
-  if (PD_KNOCK & (((int)(threadIdx.x >> 6) >= (int)blockDim.x / 128) ? 2 : 1)) return value;
-  return pair_wait(flag, value);
-}
-#define pair_wait pair_wait_knock
+#undef pair_wait
+#if !(PD_KNOCK & 16)
+#define pair_wait(f, v) pair_wait_knock(f, v, knock_role)
+#endif
 #endif
 // QUAD: the body wave in the four-lanes-per-body form (pd_quad.h), one env per wave, 64-lane mapping -- see k_rollout_fwd.
 template <int SEGW, int JT, bool SPLIT, bool EARLY = false, bool QUAD = false>
@@ -1354,6 +1370,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   const int bw = (int)blockDim.x / (QUAD ? 192 : (SPLIT ? 128 : 64));  // env groups per workgroup (host's choice per launch)
   const int role = SPLIT ? (int)(threadIdx.x >> 6) / bw : 0;  // wave-uniform: 0 body wave, 1 contact wave, 2 (QUAD) state wave
   const bool contact_wave = role != 0;
+  [[maybe_unused]] const int knock_role = role;
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
@@ -1382,6 +1399,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
     if (lane == 0 && !contact_wave) { sig[0] = 0; sig[1] = 0; sig[2] = 0; sig[3] = 0; }
     __syncthreads();
   }
+  PD_KNOCK_EXIT(false, knock_role);
   if constexpr (QUAD) {
     if (!env_ok) return;  // one env per wave pair: a pair past the batch has nothing to do (no workgroup barrier follows)
   }
@@ -2115,6 +2133,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
   const int lane = threadIdx.x & 63, wave_id = threadIdx.x >> 6;
   // 0: I (+ contacts when ROLES == 2), 1: C, 2: J   (wave-uniform)
   const int role = ROLES == 3 ? wave_id / bw : (wave_id / bw ? 2 : 0), wave = wave_id % bw;
+  [[maybe_unused]] const int knock_role = role;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
   const bool env_ok = env < a.bs;
@@ -2157,6 +2176,7 @@ __global__ __launch_bounds__(PD_BWD3_BOUNDS(ROLES)) void k_rollout_bwd3(PdDevMod
     }
   }
   __syncthreads();
+  PD_KNOCK_EXIT(false, knock_role);
 
   const size_t idx = (size_t)ec * nb + b;
   const unsigned boff = (unsigned)idx * 4u;  // per-lane byte offset of this body's float

@@ -58,7 +58,16 @@ if wf >= 2 * G:
     report("FWD", "contact wave", r, cn)
     print("FWD contact wave: exact cull redone in %.2f%% of wave-steps; speculated candidates (env 0 of the wave) %.2f per step" % (
         100 * r[:, 13].mean() / T, r[:, 14].mean() / T))
-if wb == 3 * G:  # 3-role adjoint
+if segw == 64 and name == "laikago" and os.environ.get("PD_FAMILY", "") != "1":  # quad-lane adjoint (small batches): body, contact and state wave
+    report("BWD", "body wave (quad)", rows(b_all, 0), [(0, "seeds added"), (1, "integrate adj phase 1 (reverse part) + adjf + signal A"),
+                                                      (5, "g_res_f stores + integrate adj phase 2"),
+                                                      (2, "LDS reads + rev_adjoint"), (7, "rotm adjoint + slots + control-gradient stores"),
+                                                      (3, "child gather"), (9, "look-ahead: seeds / target requested, wait S, the state wave's values taken"),
+                                                      (8, "wait B"), (4, "cacc")])
+    report("BWD", "contact wave", rows(b_all, 1), [(7, "prefetch issue"), (9, "wait at hand-over A"),
+                                                  (10, "contact adjoint per hit"), (11, "per-body sums"), (12, "tail / generic sweep")])
+    print("BWD state wave: not stamped (it runs up to two steps ahead of the other two)")
+elif wb == 3 * G:  # 3-role adjoint
     report("BWD", "integrate wave", rows(b_all, 0), [(0, "top: seeds + unpack + stage"), (1, "integrate adj (phase 1, signal A, phase 2) + g_res_f"),
                                                     (2, "wait J"), (3, "own + child gather"), (4, "wait C + cacc")])
     report("BWD", "contact wave", rows(b_all, 1), [(7, "prefetch issue"), (9, "wait A"), (10, "contact adjoint per hit"), (11, "per-body sums"),
@@ -71,14 +80,6 @@ elif wb == 2 * G and name != "laikago":  # 2-role k_rollout_bwd3: integrate (+ c
                                                     (2, "wait J"), (3, "own + child gather"), (4, "cacc")])
     report("BWD", "joint wave", rows(b_all, 1), [(7, "top: prefetch controls"), (8, "wait S + joint_adj_prep"), (9, "wait A"),
                                                 (10, "joint_adj_apply + slots"), (11, "signal J + control-gradient stores")])
-elif segw == 64 and name == "laikago" and os.environ.get("PD_FAMILY", "") != "1":  # quad-lane adjoint (small batches)
-    report("BWD", "body wave (quad)", rows(b_all, 0), [(0, "seeds added"), (1, "integrate adj phase 1 (reverse part) + adjf + signal A"),
-                                                      (5, "g_res_f stores + integrate adj phase 2"), (6, "wait J (joint hand-over records)"),
-                                                      (2, "LDS reads + rev_adjoint"), (7, "rotm adjoint + slots + control-gradient stores"),
-                                                      (3, "child gather"), (9, "PRE of the next iteration: unpack, prefetch, rotm, stage, forward values"),
-                                                      (8, "wait B"), (4, "cacc")])
-    report("BWD", "contact wave", rows(b_all, 1), [(8, "joint state-only half -> LDS"), (7, "prefetch issue"), (9, "wait at hand-over A"),
-                                                  (10, "contact adjoint per hit"), (11, "per-body sums"), (12, "tail / generic sweep")])
 else:
     report("BWD", "body wave", rows(b_all, 0), [(0, "top: seeds + unpack + prefetch + stage"), (1, "integrate adj + g_res_f + adjf"),
                                                (2, "wait A + joints adj + stores"), (3, "child gather"), (4, "wait B + cacc gather")])
