@@ -378,7 +378,7 @@ def main():
         i = dm.last_launch_info(kind)
         waves, envs = i["threads_per_wg"] // 64, max(1, i["envs_per_wg"])
         if waves >= 2 * envs:
-            return "quad-lane: one env per wave pair"
+            return "quad-lane: one env per %d waves" % (waves // envs)
         epw = 64 // max(1, dm.segment_width())                 # envs per wave of the lane-per-body kernels
         roles = waves * epw // envs                            # waves per env group
         return "lane per body: %d envs per wave, %d wave%s per env group" % (epw, roles, "" if roles == 1 else "s")

@@ -57,6 +57,14 @@ inline int pd_kernel_variant(int kind, int jt, int n_groups, int cu_count) {
   }
   return PD_KV_FK;
 }
+// The forward kernels' cull wave (wave-specialised kernels of revolute-only robots, pd_kernels.hip CULLW) keeps its candidate list and a
+// SHORT tile list in the room the adjoint's wider per-hit slots leave in the shared per-env LDS size: the tile list's capacity in entries
+// (the kernel computes the same from its pointers).  Below PD_CULLW_MIN_CAP the launch stays with two roles.
+#define PD_CULLW_MIN_CAP 48
+inline int pd_fwd_cull_cap(int nb, int segw, int list_cap, int env_lds_floats, int rec, int w6) {
+  const int spec_off = ((4 + rec + 2 * w6) * nb + w6 + 3) & ~3;
+  return env_lds_floats - (spec_off + 8 * nb + 4 + list_cap + 8 * segw + 6 * segw + 8 * segw);
+}
 inline int pd_variant_roles(int kv) {
   return kv == PD_KV_BWD_3ROLE ? 3 : ((kv == PD_KV_FWD_UNSPLIT || kv == PD_KV_BWD_UNSPLIT || kv == PD_KV_FK) ? 1 : 2);
 }

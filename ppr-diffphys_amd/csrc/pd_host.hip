@@ -335,6 +335,11 @@ static PdLaunchCfg launch_cfg(const pd_model *m, int kind, int n_envs, bool loss
   // the branch-free form the other forward kernels of plain models have, and an env must give the same bits whichever kernel runs it
   if (loss && c.kernel == PD_KV_FWD_UNSPLIT) c.kernel = PD_KV_FWD_SPLIT;
   c.roles = pd_variant_roles(c.kernel);
+#ifndef PD_NO_CULLW
+  // revolute-only robots: a third wave per env group runs the speculative contact cull (k_rollout_fwd CULLW)
+  if (c.kernel == PD_KV_FWD_SPLIT && m->jt == PD_JT_REVOLUTE && pd_fwd_cull_cap(d.nb, m->segw, d.list_cap, d.env_lds_floats, PD_REC, PD_W6) >= PD_CULLW_MIN_CAP)
+    c.roles = 3;
+#endif
   c.groups = kind <= PD_K_ROLLOUT_BWD ? (g_groups ? g_groups : pd_groups_per_wg(n_groups, d.cu_count)) : PD_BWAVES;
   c.nblocks = (n_groups + c.groups - 1) / c.groups;
   c.threads = c.roles * c.groups * 64;
@@ -363,9 +368,13 @@ static hipError_t launch(const pd_model *m, int kind, const void *args, int n_en
     const PdDevModel &d = m->quad->dev;
     PdLaunchCfg c{};
     c.kernel = kind == PD_K_ROLLOUT_FWD ? PD_KV_FWD_QUAD : PD_KV_BWD_QUAD;
-    c.roles = kind == PD_K_ROLLOUT_FWD ? 2 : 3;   // adjoint: body, contact and state wave per env
+    c.roles = 3;   // forward: body, contact and cull wave per env; adjoint: body, contact and state wave
+#ifdef PD_NO_CULLW
+    if (kind == PD_K_ROLLOUT_FWD) c.roles = 2;
+#endif
+    if (kind == PD_K_ROLLOUT_FWD && pd_fwd_cull_cap(d.nb, 64, d.list_cap, d.env_lds_floats, PD_REC, PD_W6) < PD_CULLW_MIN_CAP) c.roles = 2;
     c.groups = g_groups ? g_groups : pd_groups_per_wg(n_envs, d.cu_count);
-    if (c.roles == 3 && c.groups > 2) c.groups = 2;   // (three roles: at most 384 threads, two waves per SIMD -- the body wave needs its 256 VGPRs)
+    if (kind == PD_K_ROLLOUT_BWD && c.groups > 2) c.groups = 2;   // (three roles: at most 384 threads, two waves per SIMD -- the body wave needs its 256 VGPRs)
     c.nblocks = (n_envs + c.groups - 1) / c.groups;
     c.threads = c.roles * c.groups * 64;
     c.lds = kind == PD_K_ROLLOUT_FWD ? m->quad->lds_tables + (size_t)c.groups * d.env_lds_floats * 4   // contact tables in LDS

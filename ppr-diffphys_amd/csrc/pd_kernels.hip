@@ -273,9 +273,10 @@ PD_DEV void sweep_flush_batch(const SweepTables &T, const float *rec, const int 
 // L1 + L2 of the sweep: fills list[] with the packed tiles that may hold a hit and returns their count (per env).
 // cv / cull may be the exact cull vectors of the state, or -- speculative pre-cull of the NEXT state, wave-specialised
 // forward kernel -- vectors whose height is lowered by a verified bound on the body's motion (see k_rollout_fwd).
+// cap: capacity of list[] per env (the cull wave's short list; the count returned may exceed it: the caller then drops the cull)
 template <int SEGW>
 PD_DEV int sweep_cull(const PdDevModel &m, const SweepTables &T, const BodyConst &c, float4 cv, const float4 *cull, int *list,
-                      bool is_body, int seg, int l STAMP_ARGS) {
+                      bool is_body, int seg, int l STAMP_ARGS, int cap = 0x7fffffff) {
   if (m.nc == 0) return 0;
   const bool surv = is_body && c.sphere.w >= 0.0f && !cull_above(cv, c.sphere);
   const unsigned long long wave_any = __ballot(surv);
@@ -296,7 +297,7 @@ PD_DEV int sweep_cull(const PdDevModel &m, const SweepTables &T, const BodyConst
         pass = !cull_above_box(cull[e >> 16], T.tlo[e & 0xffff], T.thi[e & 0xffff]);
       }
       int s = seg_slot(pass, sm, nlist);
-      if (pass) list[s] = pk;
+      if (pass && s < cap) list[s] = pk;
     }
   }
   // ---- L2, big bodies (rarely survive L1): the segment's lanes share one body's tiles
@@ -319,7 +320,7 @@ PD_DEV int sweep_cull(const PdDevModel &m, const SweepTables &T, const BodyConst
         pass = !cull_above_box(cb, T.tlo[t_first + t], T.thi[t_first + t]);
       }
       int s = seg_slot(pass, sm, nlist);
-      if (pass) list[s] = pk;
+      if (pass && s < cap) list[s] = pk;
     }
   }
   STAMP(9);
@@ -488,10 +489,11 @@ PD_DEV void sweep_contacts(const PdDevModel &m, const SweepTables &T, const Body
 // margin then: more exact sweeps, the same results)
 #define PD_SPEC_SAFETY_TIGHT 1.25f
 #define PD_SPEC_SLACK_TIGHT 1.0e-4f
-template <int JT>
+// STEPS: how many steps the margin must hold for (PD_SPEC_K; one more when a cull wave delivers the candidates a step later)
+template <int JT, int STEPS = PD_SPEC_K>
 PD_DEV float sink_margin(const PdDevModel &m, const BodyConst &c, const BodyState &s, float dt) {
   const float safety = JT == PD_JT_REVOLUTE ? PD_SPEC_SAFETY_TIGHT : m.spec_safety, slack = JT == PD_JT_REVOLUTE ? PD_SPEC_SLACK_TIGHT : m.spec_slack;
-  return (float)PD_SPEC_K * (safety * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + slack);
+  return (float)STEPS * (safety * dt * (fabsf(s.v.y) + (fabsf(s.w.x) + fabsf(s.w.y) + fabsf(s.w.z)) * c.reach) + slack);
 }
 
 // Copies the contact tables into LDS (once per workgroup) and returns the per-env scratch base.  COPY = false leaves
@@ -547,17 +549,19 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 #if defined(PD_KNOCK) && (PD_KNOCK & 16)
 #define pair_wait(f, v) pair_wait_knock(f, v, knock_role)
 #endif
-template <int SEGW, int JT, bool SPLIT, bool LOSS = false, bool QUAD = false>
-__global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
+template <int SEGW, int JT, bool SPLIT, bool LOSS = false, bool QUAD = false, bool CULLW = false>
+__global__ __launch_bounds__(CULLW ? PD_BLOCK3 : (SPLIT ? PD_BLOCK : PD_FK_BLOCK), CULLW ? 3 : 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   static_assert(!QUAD || (SEGW == 64 && SPLIT && JT == PD_JT_REVOLUTE), "quad-lane body wave: one env per wave, revolute-only plain models");
+  static_assert(!CULLW || (SPLIT && JT == PD_JT_REVOLUTE), "cull wave: wave-specialised kernels of revolute-only robots (<= 168 VGPRs: three waves per SIMD)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EPW = Seg<SEGW>::EPW;
   constexpr int ND = (JT & PD_JT_COMPOUND) ? 3 : 1;
   // env groups (= body waves) per workgroup: chosen by the host per launch (1 .. PD_BWAVES) so that small batches spread
   // over all compute units instead of filling a few
-  const int bw = (int)blockDim.x / (SPLIT ? 128 : 64);
-  const bool contact_wave = SPLIT && (int)(threadIdx.x >> 6) >= bw;  // wave-uniform role
-  [[maybe_unused]] const int knock_role = contact_wave ? 1 : 0;
+  const int bw = (int)blockDim.x / (CULLW ? 192 : (SPLIT ? 128 : 64));
+  const int role = SPLIT ? (int)(threadIdx.x >> 6) / bw : 0;  // wave-uniform: 0 body wave, 1 contact wave, 2 (CULLW) cull wave
+  const bool contact_wave = role != 0;
+  [[maybe_unused]] const int knock_role = role;
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % bw;
   const int seg = lane / SEGW, l = lane % SEGW;
   const int env = (blockIdx.x * bw + wave) * EPW + seg;
@@ -577,11 +581,15 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   const int spec_off = ((4 + PD_REC + 2 * PD_W6) * nb + PD_W6 + 3) & ~3;  // 16-byte aligned like cull
   float4 *spec = (float4 *)(scratch + spec_off);
   int *spec_bad = (int *)(scratch + spec_off + 8 * nb);  // 4 words: [0] unused, [1..2] of the wave's first env = pair signals
-  int *sig = (int *)(scratch - (size_t)seg * m.env_lds_floats + spec_off + 8 * nb) + 1;  // pair signals: words 1, 2 after the first env's flag
+  int *sig = (int *)(scratch - (size_t)seg * m.env_lds_floats + spec_off + 8 * nb) + 1;  // pair signals: words 1, 2 (, 3) after the first env's flag
   int *list = spec_bad + 4, *hits = list + m.list_cap;
   float *slot = (float *)(hits + PD_HIT_CAP_TILES * SEGW);
+  // CULLW: the cull wave's own candidate list and (short) tile list, in the room the adjoint kernel's wider per-hit slots leave in the
+  // shared per-env size (the forward pass sums six floats per hit, the adjoint thirteen); spec_bad[0] of an env = its candidate count
+  int *hits2 = (int *)(slot + 6 * SEGW), *list2 = hits2 + PD_HIT_CAP_TILES * SEGW;
+  const int cap2 = m.env_lds_floats - (int)((float *)list2 - scratch);
   if (SPLIT) {
-    if (lane == 0) { sig[0] = 0; sig[1] = 0; }
+    if (lane == 0) { sig[0] = 0; sig[1] = 0; sig[2] = 0; }
     __syncthreads();
   }
   PD_KNOCK_EXIT(true, knock_role);
@@ -599,6 +607,36 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     out[3] = touching ? -o.f.x : 0.f; out[4] = touching ? -o.f.y : 0.f; out[5] = touching ? -o.f.z : 0.f;
     return touching;
   };
+  if constexpr (CULLW) {
+    if (role == 2) {
+      // ---- cull wave (round 6).  The speculative cull of an epoch costs 3 600-4 200 cycles; on the contact wave it began after hand-over
+      // B of the epoch's first step and overran the next hand-over A by ~2 400 cycles (Laikago 4096: the hit pass of the epoch's second
+      // step started that late; with the culls taken out -- a timing build, wrong results -- the forward pass took 0.162-0.172 ms against
+      // 0.203, the quad-lane one 0.115 against 0.135).  Here it has a wave of its own and TWO steps: it culls with the vectors of state
+      // e K (staged before hand-over A of that step, margins for PD_SPEC_K + 1 steps) and the contact wave takes the candidates over
+      // after hand-over B of step e K + 1, for the hit passes of steps e K + 2 .. e K + K + 1.  One generation of hits2 / list2: the next
+      // cull starts behind hand-over A of step (e + 1) K, which the body wave signals after B of step e K + 2 at the earliest.
+      STAMP_DECL;
+      for (int e = 0; e * PD_SPEC_K + 2 < a.nsteps; ++e) {
+        pair_wait(sig, e * PD_SPEC_K + 1);
+        STAMP(7);
+        const float4 *sp = spec + (e & 1) * nb;
+        float4 cv = make_float4(0.f, 0.f, 1.f, 0.f);
+        if (is_body) cv = sp[b];
+        const int nlist = sweep_cull<SEGW>(m, tabs, c, cv, sp, list2, is_body, seg, l STAMP_PASS, cap2);
+        int nh2 = 0;
+        bool ok = __ballot(nlist > cap2) == 0ull;   // (a tile list that did not fit: no candidates this epoch, the contact wave sweeps exactly)
+        if (ok) ok = sweep_l3_spec<SEGW>(tabs, sp, list2, nlist, hits2, seg, l, nh2);
+        if (l == 0) spec_bad[0] = nh2;
+        STAMP(10);
+        STAMP_COUNT(13, ok ? 0 : 1);
+        STAMP_COUNT(14, __shfl(nlist, 0));
+        pair_signal(sig + 2, (e + 1) | (ok ? 0 : PD_SIG_FLAG));  // C: the candidates of epoch e
+      }
+      STAMP_FLUSH(a);
+      return;
+    }
+  }
   if (SPLIT && contact_wave) {
     // ---- contact wave: eval_body_contacts for the partner body wave's envs, between hand-overs A and B of each step.
     // The cull (L1-L3) is SPECULATED, once per epoch of PD_SPEC_K steps, in the wait for the body wave's integration:
@@ -629,7 +667,11 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       const int sigA = pair_wait(sig, step + 1);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for this hit pass
       STAMP(7);
+#ifdef PD_ALWAYS_REDO   // (checking build: the exact sweep every step -- the speculated passes must give the same bits)
+      const bool redo = true;
+#else
       const bool redo = !have || (sigA & PD_SIG_FLAG) != 0;  // wave-uniform
+#endif
       STAMP_COUNT(13, redo ? 1 : 0);
       STAMP_COUNT(14, __shfl(nh, 0));
       int log_n = 0;
@@ -687,7 +729,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       }
       STAMP(12);
       pair_signal(sig + 1, step + 1);  // B: contact wrenches are complete
-      const bool cull_now = step % PD_SPEC_K == 0 && step + 1 < a.nsteps;  // state `step` opened an epoch: cull for the steps it serves
+      const bool cull_now = !CULLW && step % PD_SPEC_K == 0 && step + 1 < a.nsteps;  // state `step` opened an epoch: cull for the steps it serves
       if (!cull_now) __builtin_amdgcn_s_setprio(0);  // (the cull stays urgent: the next hit pass needs its candidates)
       // the adjoint's log is written off the critical path
       if (redo) {
@@ -702,6 +744,26 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
         if (l == 0 && env_ok) lg[0] = log_n < PD_HITLOG ? log_n : -1;
       }
       if (redo) lane_owns = false;
+      if (CULLW && step % PD_SPEC_K == 1 && step + 1 < a.nsteps) {
+        // the cull wave's candidates of the epoch that opened with state step - 1: they serve the hit passes of steps step + 1 .. step + K
+        WAVE_SYNC();  // the log is read out of hits[] before candidates may overwrite it
+        const int sigC = pair_wait(sig + 2, step / PD_SPEC_K + 1);
+        have = (sigC & PD_SIG_FLAG) == 0;
+        nh = have ? spec_bad[0] : 0;
+        lane_owns = have && __ballot(nh > 2 * SEGW) == 0ull;
+        two = lane_owns && __ballot(nh > SEGW) != 0ull;
+        if (lane_owns) {
+          c_e = l < nh ? hits2[l] : 0;
+          c_P = tabs.pts[c_e & 0xffff]; c_M = tabs.mats[(c_e >> 16) & 0xff];
+          if (two) {
+            c_e2 = SEGW + l < nh ? hits2[SEGW + l] : 0;
+            c_P2 = tabs.pts[c_e2 & 0xffff]; c_M2 = tabs.mats[(c_e2 >> 16) & 0xff];
+          }
+        } else if (have) {  // more candidates than two per lane somewhere: they stay a list, in this wave's own buffer
+          for (int j = l; j < nh; j += SEGW) hits[j] = hits2[j];
+          WAVE_SYNC();
+        }
+      }
       if (cull_now) {
         WAVE_SYNC();  // the log is read out of hits[] before the candidates overwrite it
         const float4 *sp = spec + ((step / PD_SPEC_K) & 1) * nb;
@@ -790,7 +852,7 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     q_rotm(k, s.r, Rr, Rc);
     float rc = q_mvc(Rr, B.com0, B.com1, B.com2);
     auto q_margin = [&](const QState &x) {  // sink_margin (the speculative contact cull), all four lanes
-      return (float)PD_SPEC_K * (PD_SPEC_SAFETY_TIGHT * a.dt * (Q_BC1(fabsf(x.v)) + q_sum3(fabsf(x.w)) * B.reach) + PD_SPEC_SLACK_TIGHT);  // (quad-lane: revolute-only)
+      return (float)(CULLW ? PD_SPEC_K + 1 : PD_SPEC_K) * (PD_SPEC_SAFETY_TIGHT * a.dt * (Q_BC1(fabsf(x.v)) + q_sum3(fabsf(x.w)) * B.reach) + PD_SPEC_SLACK_TIGHT);  // (quad-lane: revolute-only)
     };
     // staging: the record fields are contiguous vectors, lane c writes component c of each; the cull vector (p_y, row 1 of rotm) is
     // lane 1's: its own p and its row
@@ -808,6 +870,9 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     float margin = q_margin(s), sunk = 0.f;
     WAVE_SYNC();  // every lane has read the FK records
     q_stage(s, rc, Rr, margin, spec);  // epoch 0
+    // (CULLW, see the lane-per-body form: the pair in use and the pair staged; nothing is in use before state 2)
+    [[maybe_unused]] float margin_n = margin, sunk_n = 0.f;
+    if (CULLW) margin = __builtin_inff();
     bool spec_failed = true;
     // controls one step ahead; the trajectory planes are float4 per body: lane c owns float c of each
     const unsigned boff_qd = (unsigned)((size_t)ec * m.nqd + B.qdstart) * 4u, boff_rf = (unsigned)(qidx * 6 + qv) * 4u;
@@ -947,14 +1012,23 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
       STAMP(4);
       {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
         sunk += sink * a.dt;
+        if (CULLW) sunk_n += sink * a.dt;
         const bool bad = B.sphere_w >= 0.0f && !(sunk <= 0.98f * margin);
         spec_failed = __ballot(bad) != 0ull;
+        if constexpr (CULLW) {
+          const bool rot = step % PD_SPEC_K == 0;
+          margin = rot ? margin_n : margin; sunk = rot ? sunk_n : sunk;
+        }
       }
       WAVE_SYNC();
       {
         const bool epoch = (step + 1) % PD_SPEC_K == 0;  // state step+1 opens a speculation epoch
-        if (epoch) { margin = q_margin(s); sunk = 0.f; }
-        q_stage(s, rc, Rr, margin, epoch ? spec + (((step + 1) / PD_SPEC_K) & 1) * nb : nullptr);
+        float lower = margin;
+        if (epoch) {
+          lower = q_margin(s);
+          if (CULLW) { margin_n = lower; sunk_n = 0.f; } else { margin = lower; sunk = 0.f; }
+        }
+        q_stage(s, rc, Rr, lower, epoch ? spec + (((step + 1) / PD_SPEC_K) & 1) * nb : nullptr);
       }
       STAMP(5);
     }
@@ -1029,14 +1103,19 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
   v3 rc = V3(0, 0, 0);  // Rm com of the current state, shared by staging, joints and integration
   float margin = 0.f, sunk = 0.f;  // speculative contact cull: allowed / integrated loss of height since the epoch's state
   float margin98 = __builtin_inff();
+  // CULLW: the candidates of the epoch that opens with state S serve states S + 2 .. S + K + 1 (the cull wave has two steps), so an epoch's
+  // bound and sum run beside its predecessor's for one step: (margin98, sunk) is the pair in use, (margin98_n, sunk_n) the one staged
+  constexpr int SPEC_STEPS = CULLW ? PD_SPEC_K + 1 : PD_SPEC_K;
+  [[maybe_unused]] float margin98_n = __builtin_inff(), sunk_n = 0.f;
   for (int d = 0; d <= m.max_depth; ++d) {
     if (wr && c.depth == d) {
       s = fk_joint<JT>(c, a.q_init + (size_t)ec * m.nq + c.qstart, a.qd_init + (size_t)ec * m.nqd + c.qdstart, rec);
       rotm(s.r, Rm);
       rc = mat_vec(Rm, c.com);
       float4 cv = stage_record(rec, cull, b, s, rc, Rm);
-      margin = sink_margin<JT>(m, c, s, a.dt);
-      margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
+      margin = sink_margin<JT, SPEC_STEPS>(m, c, s, a.dt);
+      if (CULLW) margin98_n = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
+      else margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
       cv.x -= margin;
       if (SPLIT) spec[b] = cv;  // epoch 0
     }
@@ -1303,16 +1382,22 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK, 2) void k_rollout_f
     STAMP(4);
     {  // did every body stay inside the margin the cull speculated with?  (NaN counts as "no")
       sunk += sink_rate * a.dt;
+      if (CULLW) sunk_n += sink_rate * a.dt;
       // CLONE: one compare -- the bound carries "has candidates at all" (+inf otherwise) and the factor, set where the margin is
       const bool bad = CLONE ? !(sunk <= margin98) : (wr && c.sphere.w >= 0.0f && !(sunk <= 0.98f * margin));
       spec_failed = __ballot(bad) != 0ull;
+      if constexpr (CULLW) {  // state step + 1 was the last one of the previous epoch's (selects: a branch here would end the basic block the
+        const bool rot = step % PD_SPEC_K == 0;  // compiler contracts multiply-adds in, and the poses' last bits with it)
+        margin98 = rot ? margin98_n : margin98; sunk = rot ? sunk_n : sunk;
+      }
     }
     WAVE_SYNC();
     if (wr) {
       float4 cv = stage_record(rec, cull, b, s, rc, Rm);
       if (SPLIT && (step + 1) % PD_SPEC_K == 0) {  // state step+1 opens a speculation epoch
-        margin = sink_margin<JT>(m, c, s, a.dt); sunk = 0.f;
-        margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff();
+        margin = sink_margin<JT, SPEC_STEPS>(m, c, s, a.dt);
+        if (CULLW) { sunk_n = 0.f; margin98_n = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff(); }
+        else { sunk = 0.f; margin98 = c.sphere.w >= 0.0f ? 0.98f * margin : __builtin_inff(); }
         cv.x -= margin;
         spec[(((step + 1) / PD_SPEC_K) & 1) * nb + b] = cv;
       }
@@ -2724,10 +2809,23 @@ static hipError_t launch_jt(int kind, const PdDevModel &m, const void *args, con
     case PD_K_ROLLOUT_FWD:
       if (cfg.kernel == PD_KV_FWD_QUAD) {
         if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
-          if (((const RolloutArgs *)args)->loss_target)
-            hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
-          else
-            hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          const bool loss = ((const RolloutArgs *)args)->loss_target != nullptr;
+          if (cfg.roles == 3) {  // with the cull wave
+            if (loss) hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+            else hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          } else {
+            if (loss) hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+            else hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          }
+          break;
+        } else {
+          return hipErrorInvalidValue;
+        }
+      }
+      if (cfg.roles == 3) {  // wave-specialised forward with the cull wave (revolute-only robots)
+        if constexpr (JT == PD_JT_REVOLUTE) {
+          if (((const RolloutArgs *)args)->loss_target) hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, true, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
+          else hipLaunchKernelGGL((k_rollout_fwd<PD_SEGW, JT, true, false, false, true>), g, t, lds, st, m, *(const RolloutArgs *)args);
           break;
         } else {
           return hipErrorInvalidValue;
@@ -2785,6 +2883,14 @@ static hipError_t set_lds_jt(int bytes) {
   if constexpr (PD_SEGW == 64 && JT == PD_JT_REVOLUTE) {
     if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
     if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+  }
+  if constexpr (JT == PD_JT_REVOLUTE) {  // ... with the cull wave
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    if constexpr (PD_SEGW == 64) {
+      if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+      if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+    }
   }
   if ((e = hipFuncSetAttribute((const void *)k_rollout_fwd<PD_SEGW, JT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
   if constexpr (pd_split(JT)) {

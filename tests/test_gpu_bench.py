@@ -55,7 +55,8 @@ def test_bench_line_contract_and_consistency():
     else:
         assert r["valu"] is None and f["valu"] is None and r["traffic"] is None and "another build" in r["traffic_source"], r["traffic_source"]
         assert r["secondary"]["valu_busy"] is None and r["secondary"]["wave_wait_share"] is None
-    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["envs"] == 4096 and d["per_rank"][0]["fwd_family"].startswith("lane per body: 4 envs per wave, 2 waves")
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["envs"] == 4096 and d["per_rank"][0]["fwd_family"].startswith("lane per body: 4 envs per wave, 3 waves")   # body, contact and cull wave
+    assert d["per_rank"][0]["bwd_family"].startswith("lane per body: 4 envs per wave, 2 waves")
     assert abs(d["per_rank"][0]["ms_per_step"] - d["ms_per_step"]) < 1e-9   # one rank: its own clock IS the line's
     assert d["collective_backend"] is None and d["ranks_seen"] == 1 and d["launcher"] == "none"
     assert len(d["devices_seen"]) == 1 and d["devices_distinct"] == 1 and d["devices_seen"][0]["index"] == 0

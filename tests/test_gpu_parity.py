@@ -1042,7 +1042,7 @@ def test_revolute_tree_with_six_children_on_the_root(family, dev, oracle_libs):
     dm.set_kernel_family(family)
     out = gpu_rollout(dm, inp, dev)
     info = dm.last_launch_info(0)
-    assert info["envs_per_wg"] * 128 // info["threads_per_wg"] == (1 if family == 2 else 4)   # envs per wave pair: which family ran
+    assert info["envs_per_wg"] * 192 // info["threads_per_wg"] == (1 if family == 2 else 4)   # envs per wave triple (body, contact, cull): which family ran
     rc = RefC(tpl, np.float32)
     st = rc.rollout_forward(inp, T, inp["frame2step"], inp["dt"])
     gr = rc.rollout_backward(st, inp["adj_pos"], inp["adj_vel"])
@@ -1258,7 +1258,7 @@ def test_mixed_families_between_the_two_thresholds(dev, oracle_libs):
     info_f = dm.last_launch_info(0)
     g_auto = bwd(auto[4])
     info_b = dm.last_launch_info(1)
-    assert info_f["envs_per_wg"] * 128 // info_f["threads_per_wg"] == 1 and info_b["envs_per_wg"] * 128 // info_b["threads_per_wg"] == 4
+    assert info_f["envs_per_wg"] * 192 // info_f["threads_per_wg"] == 1 and info_b["envs_per_wg"] * 128 // info_b["threads_per_wg"] == 4   # (forward: body, contact, cull wave)
     dm.set_kernel_family(2)
     q = fwd()
     assert all(torch.equal(a, b) for a, b in zip(auto[:4], q[:4]))
