@@ -508,8 +508,8 @@ def main():
                 "bound": "valu-issue",
                 "hbm_frac": ach_bwd / HBM_PEAK_BYTES,
                 "limiter": "fp32 VALU issue: a SIMD issues one non-packed wave64 fp32 instruction per ~4.2 cycles whatever the waves or "
-                           "their ILP; the adjoint's two waves per SIMD keep it ~95 % busy (roofline.valu; the forward pass ~53 %: hand-over "
-                           "latency).  frac of HBM is what the contract asks for",
+                           "their ILP; the adjoint's two waves per SIMD keep it ~95 % busy (roofline.valu; the forward pass, three waves per SIMD -- "
+                           "body, contact, cull -- ~56 %: the step's chain crosses two hand-overs).  frac of HBM is what the contract asks for",
                 "valu": valu_roofline(pb, bwd_ms),
                 "kernel": "k_rollout_bwd",
                 "achieved": ach_bwd / 1e9,
@@ -534,7 +534,7 @@ def main():
                 "fwd_kernel": {"kernel": "k_rollout_fwd", "achieved": ach_fwd / 1e9, "frac": ach_fwd / HBM_PEAK_BYTES,
                                "frac_of_achievable": ach_fwd / HBM_ACHIEVABLE_BYTES, "avg_launch_ms": fwd_ms,
                                "algorithmic_bytes_per_env_step": bf, "secondary": secondary(geo_f, pf), "valu": valu_roofline(pf, fwd_ms)},
-                "note": "VALU-issue bound (adjoint) / hand-over-latency bound (forward), not HBM-bound (roofline.valu, roofline.secondary, "
+                "note": "VALU-issue bound (adjoint) / hand-over chain of three waves sharing a SIMD's issue slots (forward), not HBM-bound (roofline.valu, roofline.secondary, "
                         "DESIGN.md section 4); launch durations are per dispatch, measured on launches enqueued back to back like the timed region",
             },
         }

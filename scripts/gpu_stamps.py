@@ -58,6 +58,12 @@ if wf >= 2 * G:
     report("FWD", "contact wave", r, cn)
     print("FWD contact wave: exact cull redone in %.2f%% of wave-steps; speculated candidates (env 0 of the wave) %.2f per step" % (
         100 * r[:, 13].mean() / T, r[:, 14].mean() / T))
+if wf >= 3 * G:  # forward with the cull wave (revolute-only robots): per-step averages of work done once per epoch of 4 steps
+    r = rows(f_all, 2)
+    report("FWD", "cull wave", r, [(7, "wait for the epoch's vectors (hand-over A of step e K)"), (8, "L1 body cull"), (9, "L2 tile cull"),
+                                  (10, "L3 point cull -> candidate list, hand-over C")])
+    print("FWD cull wave: culls dropped (tile list over its capacity) %.0f of %.0f; tiles after L2 (env 0 of the wave) %.1f per cull" % (
+        r[:, 13].sum(), len(r) * max(1, (T - 2 + 3) // 4), r[:, 14].mean() / max(1, (T - 2 + 3) // 4)))
 if segw == 64 and name == "laikago" and os.environ.get("PD_FAMILY", "") != "1":  # quad-lane adjoint (small batches): body, contact and state wave
     report("BWD", "body wave (quad)", rows(b_all, 0), [(0, "seeds added"), (1, "integrate adj phase 1 (reverse part) + adjf + signal A"),
                                                       (5, "g_res_f stores + integrate adj phase 2"),
