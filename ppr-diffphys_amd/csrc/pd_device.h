@@ -431,6 +431,79 @@ PD_DEV bool contact_point_adj(const float *r, float4 cv, float4 P, float4 mat, v
   return true;
 }
 
+// contact_point_adj (quaternion form) in two pieces for the adjoint kernels' contact wave (round 6): everything the hit's adjoint needs of
+// the STATE -- the forward pass's quantities again -- is computed when the body's record is staged, before the wrench adjoints exist
+// (hand-over A); the reverse sweep follows them.  contact_pre_barrier pins the values at the seam so that the same instructions come out
+// wherever the two pieces are called (back to back in the generic sweep, around the wait in the fast path).
+struct ContactPre { bool touch, a_lt_b; v3 rr, fc, f_raw, nvt, vt, w, com; qt q; float mm, vn, stepc; };
+PD_DEV ContactPre contact_point_adj_pre(const float *r, float4 cv, float4 P, float4 mat) {
+  ContactPre C;
+  const v3 p = ld3(r), v = ld3(r + 10), rc = ld3(r + 13);
+  C.w = ld3(r + 7);
+  C.q = ld4(r + 3);
+  const v3 cpt = V3(P.x, P.y, P.z);
+  C.com = qrot_inv(C.q, rc);
+  v3 cp = (p + qrot(C.q, cpt)) - V3(0.f, P.w, 0.f);
+  cp.y = contact_height(cv, P);
+  const float c = cp.y;
+  C.touch = !(c > 0.0f);
+  C.rr = cp - (p + rc);
+  const v3 dpdt = v + cross(C.w, C.rr);
+  const float ke = mat.x, kd = mat.y, kf = mat.z, mu = mat.w;
+  C.vn = dpdt.y;
+  C.vt = V3(dpdt.x, dpdt.y - C.vn, dpdt.z);
+  const float fn = c * ke;
+  C.stepc = c < 0.0f ? 1.0f : 0.0f;
+  const float fd = fminf(C.vn, 0.0f) * kd * C.stepc;
+  const float lvt = length(C.vt);
+  C.nvt = normalize(C.vt);
+  const float a_ = kf * lvt, b_ = 0.0f - mu * (fn + fd);
+  C.a_lt_b = a_ < b_;
+  C.mm = C.a_lt_b ? a_ : b_;
+  C.f_raw = V3(C.nvt.x * C.mm, (fn + fd) + C.nvt.y * C.mm, C.nvt.z * C.mm);
+  C.fc = clamp3(C.f_raw, 500.0f);
+  return C;
+}
+#define PD_PIN_(x) asm volatile("" : "+v"(x))
+#define PD_PIN3_(a) do { PD_PIN_((a).x); PD_PIN_((a).y); PD_PIN_((a).z); } while (0)
+PD_DEV void contact_pre_barrier(ContactPre &C) {
+  PD_PIN3_(C.rr); PD_PIN3_(C.fc); PD_PIN3_(C.f_raw); PD_PIN3_(C.nvt); PD_PIN3_(C.vt); PD_PIN3_(C.w); PD_PIN3_(C.com);
+  PD_PIN_(C.q.x); PD_PIN_(C.q.y); PD_PIN_(C.q.z); PD_PIN_(C.q.w); PD_PIN_(C.mm); PD_PIN_(C.vn); PD_PIN_(C.stepc);
+}
+PD_DEV bool contact_point_adj_rest(const ContactPre &C, float4 P, float4 mat, v3 g_t, v3 g_f, BodyAdj &out) {
+  if (!C.touch) return false;
+  const v3 cpt = V3(P.x, P.y, P.z);
+  const float ke = mat.x, kd = mat.y, kf = mat.z, mu = mat.w;
+  // reverse (body_f -= (t, f))
+  v3 adj_t = -g_t, adj_fc = -g_f, adj_r = V3(0, 0, 0);
+  adj_cross(C.rr, C.fc, adj_r, adj_fc, adj_t);
+  v3 adj_fr = clamp3_pass(C.f_raw, adj_fc, 500.0f);
+  float adj_fnfd = adj_fr.y;
+  v3 adj_nvt = adj_fr * C.mm;
+  float adj_m = dot(adj_fr, C.nvt);
+  float adj_lvt = 0.f;
+  if (C.a_lt_b) adj_lvt = adj_m * kf; else adj_fnfd += -mu * adj_m;
+  v3 adj_vt = V3(0, 0, 0);
+  adj_normalize(C.vt, adj_vt, adj_nvt);
+  adj_length(C.vt, adj_vt, adj_lvt);
+  float adj_c = adj_fnfd * ke;
+  float adj_vn = (C.vn < 0.0f ? 1.0f : 0.0f) * kd * C.stepc * adj_fnfd;
+  v3 adj_dpdt = adj_vt;
+  adj_vn += -adj_vt.y;
+  adj_dpdt.y += adj_vn;
+  v3 adj_w = V3(0, 0, 0);
+  adj_cross(C.w, C.rr, adj_w, adj_r, adj_dpdt);
+  v3 adj_cp = V3(adj_r.x, adj_r.y + adj_c, adj_r.z);
+  qt adj_q = Q4(0, 0, 0, 0);
+  adj_qrot_q(C.q, C.com, adj_q, -adj_r);
+  adj_qrot_q(C.q, cpt, adj_q, adj_cp);
+  out.p = adj_cp - adj_r;
+  out.r = adj_q;
+  out.w = adj_w;
+  out.v = adj_dpdt;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Joint PD + attachment forces for joint i == child body i (integrator_euler.py:289-451).
 PD_DEV float joint_force(float q, float qd, float target, float ke, float kd, float act, float lo, float up, float lke,

@@ -1505,7 +1505,13 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
   auto contact_hit = [&](const float *r, float4 P, float4 mat, float *out) {
     const int pb = (int)(r - rec_s) / PD_REC;
     BodyAdj o = adj_zero();
-    contact_point_adj(r, cull_s[pb], P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    if constexpr (QUAD) {  // the two pieces of contact_point_adj, as the quad-lane kernel's contact wave runs them on its fast path
+      ContactPre C = contact_point_adj_pre(r, cull_s[pb], P, mat);
+      contact_pre_barrier(C);
+      contact_point_adj_rest(C, P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    } else {
+      contact_point_adj(r, cull_s[pb], P, mat, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+    }
     adj_store(out, o);
   };
   if (SPLIT && contact_wave) {
@@ -1657,21 +1663,38 @@ __global__ __launch_bounds__(SPLIT ? PD_BLOCK : PD_FK_BLOCK) void k_rollout_bwd(
       const bool fast = __ballot(env_ok && (cnt_c < 0 || cnt_c > SEGW)) == 0ull;  // wave-uniform
       const int nh = fast && env_ok ? cnt_c : 0;
       STAMP(7);
-      // A: this step's hand-over records are published; wait for the records, cull vectors and wrench adjoints (adjf)
-      if constexpr (!QUAD) pair_signal(sig + 1, a.nsteps - step);
+      if constexpr (!QUAD) pair_signal(sig + 1, a.nsteps - step);   // J: this step's joint hand-over records
+      // Round 6, quad-lane kernel: the STATE half of the logged hits' adjoints (contact_point_adj_pre: the forward pass's quantities again) runs
+      // as soon as the state wave has staged the step's records (hand-over S) instead of behind the wrench adjoints (hand-over A): that much
+      // less stands between A and B (adjoint 0.177 -> 0.168 ms at 512 envs).  The lane-per-body kernel keeps both halves behind A: with a
+      // hand-over R of its body wave right behind the staging, the early half took issue slots from that wave's phase 1 (4096 envs: 0.268 -> 0.273)
+      const int pb = l < nh ? (e_c >> 24) & 0x3f : -2;
+      ContactPre cpre;
+      cpre.touch = false;
+      if constexpr (QUAD) {
+        pair_wait(sig + 1, a.nsteps - step);
+        rec_s = qgen + g3 * qgen_floats + 4 * nb;
+        cull_s = (const float4 *)(qgen + g3 * qgen_floats);
+        if (fast && l < nh) cpre = contact_point_adj_pre(rec_s + pb * PD_REC, cull_s[pb], P_c, M_c);
+      }
+      // A: wait for the wrench adjoints (adjf; lane-per-body kernel: and the records, cull vectors)
       pair_wait(sig, a.nsteps - step);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for these contact adjoints
       STAMP(9);
-      if constexpr (QUAD) {
-        rec_s = qgen + g3 * qgen_floats + 4 * nb;
-        cull_s = (const float4 *)(qgen + g3 * qgen_floats);
-      }
       if (fast) {
         float out[PD_ADJ];
 #pragma unroll
         for (int i = 0; i < PD_ADJ; ++i) out[i] = 0.f;
-        const int pb = l < nh ? (e_c >> 24) & 0x3f : -2;
-        if (l < nh) contact_hit(rec_s + pb * PD_REC, P_c, M_c, out);
+        if constexpr (QUAD) {
+          if (l < nh) {
+            BodyAdj o = adj_zero();
+            contact_pre_barrier(cpre);
+            contact_point_adj_rest(cpre, P_c, M_c, ld3(adjf + pb * PD_W6), ld3(adjf + pb * PD_W6 + 3), o);
+            adj_store(out, o);
+          }
+        } else {
+          if (l < nh) contact_hit(rec_s + pb * PD_REC, P_c, M_c, out);
+        }
         STAMP(10);
         bool last;
         seg_run_sum<PD_ADJ>(out, pb, l, nh, last);
