@@ -474,6 +474,53 @@ def test_against_frozen_bits(name, dev):
                     assert d < 1e-3, (tag, which, k, d)
 
 
+@pytest.mark.parametrize("family", [1, 2], ids=["lane-per-body", "quad-lane"])
+def test_long_horizon_hit_log_is_complete(family, dev, oracle_libs):
+    """Round 6: the speculative contact cull of revolute-only robots runs on a wave of its own, a step earlier and for one step more
+    (csrc/pd_kernels.hip CULLW), with two overlapping epochs validated by the body wave.  Over the reference's window length (760 steps =
+    190 epochs; main.py:86) and with robots dropped / kicked into the ground, every candidate that touches by the restated pinned fp32
+    height test on the kernel's OWN stored states must be in the hit log the forward pass wrote for that env-step -- a contact the
+    speculation missed would be missing there (and its force from every later state).  Both kernel families."""
+    import torch
+
+    from helpers import INPUT_NAMES
+    from diffphys_amd import hip_backend, robots, synth
+    from oracle.ref_c import RefC
+
+    tpl = robots.load_template("laikago")
+    bs, T = 48, 760
+    inp = synth.make_inputs(tpl, "laikago", bs=bs, nsteps=T, seed=61, steps_per_frame=190, penetration=0.004, seqs=("mi-trot", "mi-spin", "mi-turn"))
+    rng = np.random.RandomState(61)
+    inp["qd_init"] = (rng.randn(*inp["qd_init"].shape) * 0.4).astype(np.float32)      # kicked: feet leave and hit the ground
+    dm = hip_backend.DeviceModel(tpl)
+    dm.set_kernel_family(family)
+    FWD = ("q_init", "qd_init", "torques", "res_f", "refs", "target_ke", "target_kd", "body_inv_mass", "body_inertia", "body_inv_inertia")
+    t = {k: torch.from_numpy(np.ascontiguousarray(inp[k], dtype=np.float32)).to(dev) for k in INPUT_NAMES}
+    pos, vel, grf, jaf, ws = dm.rollout_forward(bs, T, inp["dt"], *[t[k] for k in FWD], frame2step=list(inp["frame2step"]))
+    assert dm.last_launch_info(0)["threads_per_wg"] % 192 == 0   # body, contact and cull wave per env group
+    bq, bqd, bf, mask = dm.saved_trajectory(ws, bs, T)
+    traj = dict(states_q=bq.cpu().numpy(), states_qd=bqd.cpu().numpy(), states_f=bf.cpu().numpy())
+    assert np.isfinite(traj["states_q"]).all()
+    rc = RefC(tpl, np.float64)
+    st = rc.trajectory_state(traj, inp)
+    log = dm.saved_hit_log(ws, bs, T)             # [T, bs, 32]
+    tch = rc.touch_fp32(st, cap=32)               # [T, bs, 32]
+    ok = log[..., 0] >= 0
+    n_t = tch[..., 0]
+    missing = 0
+    for j in range(31):
+        has = (j < n_t) & ok
+        if not has.any():
+            break
+        k = tch[..., 1 + j]
+        missing += int((has & ~(log[..., 1:] == k[..., None]).any(-1)).sum())
+    changes = int((np.diff(n_t, axis=0) != 0).sum())
+    print("family %d: %d env-steps, touching candidates %d, env-steps whose touch count changed %d, logs that overflowed %d, missing %d" % (
+        family, T * bs, int(n_t.sum()), changes, int((~ok).sum()), missing))
+    assert int(n_t.sum()) > 4 * T * bs and changes > T * bs // 50, (int(n_t.sum()), changes)   # contacts are active (measured: 6 per env-step), made and broken throughout (1 750 changes)
+    assert missing == 0, missing
+
+
 @pytest.mark.parametrize("name,bs", [("human", 1024), ("quad", 2048)])
 def test_role_split_adjoint_is_deterministic_and_batch_invariant(name, bs, dev):
     """k_rollout_bwd3 (integrate + joint wave handing over through polled LDS words, double-buffered records): a race would
