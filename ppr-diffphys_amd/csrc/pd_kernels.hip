@@ -553,6 +553,9 @@ PD_DEV float *lds_setup(const PdDevModel &m, unsigned char *smem, SweepTables &T
 template <int SEGW, int JT, bool SPLIT, bool LOSS = false, bool QUAD = false, bool CULLW = false, bool RUNSUM = false>
 __global__ __launch_bounds__(CULLW ? PD_BLOCK3 : (SPLIT ? PD_BLOCK : PD_FK_BLOCK), CULLW ? 3 : 2) void k_rollout_fwd(PdDevModel m, RolloutArgs a) {
   static_assert(!RUNSUM || (CULLW && !QUAD), "run sums in the hit pass: the lane-per-body kernels with the cull wave");
+  // TRAJC: the contact wave stores planes 0-2 of the trajectory out of the staged records (round 3 measured this a loss, when that wave's idle
+  // window held the cull; with the cull on its own wave: Laikago 2 048 / 4 096 / 8 192 envs forward 0.170 / 0.188 / 0.377 -> 0.166 / 0.186 / 0.371 ms)
+  constexpr bool TRAJC = CULLW && !QUAD;
   static_assert(!QUAD || (SEGW == 64 && SPLIT && JT == PD_JT_REVOLUTE), "quad-lane body wave: one env per wave, revolute-only plain models");
   static_assert(!CULLW || (SPLIT && JT == PD_JT_REVOLUTE), "cull wave: wave-specialised kernels of revolute-only robots (<= 168 VGPRs: three waves per SIMD)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -669,6 +672,14 @@ __global__ __launch_bounds__(CULLW ? PD_BLOCK3 : (SPLIT ? PD_BLOCK : PD_FK_BLOCK
       const int sigA = pair_wait(sig, step + 1);
       __builtin_amdgcn_s_setprio(PD_PRIO_CRITICAL);  // the body wave will wait for this hit pass
       STAMP(7);
+      // TRAJC: this step's state out of the staged record of this lane's body (the body wave restages it only behind hand-over B): this wave,
+      // idle 58 % of the step since the cull has a wave of its own, stores planes 0-2 of the trajectory behind B
+      [[maybe_unused]] v3 ts_p = V3(0, 0, 0), ts_w = ts_p, ts_v = ts_p;
+      [[maybe_unused]] qt ts_q = Q4(0, 0, 0, 1);
+      if constexpr (TRAJC) {
+        const float *r = rec + b * PD_REC;
+        ts_p = ld3(r); ts_q = ld4(r + 3); ts_w = ld3(r + 7); ts_v = ld3(r + 10);
+      }
 #ifdef PD_ALWAYS_REDO   // (checking build: the exact sweep every step -- the speculated passes must give the same bits)
       const bool redo = true;
 #else
@@ -746,6 +757,15 @@ __global__ __launch_bounds__(CULLW ? PD_BLOCK3 : (SPLIT ? PD_BLOCK : PD_FK_BLOCK
       }
       STAMP(12);
       pair_signal(sig + 1, step + 1);  // B: contact wrenches are complete
+      if constexpr (TRAJC) {
+        if (is_body) {
+          float *tj = a.ws + (size_t)step * (PD_TRAJ_G * 4) * N;
+          const unsigned boff16c = (unsigned)((size_t)ec * nb + b) * 16u;
+          stg4(tj, boff16c, make_float4(ts_q.x, ts_q.y, ts_q.z, ts_q.w));
+          stg4(tj + (size_t)4 * N, boff16c, make_float4(ts_w.x, ts_w.y, ts_w.z, ts_v.x));
+          stg4(tj + (size_t)8 * N, boff16c, make_float4(ts_p.x, ts_p.y, ts_p.z, ts_v.y));
+        }
+      }
       const bool cull_now = !CULLW && step % PD_SPEC_K == 0 && step + 1 < a.nsteps;  // state `step` opened an epoch: cull for the steps it serves
       if (!cull_now) __builtin_amdgcn_s_setprio(0);  // (the cull stays urgent: the next hit pass needs its candidates)
       // the adjoint's log is written off the critical path
@@ -1182,9 +1202,11 @@ __global__ __launch_bounds__(CULLW ? PD_BLOCK3 : (SPLIT ? PD_BLOCK : PD_FK_BLOCK
     //                    inside the divergent region the forced scalar does not compile)
     float *tj = a.ws + oj;
     if (!gw) return;
-    stg4(tj, boff16, make_float4(cs.r.x, cs.r.y, cs.r.z, cs.r.w));
-    stg4(tj + (size_t)4 * N, boff16, make_float4(cs.w.x, cs.w.y, cs.w.z, cs.v.x));
-    stg4(tj + (size_t)8 * N, boff16, make_float4(cs.p.x, cs.p.y, cs.p.z, cs.v.y));
+    if constexpr (!TRAJC) {  // (TRAJC: the contact wave stores these three planes)
+      stg4(tj, boff16, make_float4(cs.r.x, cs.r.y, cs.r.z, cs.r.w));
+      stg4(tj + (size_t)4 * N, boff16, make_float4(cs.w.x, cs.w.y, cs.w.z, cs.v.x));
+      stg4(tj + (size_t)8 * N, boff16, make_float4(cs.p.x, cs.p.y, cs.p.z, cs.v.y));
+    }
     if (cfr >= 0) {  // frame gather (dp_model.py:1231-1248)
       float *o = a.wp_pos + ((size_t)cfr * N + idx) * 7;
       o[0] = cs.p.x; o[1] = cs.p.y; o[2] = cs.p.z; o[3] = cs.r.x; o[4] = cs.r.y; o[5] = cs.r.z; o[6] = cs.r.w;
